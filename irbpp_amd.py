@@ -1,0 +1,13 @@
+"""Import shim: the package directory is ``ir-bpp_amd/`` (not a valid Python
+identifier), so ``import irbpp_amd`` loads it under this importable name."""
+import importlib.util
+import os
+import sys
+
+_pkg_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ir-bpp_amd")
+_spec = importlib.util.spec_from_file_location(
+    "irbpp_amd", os.path.join(_pkg_dir, "__init__.py"),
+    submodule_search_locations=[_pkg_dir])
+_mod = importlib.util.module_from_spec(_spec)
+sys.modules["irbpp_amd"] = _mod
+_spec.loader.exec_module(_mod)
