@@ -1,0 +1,350 @@
+#!/usr/bin/env python
+"""Generate golden vectors by running the REFERENCE'S OWN Python in the build container.
+
+Run from the repo root (only where /root/reference exists -- never on the GPU box):
+
+    python tests/golden/make_golden.py
+
+What executes from /root/reference, unmodified:
+    environment/physics0/space.py     Space.__init__, reset, get_possible_position
+    environment/physics0/cvTools.py   find_out_contour, find_convex_vetex, convexHulls,
+                                      getConvexHullActions
+    environment/physics0/IRcreator.py ItemCreator, LoadItemCreator
+    environment/physics0/binPhy.py    PackingGame.__init__/reset/cur_observation/
+                                      get_action_candidates/action_to_position/prejudge/
+                                      step/get_ratio/get_item_ratio
+    environment/physics0/Interface.py Interface.simulateHeight, adjustHeight, get_wraped_AABB,
+                                      get_Wraped_Position_And_Orientation (inherited)
+    wrapper/shmem_vec_env.py:141-144  auto-reset, wrapper/monitor.py:58-75 episode info
+                                      (re-enacted inline; those modules need a gym install)
+
+What is substituted, because the third-party package is absent from this image
+(pybullet, trimesh, cv2, gym, transforms3d) -- the substitutions are the
+"parity unpinned" pieces named in DESIGN.md:
+    cv2.findContours / cv2.approxPolyDP -> oracle/contours.py (restated OpenCV 4.4 algorithm)
+    Interface's pybullet/trimesh state  -> kinematic AABB (FLB + extents), below
+    Space.place_item_trimesh            -> the closed form of space.py:213
+    transforms3d / gym                  -> minimal stand-ins (rotation about z; Env/spaces shells)
+    np.int / np.float                   -> aliases removed from numpy >= 1.24 are restored (= int, float)
+
+Outputs: tests/golden/*.npz (compressed, small) consumed by tests/test_golden.py.
+"""
+import os
+import sys
+import tempfile
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REF = "/root/reference"
+sys.path.insert(0, ROOT)
+
+from oracle import contours as ocontours  # noqa: E402
+import irbpp_amd  # noqa: E402,F401
+from irbpp_amd import synthetic  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+# ---------------------------------------------------------------------------------------------
+# stand-ins for absent third-party modules
+# ---------------------------------------------------------------------------------------------
+np.int = int          # binPhy.py:235, tools.py:382
+np.float = float      # space.py:73
+
+
+def _install_stubs():
+    cv2 = types.ModuleType("cv2")
+    cv2.RETR_TREE, cv2.CHAIN_APPROX_SIMPLE = 3, 2
+
+    def findContours(image, mode, method):
+        assert mode == cv2.RETR_TREE and method == cv2.CHAIN_APPROX_SIMPLE
+        c, h, _ = ocontours.find_contours(image)
+        return c, h
+
+    cv2.findContours = findContours
+    cv2.approxPolyDP = lambda curve, eps, closed: ocontours.approx_poly_dp(curve, eps, closed)
+    sys.modules["cv2"] = cv2
+
+    for name in ("pybullet", "trimesh"):
+        sys.modules[name] = types.ModuleType(name)
+
+    t3d = types.ModuleType("transforms3d")
+    euler = types.ModuleType("transforms3d.euler")
+    quats = types.ModuleType("transforms3d.quaternions")
+
+    def euler2mat(ai, aj, ak, axes="sxyz"):
+        # the reference only ever needs rotations about z for ZRotList (tools.py:61-68);
+        # the x/y ones build DownFaceList of which entry 0 (identity) alone is used.
+        c, s = np.cos(ak), np.sin(ak)
+        return np.array([[c, -s, 0.0], [s, c, 0.0], [0.0, 0.0, 1.0]])
+
+    def mat2quat(m):
+        ang = np.arctan2(m[1, 0], m[0, 0])
+        return np.array([np.cos(ang / 2), 0.0, 0.0, np.sin(ang / 2)])      # wxyz
+
+    euler.euler2mat, quats.mat2quat = euler2mat, mat2quat
+    t3d.euler, t3d.quaternions = euler, quats
+    sys.modules.update({"transforms3d": t3d, "transforms3d.euler": euler, "transforms3d.quaternions": quats})
+
+    gym = types.ModuleType("gym")
+
+    class Env(object):
+        pass
+
+    class Box(object):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.low, self.high, self.shape, self.dtype = low, high, shape, dtype
+
+    class Discrete(object):
+        def __init__(self, n):
+            self.n = n
+
+    spaces = types.ModuleType("gym.spaces")
+    spaces.Box, spaces.Discrete = Box, Discrete
+    envs = types.ModuleType("gym.envs")
+    reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda **kw: None
+    envs.registration = reg
+    gym.Env, gym.spaces, gym.envs = Env, spaces, envs
+    gym.make = None
+    sys.modules.update({"gym": gym, "gym.spaces": spaces, "gym.envs": envs, "gym.envs.registration": reg})
+
+
+_install_stubs()
+sys.path.insert(0, REF)
+import environment.physics0.Interface as ref_interface  # noqa: E402
+import environment.physics0.binPhy as ref_binphy  # noqa: E402
+import environment.physics0.cvTools as ref_cvtools  # noqa: E402
+import environment.physics0.IRcreator as ref_ircreator  # noqa: E402
+import environment.physics0.space as ref_space  # noqa: E402
+
+
+class _Mesh(object):
+    """What binPhy/space read from a trimesh object on this path: ``.extents``."""
+
+    def __init__(self, extents):
+        self.extents = np.array(extents, dtype=np.float64)
+
+
+class KinematicInterface(ref_interface.Interface):
+    """The reference Interface with pybullet/trimesh state replaced by FLB + extents.
+    simulateHeight / adjustHeight / the get_wraped_* wrappers are INHERITED from the reference."""
+
+    shapes = None          # set per scenario
+
+    def __init__(self, bin=None, foldername=None, visual=False, scale=None, simulationScale=None, maxBatch=2):
+        self.defaultScale = np.array(scale, dtype=np.float64)
+        self.bin = np.round(np.array(bin) * self.defaultScale, decimals=6)        # Interface.py:39-40
+        self.objs, self.objsDynamic = [], []
+        self.flb, self.ext, self.quat = {}, {}, {}
+
+    def close(self):
+        pass
+
+    def reset(self):
+        self.objs, self.objsDynamic = [], []
+        self.flb, self.ext, self.quat = {}, {}, {}
+
+    def addObject(self, name, targetFLB=None, rotation=None, scale=None, density=1.0,
+                  linearDamping=0.1, angularDamping=0.1, path=None, color=None):
+        if scale is None:
+            scale = self.defaultScale
+        targetFLB = np.array(targetFLB) * scale                                   # Interface.py:201
+        ang = 2.0 * np.arctan2(rotation[2], rotation[3])                          # xyzw, rotation about z
+        deg = np.degrees(ang) % 360.0
+        rot = int(np.argmin([min(abs(deg - d), 360 - abs(deg - d)) for d in synthetic.ROT_DEGREES[:self.shapes.n_rot]]))
+        oid = len(self.objs)
+        self.flb[oid] = targetFLB.astype(np.float64)
+        self.ext[oid] = self.shapes.extents[int(name)][rot] * scale[0]            # mesh.apply_scale (Interface.py:208)
+        self.quat[oid] = np.array(rotation, dtype=np.float64)
+        self.objs.append(oid)
+        self.objsDynamic.append(oid)
+        return oid
+
+    def disableObject(self, id, targetZ=None):
+        pass
+
+    def get_trimesh_AABB(self, id, inner=True):
+        bounds = np.array([self.flb[id], self.flb[id] + self.ext[id]])
+        if not inner:
+            bounds = bounds / self.defaultScale
+        return bounds
+
+    def get_trimesh_Position_And_Orientation(self, id, inner=True, getPosBase=False):
+        bounds = self.get_trimesh_AABB(id, inner)
+        out = [np.array(bounds[0]), np.array(self.quat[id])]
+        if getPosBase:
+            out.append(np.array(bounds[0]))
+        return out
+
+    def reset_trimesh_height(self, id, targetHeight):
+        self.flb[id][2] = targetHeight
+
+    def getAllPositionAndOrientation(self, inner=True):
+        pos = [self.get_trimesh_AABB(i, inner)[0] for i in self.objs]
+        ori = [self.quat[i] for i in self.objs]
+        return pos, ori
+
+
+def _place_closed_form(self, mesh, poseT, debugInfo):
+    """space.py:213 in place of the trimesh ray cast of space.py:75-94."""
+    bounds, item_id = debugInfo
+    positionT, orientationT = poseT
+    ang = np.degrees(2.0 * np.arctan2(orientationT[2], orientationT[3])) % 360.0
+    rot = int(np.argmin([min(abs(ang - d), 360 - abs(ang - d)) for d in synthetic.ROT_DEGREES[:self.rotNum]]))
+    lx = int(round(bounds[0][0] / self.resolutionAct))
+    ly = int(round(bounds[0][1] / self.resolutionAct))
+    heightMapT, heightMapB, maskH, maskB = self.shotInfo[item_id][rot]
+    posZ = self.posZmap[rot, lx, ly]
+    X, Y = lx * self.stepSize, ly * self.stepSize
+    fx, fy = heightMapT.shape
+    self.heightmapC[X:X + fx, Y:Y + fy] = np.max(((heightMapT + posZ) * maskH,
+                                                  self.heightmapC[X:X + fx, Y:Y + fy]), axis=0)
+
+
+ref_binphy.Interface = KinematicInterface
+ref_space.Space.place_item_trimesh = _place_closed_form
+
+
+def make_reference_env(shapes, sequences, buffer_size=1, selected=500, res_a=0.02, res_h=0.01, res_z=0.01):
+    tmp = tempfile.mkdtemp()
+    dic = os.path.join(tmp, "id2shape.pt")
+    torch.save({k: "%d.obj" % k for k in range(shapes.n_shapes)}, dic)
+    seqp = os.path.join(tmp, "test_sequence.pt")
+    torch.save([list(map(int, row)) for row in sequences], seqp)
+    KinematicInterface.shapes = shapes
+    shapeDict = {k: [_Mesh(shapes.extents[k][r]) for r in range(shapes.n_rot)] for k in range(shapes.n_shapes)}
+    args = types.SimpleNamespace(
+        resolutionA=res_a, resolutionH=res_h, resolutionZ=res_z,
+        bin_dimension=np.round([0.32, 0.32, 0.30], decimals=6), scale=[100, 100, 100],
+        objPath=tmp, meshScale=1, shapeDict=shapeDict, infoDict=shapes.info_dict(), dicPath=dic,
+        ZRotNum=shapes.n_rot, heightMap=True, only_simulate_current=True, selectedAction=selected,
+        bufferSize=buffer_size, simulation=False, evaluate=True, maxBatch=2, dataSample="instance",
+        test_name=seqp, visual=False, non_blocking=False, time_limit=0.01, shotInfo=shapes.shot_info())
+    return ref_binphy.PackingGame(args)
+
+
+def minz_action(obs, S):
+    """Scripted policy shared by every implementation: lowest-H valid candidate, first on ties."""
+    c = np.asarray(obs[:5 * S]).reshape(S, 5)
+    v = c[:, 4] == 1
+    if not v.any():
+        return 0
+    return int(np.argmin(np.where(v, c[:, 3], np.inf)))
+
+
+def run_online(shapes, sequences, steps, S=500, res_h=0.01):
+    env = make_reference_env(shapes, sequences, 1, S, res_h=res_h)
+    obs = env.reset()
+    rec = dict(obs=[obs.copy()], act=[], rew=[], done=[], counter=[], ratio=[], ep_r=[],
+               mask=[env.space.naiveMask.copy()], posz=[env.space.posZmap.copy()])
+    rewards = []
+    for _ in range(steps):
+        a = minz_action(obs, S)
+        obs, r, d, info = env.step(a)
+        rewards.append(r)
+        rec["act"].append(a); rec["rew"].append(r); rec["done"].append(d)
+        rec["counter"].append(info.get("counter", -1)); rec["ratio"].append(info.get("ratio", -1.0))
+        if d:                                           # shmem_vec_env.py:142-144, monitor.py:62-64
+            rec["ep_r"].append(round(sum(rewards), 6)); rewards = []
+            obs = env.reset()
+        else:
+            rec["ep_r"].append(-1.0)
+        rec["obs"].append(obs.copy())
+        rec["mask"].append(env.space.naiveMask.copy()); rec["posz"].append(env.space.posZmap.copy())
+    return {k: np.array(v) for k, v in rec.items()}
+
+
+def run_hier(shapes, sequences, steps, k, S=500):
+    env = make_reference_env(shapes, sequences, k, S)
+    order_obs = env.reset()
+    rec = dict(order_obs=[order_obs.copy()], loc_obs=[], order_act=[], act=[], rew=[], done=[],
+               counter=[], ratio=[])
+    for t in range(steps):
+        oa = (t * 7 + 3) % k                            # scripted order policy: cycles over the buffer
+        loc = env.get_action_candidates(oa)
+        a = minz_action(loc, S)
+        order_obs, r, d, info = env.step(a)
+        rec["order_act"].append(oa); rec["loc_obs"].append(np.array(loc)); rec["act"].append(a)
+        rec["rew"].append(r); rec["done"].append(d)
+        rec["counter"].append(info.get("counter", -1)); rec["ratio"].append(info.get("ratio", -1.0))
+        if d:
+            order_obs = env.reset()
+        rec["order_obs"].append(order_obs.copy())
+    return {k2: np.array(v) for k2, v in rec.items()}
+
+
+def cvtools_cases(n_cases=48, seed=7):
+    """Random (posZValid, naiveMask) grids through the reference's getConvexHullActions."""
+    rng = np.random.RandomState(seed)
+    posz, mask, cand, cand_len = [], [], [], []
+    for i in range(n_cases):
+        R = [2, 4, 8][i % 3]
+        m = np.zeros((R, 16, 16))
+        z = np.full((R, 16, 16), 1e3)
+        for r in range(R):
+            kind = rng.randint(4)
+            if kind == 0:       # blocky plateaus on a 1 cm lattice
+                lv = np.kron(rng.randint(0, 6, size=(4, 4)), np.ones((4, 4))) * 0.03
+            elif kind == 1:     # fine random levels
+                lv = rng.randint(0, 30, size=(16, 16)) * 0.01
+            elif kind == 2:     # smooth ramp with float noise
+                lv = np.add.outer(np.arange(16), np.arange(16)) * 0.007 + rng.uniform(0, 1e-3, (16, 16))
+            else:               # nested rings (holes and islands)
+                g = np.maximum(np.abs(np.arange(16)[:, None] - 7.5), np.abs(np.arange(16)[None, :] - 7.5))
+                lv = (np.floor(g) % 3) * 0.05
+            hx, hy = rng.randint(6, 17, size=2)
+            valid = np.zeros((16, 16), bool)
+            valid[:hx, :hy] = rng.uniform(size=(hx, hy)) < [1.0, 0.9, 0.75][rng.randint(3)]
+            m[r][valid] = 1
+            z[r][valid] = lv[valid]
+        c = ref_cvtools.getConvexHullActions(z, m, 0.01)
+        posz.append(np.pad(z, ((0, 8 - R), (0, 0), (0, 0)), constant_values=1e3))
+        mask.append(np.pad(m, ((0, 8 - R), (0, 0), (0, 0))))
+        c = np.zeros((0, 5)) if c is None else c
+        cand_len.append(len(c))
+        cand.append(np.pad(c, ((0, 2048 - len(c)), (0, 0))))
+    return dict(posz=np.array(posz), mask=np.array(mask), cand=np.array(cand), cand_len=np.array(cand_len),
+                n_rot=np.array([[2, 4, 8][i % 3] for i in range(n_cases)]))
+
+
+def ircreator_trace():
+    """LoadItemCreator (IRcreator.py:74-103) preview/pop/generate trace for k=3."""
+    tmp = tempfile.mkdtemp()
+    p = os.path.join(tmp, "seq.pt")
+    seqs = [[10 * t + i for i in range(8)] for t in range(4)]
+    torch.save(seqs, p)
+    c = ref_ircreator.LoadItemCreator(data_name=p)
+    trace = []
+    for ep in range(2):
+        c.reset()
+        for pop in (1, 0, 2, 2, 1, 0, 0, 1):
+            view = c.preview(3)
+            trace.append([(-1 if v is None else v) for v in view] + [pop, c.traj_index])
+            c.update_item_queue(pop)
+            c.generate_item()
+    return dict(seqs=np.array(seqs), trace=np.array(trace))
+
+
+def main():
+    cube = synthetic.cube_shapes()
+    blk = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    gen = synthetic.general_shapes(n_shapes=16, n_rot=8, seed=1)
+    seq_c = synthetic.make_sequences(cube.n_shapes, 16, 60, seed=123)
+    seq_b = synthetic.make_sequences(blk.n_shapes, 16, 150, seed=5)
+    seq_g = synthetic.make_sequences(gen.n_shapes, 16, 60, seed=9)
+    np.savez_compressed(os.path.join(OUT, "online_cube.npz"), seq=seq_c, **run_online(cube, seq_c, 70))
+    np.savez_compressed(os.path.join(OUT, "online_blockout.npz"), seq=seq_b, **run_online(blk, seq_b, 120))
+    np.savez_compressed(os.path.join(OUT, "online_general.npz"), seq=seq_g, **run_online(gen, seq_g, 40))
+    np.savez_compressed(os.path.join(OUT, "hier_blockout_k3.npz"), seq=seq_b, **run_hier(blk, seq_b, 90, 3))
+    np.savez_compressed(os.path.join(OUT, "cvtools_cases.npz"), **cvtools_cases())
+    np.savez_compressed(os.path.join(OUT, "ircreator_trace.npz"), **ircreator_trace())
+    for f in sorted(os.listdir(OUT)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(OUT, f)))
+
+
+if __name__ == "__main__":
+    main()
