@@ -1,0 +1,220 @@
+#!/usr/bin/env python
+"""bench.py -- placement-steps/s of the batched packing environment on N MI355X.
+
+One "step" = one batched transition of every bin on this rank: the scripted MINZ policy kernel
+picks an action from the device-resident observation, then the fused transition kernel applies
+it (placement, reward, termination, auto-reset) and produces the next observation.  Inputs
+(shape tables, trajectories, heightmaps, observations) are resident in HBM before the timed
+region; nothing crosses PCIe inside it.
+
+Workload at N=1: BASELINE.json configs[1] -- BlockOut online (bufferSize=1), 4096 bins per
+GPU, resolutionA=0.02, resolutionH=0.01, R=4, S=500 (synthetic polycubes).
+Multi-GPU: bins are sharded, no data-path collective; one RCCL all-reduce of the episode
+totals after the timed region ("weak" scaling: 4096 bins per GPU).
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import irbpp_amd  # noqa: E402,F401
+from irbpp_amd import synthetic  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md chip table)
+S = 500
+
+
+def make_workload(name):
+    if name == "blockout":
+        shapes = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 160, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.01)
+    elif name == "general":
+        shapes = synthetic.general_shapes(n_shapes=256, n_rot=8, seed=1)
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 100, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.01)
+    elif name == "abc_fine":
+        shapes = synthetic.general_shapes(n_shapes=256, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=1)
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 100, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.005)
+    elif name == "cube":
+        shapes = synthetic.cube_shapes()
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 100, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.01)
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    return shapes, seqs, kw
+
+
+def algorithmic_bytes_per_step(shapes, hc, k=1):
+    """compulsory HBM bytes of one placement-step of one bin.  The master
+    heightmap is float64 in HBM (8*Hc in and out); footprint tables are priced at the survey's
+    external layout (4-byte height + 1-byte mask per cell); the observation is float32."""
+    f = np.array([[t[0].size for t in per_rot] for per_rot in shapes.tables], dtype=np.float64)   # [n, R]
+    sum_r = f.sum(axis=1).mean()          # all rotations of the next item (overlap test)
+    f_star = f.mean()                     # the placed rotation (heightmap update)
+    reads = 8 * hc + 5 * sum_r + 5 * f_star + 4 + 4 * k
+    writes = 8 * hc + 4 * (5 * S + 9 + hc) + 5
+    if k > 1:
+        writes += 4 * (k + hc)
+    return float(reads + writes)
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the oracle (a restatement of the reference's numpy path) on the host cores
+# ---------------------------------------------------------------------------------------------
+def _cpu_worker(args):
+    name, rank, envs_per_proc, steps = args
+    sys.path.insert(0, ROOT)
+    from oracle.packing import OracleVecEnv
+    shapes, seqs, kw = make_workload(name)
+    env = OracleVecEnv(envs_per_proc, shapes, seqs, global_offset=rank * envs_per_proc, global_num=1 << 20, **kw)
+    obs = env.reset()
+
+    def minz(o):
+        c = o[:5 * S].reshape(S, 5)
+        v = c[:, 4] == 1
+        return int(np.argmin(np.where(v, c[:, 3], np.inf))) if v.any() else 0
+
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        obs, _, _, _ = env.step([minz(o) for o in obs])
+    return time.perf_counter() - t0
+
+
+def cpu_baseline(name, budget_s=15.0):
+    cores = os.cpu_count() or 1
+    envs_per_proc = 1
+    probe = _cpu_worker((name, 0, 1, 3)) / 3.0                  # seconds per env-step on one core
+    steps = max(4, int(budget_s / max(probe, 1e-4)))
+    steps = min(steps, 2000)
+    ctx = mp.get_context("fork")
+    with ctx.Pool(cores) as pool:
+        t0 = time.perf_counter()
+        pool.map(_cpu_worker, [(name, r, envs_per_proc, steps) for r in range(cores)])
+        wall = time.perf_counter() - t0
+    total = cores * envs_per_proc * steps
+    return {"value": total / wall, "unit": "placement-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x {envs_per_proc} bin x {steps} steps of the python/numpy oracle "
+                      f"(process-per-bin like shmem_vec_env; no physics, which flatters the CPU side)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU")
+    ap.add_argument("--workload", default="blockout")
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    cpu = None
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.workload, a.cpu_budget)       # before HIP is initialised: the pool forks
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from irbpp_amd.vec_env import GpuPackingEnv
+    shapes, seqs, kw = make_workload(a.workload)
+    env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, global_offset=rank * a.bins,
+                        global_bins=world * a.bins, contour_slots=a.slots, **kw)
+    hc = env.Hx * env.Hy
+    obs_a = env.reset()
+    obs_b = torch.empty_like(obs_a)
+    act = torch.empty((a.bins,), dtype=torch.int32, device=dev)
+
+    def one_step(src, dst, ev=None):
+        env.policy_minz(src, actions_out=act)
+        if ev is not None:
+            ev[0].record()
+        env.step(act, obs_out=dst)
+        if ev is not None:
+            ev[1].record()
+
+    cur, nxt = obs_a, obs_b
+    for _ in range(a.warmup):
+        one_step(cur, nxt)
+        cur, nxt = nxt, cur
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        one_step(cur, nxt, events[i])
+        cur, nxt = nxt, cur
+    barrier()
+    elapsed = time.perf_counter() - t0
+    env.check_device_error()
+
+    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))     # transition kernel only
+    tot = env.episode_totals()
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)       # the only exchange: 4 doubles of episode statistics
+    elapsed = float(t_max.item())
+    tot = tot.cpu().numpy()
+
+    if rank == 0:
+        total_steps = a.bins * world * a.steps
+        bps = algorithmic_bytes_per_step(shapes, hc, 1)
+        achieved = bps * a.bins / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
+        if os.path.exists(prof):
+            try:
+                traffic = json.load(open(prof)).get(a.workload, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "env steps/sec (placements/sec) across N parallel bins",
+            "value": total_steps / elapsed, "unit": "placement-steps/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload} online (bufferSize=1), {a.bins} bins/GPU, resolutionA=0.02 "
+                                   f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy",
+                       "bins_per_gpu": a.bins, "global_bins": a.bins * world, "parallelism": f"bins sharded x{world}"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel": "irbpp_env_kernel", "kernel_ms": kernel_ms,
+                         "algorithmic_bytes_per_step": bps},
+            "episodes": {"finished": float(tot[0]), "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
+                         "mean_items": float(tot[2] / tot[0]) if tot[0] else None},
+        }
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        print(json.dumps(out), flush=True)
+    env.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

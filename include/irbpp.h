@@ -1,0 +1,160 @@
+/*
+ * irbpp.h -- C ABI of the MI355X-native batched packing environment (libirbpp_hip.so).
+ *
+ * The reference (alexfrom0815/IR-BPP) has no FFI: its environment is Python behind the
+ * VecEnv protocol (wrapper/vec_env.py:29-138, wrapper/shmem_vec_env.py:20-157).  This
+ * header is the boundary a maintainer binds instead of spawning one process per bin:
+ * each entry point names the reference interface it replaces.  INTEGRATION.md shows the
+ * ctypes stub.
+ *
+ * Conventions
+ *   - every function returns 0 (IRBPP_OK) or a negative irbpp_status; no exceptions cross
+ *     the ABI; irbpp_status_string() explains a code.
+ *   - "_dev" pointers are caller-owned device (HBM) memory; everything else is host memory.
+ *   - launches are asynchronous on the given hipStream_t (passed as void*; NULL = the null
+ *     stream); a handle is not thread-safe; one outstanding step per handle (the
+ *     reference's `waiting_step` rule, shmem_vec_env.py:58-74).
+ *   - observation buffers are written in full on every call, so the caller may hand a
+ *     fresh buffer each step (trainer.py:184-186 keeps the previous `state` alive).
+ */
+#ifndef IRBPP_H
+#define IRBPP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct irbpp_env irbpp_env;
+
+typedef enum {
+    IRBPP_OK = 0,
+    IRBPP_ERR_ARG = -1,        /* bad argument / unsupported configuration          */
+    IRBPP_ERR_HIP = -2,        /* a HIP runtime call failed                          */
+    IRBPP_ERR_STATE = -3,      /* call order (e.g. step before load_shapes/reset)    */
+    IRBPP_ERR_DEVICE = -4,     /* a kernel raised its error word (see irbpp_device_error) */
+    IRBPP_ERR_NOMEM = -5
+} irbpp_status;
+
+/* Geometry and episode parameters: PackingGame.__init__ (binPhy.py:22-116),
+ * Space.__init__ (space.py:15-47), Interface.__init__ (Interface.py:33-40). */
+typedef struct {
+    int32_t num_bins;        /* bins simulated on this device                                   */
+    int32_t n_rot;           /* ZRotNum (arguments.py:117), 1..8                                 */
+    int32_t selected;        /* selectedAction S (arguments.py:79), 1..1024                      */
+    int32_t buffer_size;     /* bufferSize k (arguments.py:75); >1 = hierarchical, 1..16         */
+    double  resolution_a;    /* resolutionA                                                      */
+    double  resolution_h;    /* resolutionH                                                      */
+    double  resolution_z;    /* resolutionZ = heightResolution (arguments.py:84,125)             */
+    double  bin[3];          /* np.round([0.32,0.32,0.30], 6) (arguments.py:115)                 */
+    double  scale_z;         /* Interface scale[2] = 100 (arguments.py:123)                      */
+    int32_t traj_start;      /* trajectory of global bin 0's first episode; 1 = LoadItemCreator
+                                (IRcreator.py:86-92 increments before first use)                */
+    int32_t global_offset;   /* global index of this device's bin 0 (multi-GPU sharding)         */
+    int32_t global_bins;     /* bins over all ranks = trajectory stride between episodes         */
+    int32_t device;          /* HIP device ordinal                                               */
+    int32_t contour_slots;   /* 0 = default; contour tasks traced concurrently per bin           */
+} irbpp_config;
+
+/* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
+ * adds on `done` (binPhy.py:299-311,327; monitor.py:58-75).  All device pointers, one entry
+ * per bin; any pointer may be NULL to skip that output. */
+typedef struct {
+    double*  reward_dev;      /* reward of this step (item_ratio*10 or 0.0)                      */
+    uint8_t* done_dev;        /* 1 iff the episode ended with this step                          */
+    int32_t* counter_dev;     /* info['counter'] = items packed, valid where done                */
+    double*  ratio_dev;       /* info['ratio']   = get_ratio(),  valid where done                */
+    double*  ep_reward_dev;   /* sum of the episode's rewards (Monitor 'r' before round(.,6))    */
+    int32_t* ep_len_dev;      /* Monitor 'l'                                                     */
+} irbpp_step_out;
+
+const char* irbpp_status_string(int status);
+int irbpp_version(void);
+
+/* replaces: gym.make('Physics-v0', args=args) x num_processes + ShmemVecEnv.__init__
+ * (envs.py:67-99, shmem_vec_env.py:25-59) */
+int irbpp_create(const irbpp_config* cfg, irbpp_env** out);
+/* replaces: ShmemVecEnv.close_extras (shmem_vec_env.py:83-92) */
+int irbpp_destroy(irbpp_env* env);
+
+/* replaces: args.shotInfo / args.infoDict built by shotInfoPre + load_shape_dict
+ * (tools.py:227-279).  Shape id k, rotation r owns four [fx,fy] row-major float64 tables
+ * starting at pool offset offsets[k*n_rot+r]; dims[(k*n_rot+r)*2 + {0,1}] = fx, fy;
+ * extents[(k*n_rot+r)*3 + {0,1,2}] = mesh.extents; volumes[k] = infoDict[k][0]['volume'].
+ * Masks must be exactly 0.0 or 1.0.  All host pointers; copied. */
+int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes,
+                      const double* extents, const double* volumes,
+                      const int32_t* dims, const int64_t* offsets, int64_t pool_len,
+                      const double* height_top, const double* height_bottom,
+                      const double* mask_top, const double* mask_bottom);
+
+/* replaces: LoadItemCreator.item_trajs = torch.load(test_sequence.pt) (IRcreator.py:81) and
+ * the pre-drawn np.random.choice stream of the Random*Creator classes (IRcreator.py:26-72).
+ * ids: int32[n_traj][length] host memory, copied. */
+int irbpp_load_sequences(irbpp_env* env, const int32_t* ids, int32_t n_traj, int32_t length);
+
+/* obs_len of PackingGame (binPhy.py:87-98): which=0 the observation reset()/step() return
+ * (5S+9+Hx*Hy when k==1, k+Hx*Hy when k>1); which=1 the location observation of
+ * get_action_candidates (5S+9+Hx*Hy). */
+int irbpp_obs_len(const irbpp_env* env, int32_t which);
+
+/* replaces: ShmemVecEnv.reset (shmem_vec_env.py:61-68) -> PackingGame.reset (binPhy.py:128-147).
+ * obs_dev: float32[num_bins][obs_len(0)].  Restarts the trajectory counters. */
+int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream);
+
+/* replaces: ShmemVecEnv.step_async+step_wait (shmem_vec_env.py:70-81) -> PackingGame.step
+ * (binPhy.py:248-337, no-physics branch) + the worker's auto-reset (shmem_vec_env.py:141-144).
+ * actions_dev: int32[num_bins] indices into the candidate rows of the last location
+ * observation.  obs_dev: float32[num_bins][obs_len(0)]; for a finished episode it already
+ * holds the next episode's first observation. */
+int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev,
+               const irbpp_step_out* out, void* stream);
+
+/* replaces: ShmemVecEnv.get_action_candidates (shmem_vec_env.py:99-102) ->
+ * PackingGame.get_action_candidates (binPhy.py:161-169).  order_actions_dev: int32[num_bins]
+ * buffer slots; loc_obs_dev: float32[num_bins][obs_len(1)].  Hierarchical mode only. */
+int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev,
+                                float* loc_obs_dev, void* stream);
+
+/* The scripted policy used by the benchmark and the parity tests: per bin the candidate
+ * row with V==1 and the lowest H (first on ties), 0 if none.  loc_obs_dev has row stride
+ * obs_stride floats.  (Stands in for agent.py:51-58 so no host round trip is timed.) */
+int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stride,
+                      int32_t* actions_dev, void* stream);
+
+/* -- stage-level entry points (parity tests and tooling) ------------------------------- */
+
+/* Space.get_possible_position (space.py:98-129) for item_ids_dev[b] on bin b's current
+ * heightmap.  posz_dev: float64[num_bins][n_rot][Ax][Ay] = posZmap; mask_dev:
+ * uint8[num_bins][n_rot][Ax][Ay] = naiveMask.  Does not modify the environment. */
+int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev,
+                            double* posz_dev, uint8_t* mask_dev, void* stream);
+
+/* getConvexHullActions (cvTools.py:61-102) on caller-supplied grids, independent of the
+ * environment state: posz_valid_dev float64[n_grids][n_rot][Ax][Ay], mask_dev
+ * uint8[n_grids][n_rot][Ax][Ay].  vertex_rows_dev: uint32[n_grids][n_rot][Ax], bit y of word
+ * x... see DESIGN.md: word `row` has bit `col` set iff (row, col) is a candidate. */
+int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev,
+                              const uint8_t* mask_dev, uint32_t* vertex_rows_dev, void* stream);
+
+/* Space.heightmapC of every bin (space.py:26): float64[num_bins][Hx][Hy]. */
+int irbpp_get_heightmaps(irbpp_env* env, double* hm_dev, void* stream);
+int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream);
+
+/* Running totals over finished episodes since create/reset, for logging
+ * (trainer.py:215-222): out_dev float64[4] = {episodes, sum ratio, sum counter, sum reward}.
+ * The multi-GPU runner all-reduces these four numbers (RCCL). */
+int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream);
+
+/* Device-side error word raised by kernels (0 = none).  Synchronises the stream. */
+int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
+
+#define IRBPP_DEVERR_LEVEL_RANGE   1   /* a height level fell outside the 64 supported bins  */
+#define IRBPP_DEVERR_TRACE_GUARD   2   /* border following exceeded its iteration guard      */
+#define IRBPP_DEVERR_BAD_ITEM      4   /* item id outside the loaded shape table             */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRBPP_H */

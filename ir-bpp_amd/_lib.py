@@ -1,0 +1,79 @@
+"""ctypes binding of libirbpp_hip.so (include/irbpp.h).  There is no CPU fallback: if the
+library is missing or a symbol is absent, importing the binding raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from .build import LIB_PATH
+
+c_i32_p = C.POINTER(C.c_int32)
+c_f64_p = C.POINTER(C.c_double)
+
+
+class IrbppConfig(C.Structure):
+    _fields_ = [
+        ("num_bins", C.c_int32), ("n_rot", C.c_int32), ("selected", C.c_int32), ("buffer_size", C.c_int32),
+        ("resolution_a", C.c_double), ("resolution_h", C.c_double), ("resolution_z", C.c_double),
+        ("bin", C.c_double * 3), ("scale_z", C.c_double),
+        ("traj_start", C.c_int32), ("global_offset", C.c_int32), ("global_bins", C.c_int32),
+        ("device", C.c_int32), ("contour_slots", C.c_int32),
+    ]
+
+
+class IrbppStepOut(C.Structure):
+    _fields_ = [("reward_dev", C.c_void_p), ("done_dev", C.c_void_p), ("counter_dev", C.c_void_p),
+                ("ratio_dev", C.c_void_p), ("ep_reward_dev", C.c_void_p), ("ep_len_dev", C.c_void_p)]
+
+
+# every entry point include/irbpp.h declares: name -> (restype, argtypes)
+SIGNATURES = {
+    "irbpp_status_string": (C.c_char_p, [C.c_int]),
+    "irbpp_version": (C.c_int, []),
+    "irbpp_create": (C.c_int, [C.POINTER(IrbppConfig), C.POINTER(C.c_void_p)]),
+    "irbpp_destroy": (C.c_int, [C.c_void_p]),
+    "irbpp_load_shapes": (C.c_int, [C.c_void_p, C.c_int32, c_f64_p, c_f64_p, c_i32_p, C.POINTER(C.c_int64),
+                                    C.c_int64, c_f64_p, c_f64_p, c_f64_p, c_f64_p]),
+    "irbpp_load_sequences": (C.c_int, [C.c_void_p, c_i32_p, C.c_int32, C.c_int32]),
+    "irbpp_obs_len": (C.c_int, [C.c_void_p, C.c_int32]),
+    "irbpp_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(IrbppStepOut), C.c_void_p]),
+    "irbpp_get_action_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "irbpp_possible_position": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_convex_hull_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_get_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_set_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_device_error": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p]),
+}
+
+_lib = None
+
+
+def load(path: str = LIB_PATH) -> C.CDLL:
+    """dlopen the HIP library and bind every declared symbol (raises if anything is missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). irbpp_amd has no CPU fallback.")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+class IrbppError(RuntimeError):
+    pass
+
+
+def check(status: int, what: str = "") -> None:
+    if status != 0:
+        msg = load().irbpp_status_string(status).decode()
+        raise IrbppError(f"{what}: {msg} (status {status})")

@@ -1,0 +1,42 @@
+"""Build libirbpp_hip.so in-tree with hipcc for gfx950 (no JIT cache: the .so travels with the repo)."""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(PKG_DIR, "libirbpp_hip.so")
+SOURCES = ["irbpp_capi.hip", "irbpp_kernels.hip", "irbpp_device.h", "contours_device.h",
+           os.path.join("..", "..", "include", "irbpp.h")]
+# -ffp-contract=off: the float64 results must equal numpy's, so no FMA contraction anywhere
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-shared", "-fPIC",
+               "-Wno-unused-value"]
+
+
+def _hipcc() -> str:
+    for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found: the HIP library cannot be built on this machine")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/irbpp_capi.hip (which includes the kernels) into libirbpp_hip.so."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    return LIB_PATH

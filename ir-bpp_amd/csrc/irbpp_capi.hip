@@ -1,0 +1,362 @@
+// irbpp_capi.hip -- host side of libirbpp_hip.so: the C ABI declared in include/irbpp.h.
+//
+// Owns the per-device state in HBM (heightmaps, item queues, candidate keys, counters), packs
+// the shotInfo tables and trajectories once, and launches the transition kernel on the
+// caller's stream.  No torch types, no exceptions across the boundary.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "../../include/irbpp.h"
+#include "irbpp_device.h"
+#include "irbpp_kernels.hip"      // single translation unit: kernels + host ABI
+
+using namespace irbpp;
+
+struct irbpp_env {
+    irbpp_config cfg;
+    Params P;
+    Tables T;
+    State S;
+    bool shapes_loaded = false, seq_loaded = false, was_reset = false;
+    std::vector<void*> allocs;
+};
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        hipError_t _e = (expr);                         \
+        if (_e != hipSuccess) return IRBPP_ERR_HIP;     \
+    } while (0)
+
+namespace {
+
+template <typename T>
+int dev_alloc(irbpp_env* env, T** out, size_t count) {
+    void* p = nullptr;
+    if (hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : sizeof(T)) != hipSuccess) return IRBPP_ERR_NOMEM;
+    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) return IRBPP_ERR_HIP;
+    env->allocs.push_back(p);
+    *out = (T*)p;
+    return IRBPP_OK;
+}
+
+template <typename T>
+int dev_upload(irbpp_env* env, const T** out, const T* host, size_t count) {
+    T* p = nullptr;
+    int rc = dev_alloc(env, &p, count);
+    if (rc != IRBPP_OK) return rc;
+    if (count && hipMemcpy(p, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return IRBPP_ERR_HIP;
+    *out = p;
+    return IRBPP_OK;
+}
+
+inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np.round(x, 6)
+inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
+
+// dynamic-LDS carve-up of the transition kernel
+void layout_lds(Params& P, int want_slots) {
+    P.nslot = want_slots > 0 ? want_slots : 64;
+    if (P.nslot > 256) P.nslot = 256;
+    P.slot_cap = 96;
+    P.slot_stk = 24;
+    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk;              // 352, multiple of 16
+    int32_t off = 0;
+    P.o_hm = off;        off += align16(P.Hc * 8);
+    P.o_posz = off;      off += align16(P.R * P.AC * 8);
+    P.o_lev = off;       off += align16(P.R * P.AC);
+    P.o_present = off;   off += align16(P.R * 8);
+    P.o_taskidx = off;   off += align16(P.R * 64 * 2);
+    P.o_tasklist = off;  off += align16(P.R * 64 * 2);
+    P.o_img = off;       off += align16(P.nslot * 16 * 4);
+    P.o_vmask = off;     off += align16(P.R * 16 * 4);
+    P.o_red = off;       off += 256;
+    int32_t scratch = P.nslot * P.slot_bytes;
+    const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;                 // candidate keys alias the slots
+    if (scratch < keys) scratch = keys;
+    if (scratch < 4096) scratch = 4096;
+    P.o_scratch = off;
+    P.scratch_bytes = align16(scratch);
+    off += P.scratch_bytes;
+    P.lds_bytes = off;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* irbpp_status_string(int status) {
+    switch (status) {
+        case IRBPP_OK: return "ok";
+        case IRBPP_ERR_ARG: return "bad argument or unsupported configuration";
+        case IRBPP_ERR_HIP: return "HIP runtime error";
+        case IRBPP_ERR_STATE: return "call out of order (load shapes and sequences, reset, then step)";
+        case IRBPP_ERR_DEVICE: return "device-side error word set";
+        case IRBPP_ERR_NOMEM: return "out of device memory";
+        default: return "unknown status";
+    }
+}
+
+int irbpp_version(void) { return 100; }
+
+int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
+    if (!cfg || !out) return IRBPP_ERR_ARG;
+    if (cfg->num_bins < 1 || cfg->n_rot < 1 || cfg->n_rot > 8 || cfg->selected < 1 || cfg->selected > 1024 ||
+        cfg->buffer_size < 1 || cfg->buffer_size > 16)
+        return IRBPP_ERR_ARG;
+    if (!(cfg->resolution_a > 0) || !(cfg->resolution_h > 0) || !(cfg->resolution_z > 0)) return IRBPP_ERR_ARG;
+    irbpp_env* env = new (std::nothrow) irbpp_env();
+    if (!env) return IRBPP_ERR_NOMEM;
+    env->cfg = *cfg;
+    memset(&env->T, 0, sizeof(Tables));
+    memset(&env->S, 0, sizeof(State));
+    Params& P = env->P;
+    memset(&P, 0, sizeof(Params));
+    P.N = cfg->num_bins;
+    P.R = cfg->n_rot;
+    P.S = cfg->selected;
+    P.K = cfg->buffer_size;
+    P.res_a = cfg->resolution_a;
+    P.res_h = cfg->resolution_h;
+    P.res_z = cfg->resolution_z;
+    P.bin_x = cfg->bin[0];
+    P.bin_y = cfg->bin[1];
+    P.bin_z = cfg->bin[2];
+    P.bin_vol = cfg->bin[0] * cfg->bin[1] * cfg->bin[2];             // np.prod(bin_dimension)
+    P.scale_z = cfg->scale_z;
+    P.ibin_z = round6_host(cfg->bin[2] * cfg->scale_z);              // Interface.py:39-40
+    // Space.__init__ (space.py:19-24)
+    P.step = (int)(cfg->resolution_a / cfg->resolution_h);
+    if ((double)P.step != cfg->resolution_a / cfg->resolution_h || P.step < 1) { delete env; return IRBPP_ERR_ARG; }
+    P.Hx = (int)ceil(cfg->bin[0] / cfg->resolution_h);
+    P.Hy = (int)ceil(cfg->bin[1] / cfg->resolution_h);
+    P.Ax = (int)ceil(cfg->bin[0] / cfg->resolution_a);
+    P.Ay = (int)ceil(cfg->bin[1] / cfg->resolution_a);
+    P.Hc = P.Hx * P.Hy;
+    P.AC = P.Ax * P.Ay;
+    if (P.Ax > 16 || P.Ay > 16 || P.Ax < 1 || P.Ay < 1 || P.Hc > 128 * 128) { delete env; return IRBPP_ERR_ARG; }
+    P.traj_start = cfg->traj_start;
+    P.goff = cfg->global_offset;
+    P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
+    P.obs_len1 = 5 * P.S + 9 + P.Hc;
+    P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
+    layout_lds(P, cfg->contour_slots);
+    if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
+
+    if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
+    if (hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess) {
+        delete env;
+        return IRBPP_ERR_HIP;
+    }
+    State& S = env->S;
+    const size_t N = (size_t)P.N;
+    int rc = IRBPP_OK;
+#define ALLOC(field, count) if (rc == IRBPP_OK) rc = dev_alloc(env, &S.field, (count))
+    ALLOC(hm, N * P.Hc);
+    ALLOC(queue, N * P.K);
+    ALLOC(cand, N * P.S);
+    ALLOC(cursor, N);
+    ALLOC(episode, N);
+    ALLOC(cur_item, N);
+    ALLOC(nvalid, N);
+    ALLOC(order_action, N);
+    ALLOC(item_idx, N);
+    ALLOC(ratio_acc, N);
+    ALLOC(ep_reward, N);
+    ALLOC(ep_len, N);
+    ALLOC(totals, N * 4);
+    ALLOC(err, 1);
+#undef ALLOC
+    if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
+    *out = env;
+    return IRBPP_OK;
+}
+
+int irbpp_destroy(irbpp_env* env) {
+    if (!env) return IRBPP_OK;
+    hipSetDevice(env->cfg.device);
+    for (void* p : env->allocs) hipFree(p);
+    delete env;
+    return IRBPP_OK;
+}
+
+int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, const double* volumes,
+                      const int32_t* dims, const int64_t* offsets, int64_t pool_len,
+                      const double* height_top, const double* height_bottom,
+                      const double* mask_top, const double* mask_bottom) {
+    if (!env || n_shapes < 1 || !extents || !volumes || !dims || !offsets || pool_len < 1 || !height_top ||
+        !height_bottom || !mask_top || !mask_bottom)
+        return IRBPP_ERR_ARG;
+    if (env->shapes_loaded) return IRBPP_ERR_STATE;
+    const Params& P = env->P;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    const int R = P.R;
+    std::vector<ShapeRot> sr((size_t)n_shapes * R);
+    for (int k = 0; k < n_shapes; ++k) {
+        for (int r = 0; r < R; ++r) {
+            const size_t i = (size_t)k * R + r;
+            ShapeRot& s = sr[i];
+            s.ext_x = extents[i * 3 + 0];
+            s.ext_y = extents[i * 3 + 1];
+            s.ext_z = extents[i * 3 + 2];
+            const double bx = round6_host(s.ext_x), by = round6_host(s.ext_y);     // space.py:104
+            s.ext_z_r = round6_host(s.ext_z);
+            s.fx = (int32_t)ceil(bx / P.res_h);                                   // space.py:105
+            s.fy = (int32_t)ceil(by / P.res_h);
+            s.ax = (int32_t)ceil(bx / P.res_a);                                   // space.py:106
+            s.ay = (int32_t)ceil(by / P.res_a);
+            s.off = offsets[i];
+            if (s.fx != dims[i * 2] || s.fy != dims[i * 2 + 1]) return IRBPP_ERR_ARG;   // table shape must match
+            if (s.fx < 1 || s.fy < 1 || s.fx > s.ax * P.step || s.fy > s.ay * P.step) return IRBPP_ERR_ARG;
+            if (s.off < 0 || s.off + (int64_t)s.fx * s.fy > pool_len) return IRBPP_ERR_ARG;
+        }
+    }
+    std::vector<uint8_t> mt((size_t)pool_len), mb((size_t)pool_len);
+    for (int64_t i = 0; i < pool_len; ++i) {
+        if ((mask_top[i] != 0.0 && mask_top[i] != 1.0) || (mask_bottom[i] != 0.0 && mask_bottom[i] != 1.0))
+            return IRBPP_ERR_ARG;
+        mt[i] = mask_top[i] != 0.0;
+        mb[i] = mask_bottom[i] != 0.0;
+    }
+    Tables& T = env->T;
+    int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.top, height_top, (size_t)pool_len);
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.bot, height_bottom, (size_t)pool_len);
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.mtop, (const uint8_t*)mt.data(), mt.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.mbot, (const uint8_t*)mb.data(), mb.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
+    if (rc != IRBPP_OK) return rc;
+    T.n_shapes = n_shapes;
+    env->shapes_loaded = true;
+    return IRBPP_OK;
+}
+
+int irbpp_load_sequences(irbpp_env* env, const int32_t* ids, int32_t n_traj, int32_t length) {
+    if (!env || !ids || n_traj < 1 || length < 1) return IRBPP_ERR_ARG;
+    if (env->seq_loaded) return IRBPP_ERR_STATE;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    int rc = dev_upload(env, &env->T.seq, ids, (size_t)n_traj * length);
+    if (rc != IRBPP_OK) return rc;
+    env->T.n_traj = n_traj;
+    env->T.seq_len = length;
+    env->seq_loaded = true;
+    return IRBPP_OK;
+}
+
+int irbpp_obs_len(const irbpp_env* env, int32_t which) {
+    if (!env) return IRBPP_ERR_ARG;
+    return which == 0 ? env->P.obs_len0 : env->P.obs_len1;
+}
+
+static int launch_env(irbpp_env* env, const StepIO& io, int mode, void* stream) {
+    hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+                       env->P, env->T, env->S, io, mode);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream) {
+    if (!env || !obs_dev) return IRBPP_ERR_ARG;
+    if (!env->shapes_loaded || !env->seq_loaded) return IRBPP_ERR_STATE;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.obs = obs_dev;
+    io.obs_stride = env->P.obs_len0;
+    const int rc = launch_env(env, io, MODE_RESET, stream);
+    if (rc == IRBPP_OK) env->was_reset = true;
+    return rc;
+}
+
+int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const irbpp_step_out* out, void* stream) {
+    if (!env || !actions_dev || !obs_dev) return IRBPP_ERR_ARG;
+    if (!env->was_reset) return IRBPP_ERR_STATE;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = actions_dev;
+    io.obs = obs_dev;
+    io.obs_stride = env->P.obs_len0;
+    if (out) {
+        io.reward = out->reward_dev;
+        io.done = out->done_dev;
+        io.counter = out->counter_dev;
+        io.ratio = out->ratio_dev;
+        io.ep_reward = out->ep_reward_dev;
+        io.ep_len = out->ep_len_dev;
+    }
+    return launch_env(env, io, MODE_STEP, stream);
+}
+
+int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev, float* loc_obs_dev, void* stream) {
+    if (!env || !order_actions_dev || !loc_obs_dev) return IRBPP_ERR_ARG;
+    if (!env->was_reset) return IRBPP_ERR_STATE;
+    if (env->P.K < 2) return IRBPP_ERR_ARG;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = order_actions_dev;
+    io.obs = loc_obs_dev;
+    io.obs_stride = env->P.obs_len1;
+    return launch_env(env, io, MODE_CANDS, stream);
+}
+
+int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stride, int32_t* actions_dev, void* stream) {
+    if (!env || !loc_obs_dev || !actions_dev || obs_stride < 5 * env->P.S) return IRBPP_ERR_ARG;
+    const int waves_per_block = 4;
+    const int grid = (env->P.N + waves_per_block - 1) / waves_per_block;
+    hipLaunchKernelGGL(irbpp_policy_minz_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, loc_obs_dev,
+                       obs_stride, env->P.S, env->P.N, actions_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double* posz_dev, uint8_t* mask_dev, void* stream) {
+    if (!env || !item_ids_dev || !posz_dev || !mask_dev) return IRBPP_ERR_ARG;
+    if (!env->shapes_loaded) return IRBPP_ERR_STATE;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.actions = item_ids_dev;
+    io.posz_out = posz_dev;
+    io.mask_out = mask_dev;
+    return launch_env(env, io, MODE_POSSIBLE, stream);
+}
+
+int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev, const uint8_t* mask_dev,
+                              uint32_t* vertex_rows_dev, void* stream) {
+    if (!env || n_grids < 1 || !posz_valid_dev || !mask_dev || !vertex_rows_dev) return IRBPP_ERR_ARG;
+    hipLaunchKernelGGL(irbpp_hull_kernel, dim3(n_grids), dim3(256), env->P.lds_bytes, (hipStream_t)stream, env->P,
+                       env->S, posz_valid_dev, mask_dev, vertex_rows_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_get_heightmaps(irbpp_env* env, double* hm_dev, void* stream) {
+    if (!env || !hm_dev) return IRBPP_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(hm_dev, env->S.hm, (size_t)env->P.N * env->P.Hc * sizeof(double), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return IRBPP_OK;
+}
+
+int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream) {
+    if (!env || !hm_dev) return IRBPP_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(env->S.hm, hm_dev, (size_t)env->P.N * env->P.Hc * sizeof(double), hipMemcpyDeviceToDevice,
+                           (hipStream_t)stream));
+    return IRBPP_OK;
+}
+
+int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream) {
+    if (!env || !out_dev) return IRBPP_ERR_ARG;
+    hipLaunchKernelGGL(irbpp_totals_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, env->S.totals, env->P.N, out_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out) {
+    if (!env || !flags_out) return IRBPP_ERR_ARG;
+    HIP_TRY(hipMemcpyAsync(flags_out, env->S.err, sizeof(int32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return *flags_out ? IRBPP_ERR_DEVICE : IRBPP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// irbpp_device.h -- device-visible data layout of the batched packing environment.
+//
+// HBM layout (N = bins on this device, Hc = Hx*Hy, K = bufferSize, S = selectedAction):
+//   hm        f64 [N][Hc]        Space.heightmapC of every bin (space.py:26), contiguous per bin
+//   queue     i32 [N][K]         ItemCreator.item_list (IRcreator.py:6-24), always full
+//   cand      u32 [N][S]         (rot<<16 | lx<<8 | ly) of the candidate rows handed out last
+//   scalars   i32/f64 [N]        cursor, episode, cur_item, nvalid, order_action, item_idx,
+//                                ratio_acc, ep_reward, ep_len, totals
+//   ShapeRot  48 B per (shape, rot) + pooled f64 height tables and u8 masks (read-only, shared
+//                                by all bins -> L2 / Infinity-Cache resident)
+//   seq       i32 [n_traj][L]    pre-drawn item ids
+#pragma once
+#include <stdint.h>
+
+namespace irbpp {
+
+struct ShapeRot {
+    int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
+    int32_t ax, ay;        // footprint in action cells:    ceil(round(extents,6)/resA)  (space.py:106)
+    int64_t off;           // offset of the [fx][fy] tables in the pools
+    double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
+    double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
+};
+
+struct Tables {
+    const ShapeRot* sr;    // [n_shapes][R]
+    const double* top;     // heightMapT pool
+    const double* bot;     // heightMapB pool
+    const uint8_t* mtop;   // maskH pool (0/1)
+    const uint8_t* mbot;   // maskB pool (0/1)
+    const double* volume;  // [n_shapes]
+    const int32_t* seq;    // [n_traj][seq_len]
+    int32_t n_shapes, n_traj, seq_len;
+};
+
+struct State {
+    double* hm;
+    int32_t* queue;
+    uint32_t* cand;
+    int32_t* cursor;
+    int32_t* episode;
+    int32_t* cur_item;
+    int32_t* nvalid;
+    int32_t* order_action;
+    int32_t* item_idx;
+    double* ratio_acc;
+    double* ep_reward;
+    int32_t* ep_len;
+    double* totals;        // [N][4]: episodes, sum ratio, sum counter, sum reward
+    int32_t* err;          // [1] device error word
+};
+
+struct Params {
+    int32_t N, Hx, Hy, Hc, Ax, Ay, AC, step, R, S, K;
+    double res_a, res_h, res_z;
+    double bin_x, bin_y, bin_z, bin_vol;
+    double scale_z, ibin_z;        // Interface scale and round(bin_z*scale, 6)
+    int32_t traj_start, goff, gbins;
+    int32_t obs_len0, obs_len1;
+    // dynamic-LDS carve-up (byte offsets, all multiples of 16)
+    int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_vmask, o_scratch, o_red;
+    int32_t nslot, slot_cap, slot_stk, slot_bytes, scratch_bytes, lds_bytes;
+};
+
+enum Mode : int32_t {
+    MODE_RESET = 0,       // reset(): new episodes everywhere, first observation
+    MODE_STEP = 1,        // step(): apply action, auto-reset, next observation
+    MODE_CANDS = 2,       // get_action_candidates(): location observation of the chosen slot
+    MODE_POSSIBLE = 3     // get_possible_position() only, results to global memory
+};
+
+struct StepIO {
+    const int32_t* actions;     // MODE_STEP: candidate index; MODE_CANDS: buffer slot; MODE_POSSIBLE: item id
+    float* obs;                 // observation rows
+    int32_t obs_stride;
+    double* reward;
+    uint8_t* done;
+    int32_t* counter;
+    double* ratio;
+    double* ep_reward;
+    int32_t* ep_len;
+    double* posz_out;           // MODE_POSSIBLE
+    uint8_t* mask_out;
+};
+
+}  // namespace irbpp

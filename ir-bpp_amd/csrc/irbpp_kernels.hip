@@ -1,0 +1,595 @@
+// irbpp_kernels.hip -- CDNA4 (gfx950) kernels of the batched packing environment.
+//
+// One 256-thread workgroup (4 wave64) owns one bin for a whole environment transition:
+//   apply    action -> (rot,lx,ly) -> prejudge -> drop height -> height check ->
+//            heightmap update / episode end + auto-reset          (binPhy.py:248-337)
+//   observe  overlap test over (rot,X,Y)                           (space.py:98-129)
+//            height levels -> per-level binary images -> border following ->
+//            approxPolyDP -> convex vertices -> candidate set      (cvTools.py:61-102)
+//            select/pad S rows, assemble the float32 observation   (binPhy.py:183-232)
+// The float64 heightmap tile of the bin lives in LDS for the whole transition (8 KiB at
+// 32x32, 32 KiB at 64x64); footprint tables are wave-uniform reads served from L2; all
+// intermediate grids (posZValid, levels, level images, vertex bit grids, candidate keys)
+// stay in LDS.  HBM traffic per transition is the heightmap tile in/out, the observation
+// row out and ~2 KiB of candidate keys.  Arithmetic is float64 in the reference's operation
+// order (compile with -ffp-contract=off), so results are bit-identical to the numpy code.
+// No MFMA: this is subtract/max/compare and integer border following, not a contraction.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+#include "contours_device.h"
+#include "irbpp_device.h"
+#include "../../include/irbpp.h"
+
+namespace irbpp {
+
+constexpr int BLOCK = 256;
+constexpr int WAVES = BLOCK / 64;
+
+// np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
+__device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
+
+// numpy floor_divide on float64 (npy_divmod): decides which cells share a height level
+// (cvTools.py:78), e.g. 0.06 // 0.01 == 5.
+__device__ inline double np_floor_divide(double a, double b) {
+    double mod = fmod(a, b);
+    double div = (a - mod) / b;
+    if (mod != 0.0) {
+        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
+    }
+    double fd;
+    if (div != 0.0) {
+        fd = floor(div);
+        if (div - fd > 0.5) fd += 1.0;
+    } else {
+        fd = copysign(0.0, a / b);
+    }
+    return fd;
+}
+
+__device__ inline double block_max_f64(double v, double* red) {
+    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = red[0];
+    for (int w = 1; w < WAVES; ++w) r = fmax(r, red[w]);
+    return r;
+}
+
+__device__ inline int block_sum_int(int v, int* red) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    int r = 0;
+    for (int w = 0; w < WAVES; ++w) r += red[w];
+    return r;
+}
+
+// exclusive prefix count of `flag` over the block in thread order; total in `total`
+__device__ inline int block_scan_flag(bool flag, int* red, int& total) {
+    const unsigned long long bal = __ballot(flag);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int pre = __popcll(bal & ((1ull << lane) - 1ull));
+    __syncthreads();
+    if (lane == 0) red[w] = __popcll(bal);
+    __syncthreads();
+    int base = 0;
+    total = 0;
+    for (int i = 0; i < WAVES; ++i) {
+        const int c = red[i];
+        if (i < w) base += c;
+        total += c;
+    }
+    return base + pre;
+}
+
+// LoadItemCreator.generate_item (IRcreator.py:97-103) on the pre-drawn trajectories; the
+// trajectory of global bin g in its e-th episode is (traj_start + g + e*global_bins) % n_traj.
+__device__ inline int fetch_item(const Params& P, const Tables& T, const State& S, int b, int episode, int cursor) {
+    if (cursor >= T.seq_len) return -1;
+    long long row = (long long)P.traj_start + P.goff + b + (long long)episode * P.gbins;
+    row %= T.n_traj;
+    if (row < 0) row += T.n_traj;
+    const int id = T.seq[row * T.seq_len + cursor];
+    if (id >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); return -1; }
+    return id < 0 ? -1 : id;
+}
+
+__device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
+    SlotMem m;
+    m.lab = (uint32_t*)base;
+    m.pts = base + 64;
+    m.dst = m.pts + cap;
+    m.stk = (uint32_t*)(m.dst + cap);
+    m.cap = cap;
+    m.cap_stk = cap_stk;
+    return m;
+}
+
+struct Lds {
+    double* hm;
+    double* posz;
+    uint8_t* lev;
+    unsigned long long* present;
+    uint16_t* taskidx;      // [R][64] level code -> task index
+    uint16_t* tasklist;     // [ntasks] rot<<8 | level code
+    uint32_t* img;
+    uint32_t* vmask;
+    unsigned char* scratch;
+    double* redd;
+    int* redi;
+};
+
+__device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
+    Lds L;
+    L.hm = (double*)(smem + P.o_hm);
+    L.posz = (double*)(smem + P.o_posz);
+    L.lev = smem + P.o_lev;
+    L.present = (unsigned long long*)(smem + P.o_present);
+    L.taskidx = (uint16_t*)(smem + P.o_taskidx);
+    L.tasklist = (uint16_t*)(smem + P.o_tasklist);
+    L.img = (uint32_t*)(smem + P.o_img);
+    L.vmask = (uint32_t*)(smem + P.o_vmask);
+    L.scratch = smem + P.o_scratch;
+    L.redd = (double*)(smem + P.o_red);
+    L.redi = (int*)(L.redd + 8);
+    return L;
+}
+
+// ---------------------------------------------------------------------------------------
+// cvTools.getConvexHullActions on the grids in LDS: L.posz = posZValid [R][AC] (1e3 where
+// invalid), `valid` given per thread/rotation through L.lev (255 = masked).  On return
+// L.vmask[r*16 + row] has bit col set for every candidate (row, col) of rotation r.
+// ---------------------------------------------------------------------------------------
+__device__ inline void contour_stage(const Params& P, const State& S, const Lds& L) {
+    const int tid = threadIdx.x;
+    const int R = P.R, AC = P.AC;
+    // task list: one task per (rotation, present level)
+    int ntasks = 0;
+    for (int r = 0; r < R; ++r) ntasks += __popcll(L.present[r]);
+    for (int t = tid; t < R * 64; t += BLOCK) {
+        const int r = t >> 6, l = t & 63;
+        const unsigned long long m = L.present[r];
+        if ((m >> l) & 1ull) {
+            int base = 0;
+            for (int q = 0; q < r; ++q) base += __popcll(L.present[q]);
+            const int idx = base + __popcll(m & ((1ull << l) - 1ull));
+            L.tasklist[idx] = (uint16_t)((r << 8) | l);
+            L.taskidx[t] = (uint16_t)idx;
+        }
+    }
+    const int X = tid / P.Ay, Y = tid % P.Ay;
+    for (int base = 0; base < ntasks; base += P.nslot) {
+        for (int i = tid; i < P.nslot * 16; i += BLOCK) L.img[i] = 0u;
+        if (tid == 0) L.redi[8] = 0;
+        __syncthreads();
+        if (tid < AC) {
+            for (int r = 0; r < R; ++r) {
+                const int code = L.lev[r * AC + tid];
+                if (code != 255) {
+                    const int ti = (int)L.taskidx[r * 64 + code] - base;
+                    if (ti >= 0 && ti < P.nslot) atomicOr(&L.img[ti * 16 + X], 1u << Y);
+                }
+            }
+        }
+        __syncthreads();
+        {   // one lane per level image, slots spread over the four waves
+            const int lane = tid & 63, w = tid >> 6;
+            const int slot = lane * WAVES + w;
+            if (slot < P.nslot && base + slot < ntasks) {
+                const int r = L.tasklist[base + slot] >> 8;
+                const SlotMem m = carve_slot(L.scratch + slot * P.slot_bytes, P.slot_cap, P.slot_stk);
+                const int rc = level_image_vertices(L.img + slot * 16, m, L.vmask + r * 16);
+                if (rc == 1) atomicOr(&L.redi[8], 1);
+                if (rc == 2) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+            }
+        }
+        __syncthreads();
+        if (L.redi[8]) {        // a contour outgrew its slot: redo this batch serially in one big slot
+            if (tid == 0) {
+                const int cap = ((P.scratch_bytes - 64) / 6) & ~3;
+                const SlotMem m = carve_slot(L.scratch, cap, cap);
+                for (int slot = 0; slot < P.nslot && base + slot < ntasks; ++slot) {
+                    const int r = L.tasklist[base + slot] >> 8;
+                    const int rc = level_image_vertices(L.img + slot * 16, m, L.vmask + r * 16);
+                    if (rc != 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
+// ---------------------------------------------------------------------------------------
+__device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
+                                        const Lds& L, int b, int item, float* obs, bool debug_out) {
+    item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
+    const int tid = threadIdx.x;
+    const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
+    const int X = tid / Ay, Y = tid % Ay;
+    if (tid < R) L.present[tid] = 0ull;
+    for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
+    __syncthreads();
+
+    // ---- Space.get_possible_position (space.py:98-129): one action cell per lane -------
+    int my_valid = 0;
+    for (int r = 0; r < R; ++r) {
+        double z = 1e3;
+        bool valid = false;
+        if (item >= 0 && tid < AC) {
+            const ShapeRot sr = T.sr[item * R + r];
+            if (X <= Ax - sr.ax && Y <= Ay - sr.ay) {
+                const double* bp = T.bot + sr.off;
+                const uint8_t* mp = T.mbot + sr.off;
+                const double* h0 = L.hm + (X * P.step) * P.Hy + Y * P.step;
+                double m = -INFINITY;
+                for (int i = 0; i < sr.fx; ++i) {
+                    for (int j = 0; j < sr.fy; ++j) {
+                        const double d = h0[i * P.Hy + j] - bp[i * sr.fy + j];
+                        const double v = d * (double)mp[i * sr.fy + j];
+                        m = fmax(m, v);
+                    }
+                }
+                z = m;
+                valid = round6(z + sr.ext_z_r - P.bin_z) <= 0.0;
+            }
+        }
+        if (tid < AC) {
+            if (debug_out) {
+                io.posz_out[((size_t)b * R + r) * AC + tid] = z;
+                io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
+            }
+            L.posz[r * AC + tid] = valid ? z : 1e3;
+            int code = 255;
+            if (valid) {
+                const int li = (int)np_floor_divide(z, P.res_z);      // cvTools.py:78
+                if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
+                    const int idx = li + 32;
+                    if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                    else code = idx;
+                }
+                ++my_valid;
+            }
+            L.lev[r * AC + tid] = (uint8_t)code;
+            if (code != 255) atomicOr(&L.present[r], 1ull << code);
+        }
+    }
+    const int nvalid = block_sum_int(my_valid, L.redi);      // np.sum(naiveMask) for prejudge
+    if (debug_out) return;
+    __syncthreads();
+
+    contour_stage(P, S, L);
+
+    // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
+    uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
+    uint32_t* okey = keys + R * AC;                 // [S]
+    int n = 0;
+    {
+        const int cx = tid / Ax, cy = tid % Ax;     // col-major walk: x = column (ly), y = row (lx)
+        for (int r = 0; r < R; ++r) {
+            const bool flag = tid < AC && ((L.vmask[r * 16 + cy] >> cx) & 1u);
+            int total;
+            const int pos = block_scan_flag(flag, L.redi, total);
+            if (flag) keys[n + pos] = ((uint32_t)r << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+            n += total;
+        }
+    }
+    __syncthreads();
+    int nrows;
+    bool fallback = false;
+    const uint32_t* rows;
+    if (n > 0 && n <= P.S) {
+        nrows = n;
+        rows = keys;
+    } else if (n > P.S) {
+        // np.argsort(candidates[:,3])[:S] (binPhy.py:209-212), ties by ascending index
+        for (int i = tid; i < n; i += BLOCK) {
+            const uint32_t ki = keys[i];
+            const double hi = L.posz[(ki >> 16) * AC + ((ki >> 8) & 255u) * Ay + (ki & 255u)];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) {
+                const uint32_t kj = keys[j];
+                const double hj = L.posz[(kj >> 16) * AC + ((kj >> 8) & 255u) * Ay + (kj & 255u)];
+                rank += (hj < hi || (hj == hi && j < i)) ? 1 : 0;
+            }
+            if (rank < P.S) okey[rank] = ki;
+        }
+        nrows = P.S;
+        rows = okey;
+        __syncthreads();
+    } else {
+        // no candidate at all: the S smallest of posZValid.reshape(-1) (binPhy.py:217-225)
+        fallback = true;
+        const int total_cells = R * AC;
+        int valid_before_r = 0;              // valid cells of earlier rotations
+        for (int r = 0; r < R; ++r) {
+            const int c = r * AC + tid;
+            const bool in = tid < AC;
+            const double zc = in ? L.posz[c] : 1e3;
+            const bool v = in && zc < 1e3;
+            int tot;
+            const int vbefore = block_scan_flag(v, L.redi, tot);
+            if (in) {
+                int rank;
+                if (v) {
+                    rank = 0;
+                    for (int j = 0; j < total_cells; ++j) {
+                        const double zj = L.posz[j];
+                        rank += (zj < 1e3 && (zj < zc || (zj == zc && j < c))) ? 1 : 0;
+                    }
+                } else {
+                    rank = nvalid + (c - (valid_before_r + vbefore));
+                }
+                if (rank < P.S) okey[rank] = ((uint32_t)r << 16) | ((uint32_t)X << 8) | (uint32_t)Y;
+            }
+            valid_before_r += tot;
+        }
+        nrows = total_cells < P.S ? total_cells : P.S;
+        rows = okey;
+        __syncthreads();
+    }
+
+    // ---- emit: candidate block [S][5], item vector [9], heightmap [Hc]; float32 cast last
+    for (int e = tid; e < 5 * P.S; e += BLOCK) {
+        const int row = e / 5, col = e - row * 5;
+        float v = 0.0f;
+        if (row < nrows) {
+            const uint32_t k = rows[row];
+            const int r = k >> 16, lx = (k >> 8) & 255, ly = k & 255;
+            const double z = L.posz[r * AC + lx * Ay + ly];
+            switch (col) {
+                case 0: v = (float)r; break;
+                case 1: v = (float)lx; break;
+                case 2: v = (float)ly; break;
+                case 3: v = fallback ? (float)P.bin_z : (float)z; break;
+                default: v = fallback ? (z < 1e3 ? 1.0f : 0.0f) : 1.0f; break;
+            }
+        }
+        obs[e] = v;
+    }
+    for (int i = tid; i < P.S; i += BLOCK) S.cand[(size_t)b * P.S + i] = i < nrows ? rows[i] : 0u;
+    if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
+    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[i];
+    if (tid == 0) {
+        S.cur_item[b] = item;
+        S.nvalid[b] = nvalid;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// The environment transition kernel: one workgroup per bin.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Lds L = carve_lds(smem, P);
+    const int b = blockIdx.x;
+    const int tid = threadIdx.x;
+    double* ghm = S.hm + (size_t)b * P.Hc;
+    int32_t* q = S.queue + (size_t)b * P.K;
+    float* obs = io.obs ? io.obs + (size_t)b * io.obs_stride : nullptr;
+
+    // stage the heightmap tile
+    if (mode == MODE_RESET) {
+        for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }
+    } else {
+        for (int i = tid; i < P.Hc; i += BLOCK) L.hm[i] = ghm[i];
+    }
+    __syncthreads();
+
+    if (mode == MODE_POSSIBLE) {
+        int item = io.actions[b];
+        if (item >= T.n_shapes) item = -1;
+        observe_location(P, T, S, io, L, b, item, nullptr, true);
+        return;
+    }
+
+    if (mode == MODE_CANDS) {            // PackingGame.get_action_candidates (binPhy.py:161-169)
+        int oa = io.actions[b];
+        oa = oa < 0 ? 0 : (oa >= P.K ? P.K - 1 : oa);
+        const int item = q[oa];
+        if (tid == 0) S.order_action[b] = oa;
+        observe_location(P, T, S, io, L, b, item, obs, false);
+        return;
+    }
+
+    if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
+        if (tid == 0) {
+            S.episode[b] = 0;
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, 0, i);
+            S.cursor[b] = P.K;
+            S.item_idx[b] = 0;
+            S.ratio_acc[b] = 0.0;
+            S.ep_reward[b] = 0.0;
+            S.ep_len[b] = 0;
+            S.order_action[b] = 0;
+            for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
+            for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
+        }
+        __syncthreads();
+    } else {                             // PackingGame.step (binPhy.py:248-337)
+        int a = io.actions[b];
+        a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
+        const uint32_t key = S.cand[(size_t)b * P.S + a];            // action_to_position (:234-236)
+        const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
+        const int item0 = S.cur_item[b];
+        const int oa = S.order_action[b];
+        bool ok = item0 >= 0 && S.nvalid[b] > 0 && rot < P.R;        // prejudge (:238-245)
+        ShapeRot sr = {};
+        if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
+        if (ok) {
+            const double tx = round6((double)lx * P.res_a), ty = round6((double)ly * P.res_a);
+            if (round6(tx + sr.ext_x - P.bin_x) > 0.0 || round6(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
+        }
+        double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)
+        if (ok) {
+            if (lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay) {
+                const double* bp = T.bot + sr.off;
+                const uint8_t* mp = T.mbot + sr.off;
+                const double* h0 = L.hm + (lx * P.step) * P.Hy + ly * P.step;
+                double m = -INFINITY;
+                const int F = sr.fx * sr.fy;
+                for (int e = tid; e < F; e += BLOCK) {
+                    const int i = e / sr.fy, j = e - i * sr.fy;
+                    const double d = h0[i * P.Hy + j] - bp[e];
+                    m = fmax(m, d * (double)mp[e]);
+                }
+                z = block_max_f64(m, L.redd);
+            }
+            // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
+            const double top = z * P.scale_z + sr.ext_z * P.scale_z;
+            if (round6(top - P.ibin_z) > 0.0) ok = false;
+        }
+        if (ok) {
+            // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
+            const double* tp = T.top + sr.off;
+            const uint8_t* mh = T.mtop + sr.off;
+            const int base = (lx * P.step) * P.Hy + ly * P.step;
+            const int F = sr.fx * sr.fy;
+            for (int e = tid; e < F; e += BLOCK) {
+                const int i = e / sr.fy, j = e - i * sr.fy;
+                const int c = base + i * P.Hy + j;
+                const double v = (tp[e] + z) * (double)mh[e];
+                const double h = fmax(L.hm[c], v);
+                L.hm[c] = h;
+                ghm[c] = h;
+            }
+        } else {
+            for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }   // Space.reset (space.py:49-52)
+        }
+        if (tid == 0) {
+            if (ok) {
+                const double vol = T.volume[item0];
+                const double reward = (vol / P.bin_vol) * 10.0;      // binPhy.py:321-322
+                S.ep_reward[b] += reward;
+                S.ep_len[b] += 1;
+                S.item_idx[b] += 1;
+                S.ratio_acc[b] += vol;
+                int cursor = S.cursor[b];
+                for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
+                q[P.K - 1] = fetch_item(P, T, S, b, S.episode[b], cursor);   // generate_item (:325)
+                S.cursor[b] = cursor + 1;
+                if (io.reward) io.reward[b] = reward;
+                if (io.done) io.done[b] = 0;
+                if (io.counter) io.counter[b] = -1;
+                if (io.ratio) io.ratio[b] = -1.0;
+                if (io.ep_reward) io.ep_reward[b] = S.ep_reward[b];
+                if (io.ep_len) io.ep_len[b] = S.ep_len[b];
+            } else {
+                const int counter = S.item_idx[b];                   // info (binPhy.py:306-309)
+                const double ratio = S.ratio_acc[b] / P.bin_vol;     // get_ratio (:149-153)
+                const double epr = S.ep_reward[b] + 0.0;
+                const int epl = S.ep_len[b] + 1;
+                if (io.reward) io.reward[b] = 0.0;
+                if (io.done) io.done[b] = 1;
+                if (io.counter) io.counter[b] = counter;
+                if (io.ratio) io.ratio[b] = ratio;
+                if (io.ep_reward) io.ep_reward[b] = epr;
+                if (io.ep_len) io.ep_len[b] = epl;
+                double* tot = S.totals + (size_t)b * 4;
+                tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
+                // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset
+                const int ep = S.episode[b] + 1;
+                S.episode[b] = ep;
+                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
+                S.cursor[b] = P.K;
+                S.item_idx[b] = 0;
+                S.ratio_acc[b] = 0.0;
+                S.ep_reward[b] = 0.0;
+                S.ep_len[b] = 0;
+            }
+            for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
+        }
+        __syncthreads();
+    }
+
+    if (P.K == 1) {                      // online: cur_observation with a fresh item (binPhy.py:188-227)
+        const int item = L.redi[16];
+        __syncthreads();
+        observe_location(P, T, S, io, L, b, item, obs, false);
+    } else {                             // buffer branch (binPhy.py:228-230): [k ids | heightmap]
+        for (int i = tid; i < P.K; i += BLOCK) obs[i] = (float)L.redi[16 + i];
+        for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[i];
+    }
+}
+
+// getConvexHullActions on caller-supplied grids (parity tests of the contour stage).
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_hull_kernel(const Params P, const State S, const double* posz_valid, const uint8_t* mask,
+                  uint32_t* vertex_rows) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Lds L = carve_lds(smem, P);
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int R = P.R, AC = P.AC;
+    if (tid < R) L.present[tid] = 0ull;
+    for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
+    __syncthreads();
+    if (tid < AC) {
+        for (int r = 0; r < R; ++r) {
+            const size_t gi = ((size_t)g * R + r) * AC + tid;
+            const double z = posz_valid[gi];
+            const bool valid = mask[gi] != 0;
+            L.posz[r * AC + tid] = z;
+            int code = 255;
+            if (valid) {
+                const int li = (int)np_floor_divide(z, P.res_z);
+                if (li != -1) {
+                    const int idx = li + 32;
+                    if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                    else code = idx;
+                }
+            }
+            L.lev[r * AC + tid] = (uint8_t)code;
+            if (code != 255) atomicOr(&L.present[r], 1ull << code);
+        }
+    }
+    __syncthreads();
+    contour_stage(P, S, L);
+    for (int i = tid; i < R * 16; i += BLOCK) vertex_rows[(size_t)g * R * 16 + i] = L.vmask[i];
+}
+
+// Scripted policy: lowest-H row with V == 1, first on ties; 0 if none.  One wave per bin.
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_policy_minz_kernel(const float* obs, int obs_stride, int S_rows, int N, int32_t* actions) {
+    const int wave = (blockIdx.x * BLOCK + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (wave >= N) return;
+    const float* c = obs + (size_t)wave * obs_stride;
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < S_rows; i += 64) {
+        const float h = c[i * 5 + 3], v = c[i * 5 + 4];
+        if (v == 1.0f && (h < best || (h == best && i < bi))) { best = h; bi = i; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) actions[wave] = bi == 0x7fffffff ? 0 : bi;
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_totals_kernel(const double* totals, int N, double* out) {
+    __shared__ double red[4][WAVES];
+    double acc[4] = {0, 0, 0, 0};
+    for (int b = threadIdx.x; b < N; b += BLOCK)
+        for (int k = 0; k < 4; ++k) acc[k] += totals[(size_t)b * 4 + k];
+    for (int k = 0; k < 4; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        double v = 0;
+        for (int w = 0; w < WAVES; ++w) v += red[threadIdx.x][w];
+        out[threadIdx.x] = v;
+    }
+}
+
+}  // namespace irbpp

@@ -1,0 +1,327 @@
+"""Host-side mirror of the reference's vectorised-environment surface, backed by the HIP library.
+
+    GpuPackingEnv   device-tensor API straight over the C ABI (include/irbpp.h)
+    GpuVecEnv       the ShmemVecEnv/VecPyTorch protocol the trainer calls
+                    (wrapper/vec_env.py:29-138, wrapper/shmem_vec_env.py:20-117,
+                    envs.py:142-165): num_envs, observation_space, action_space, reset(),
+                    step_async()/step_wait()/step(), get_action_candidates(), close()
+    make_vec_envs   same return triple as envs.make_vec_envs (envs.py:67-99)
+
+PyTorch is plumbing only (device memory, streams); all environment arithmetic runs in
+libirbpp_hip.so.  Without that library this module raises -- there is no CPU path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from collections.abc import Sequence
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from .shapes import ShapeSet
+
+BIN_DIMENSION = (0.32, 0.32, 0.30)      # arguments.py:115
+
+
+class Box(object):
+    """Stand-in for gym.spaces.Box (binPhy.py:100-101); gym is not a dependency here."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low, self.high, self.shape, self.dtype = low, high, tuple(shape), dtype
+
+
+class Discrete(object):
+    """Stand-in for gym.spaces.Discrete (binPhy.py:102)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+class GpuPackingEnv(object):
+    """N independent bins on one MI355X.  All tensors live on ``device``; nothing here syncs."""
+
+    def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_bins: int, *,
+                 resolutionA: float = 0.02, resolutionH: float = 0.01, resolutionZ: float = 0.01,
+                 bin_dimension=BIN_DIMENSION, selectedAction: int = 500, bufferSize: int = 1,
+                 scale_z: float = 100.0, traj_start: int = 1, global_offset: int = 0,
+                 global_bins: Optional[int] = None, device="cuda:0", contour_slots: int = 0):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise RuntimeError("GpuPackingEnv needs a HIP device; irbpp_amd has no CPU fallback")
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("GpuPackingEnv runs on a HIP device only")
+        dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.num_bins = int(num_bins)
+        self.n_rot = shapes.n_rot
+        self.S = int(selectedAction)
+        self.K = int(bufferSize)
+        shapes.validate(resolutionH, resolutionA)
+        bin_r = np.round(np.asarray(bin_dimension, dtype=np.float64), decimals=6)
+        cfg = _lib.IrbppConfig(
+            num_bins=self.num_bins, n_rot=self.n_rot, selected=self.S, buffer_size=self.K,
+            resolution_a=resolutionA, resolution_h=resolutionH, resolution_z=resolutionZ,
+            bin=(C.c_double * 3)(*bin_r), scale_z=scale_z, traj_start=traj_start,
+            global_offset=global_offset, global_bins=self.num_bins if global_bins is None else global_bins,
+            device=dev_index, contour_slots=contour_slots)
+        self._h = C.c_void_p()
+        torch.cuda.set_device(self.device)
+        _lib.check(self.lib.irbpp_create(C.byref(cfg), C.byref(self._h)), "irbpp_create")
+        self.Hx = int(np.ceil(bin_r[0] / resolutionH))
+        self.Hy = int(np.ceil(bin_r[1] / resolutionH))
+        self.Ax = int(np.ceil(bin_r[0] / resolutionA))
+        self.Ay = int(np.ceil(bin_r[1] / resolutionA))
+        self.obs_len = self.lib.irbpp_obs_len(self._h, 0)
+        self.loc_obs_len = self.lib.irbpp_obs_len(self._h, 1)
+        self._load_shapes(shapes)
+        seq = np.ascontiguousarray(sequences, dtype=np.int32)
+        assert seq.ndim == 2
+        _lib.check(self.lib.irbpp_load_sequences(self._h, seq.ctypes.data_as(_lib.c_i32_p), seq.shape[0], seq.shape[1]),
+                   "irbpp_load_sequences")
+        # one contiguous block for the small per-step outputs -> a single D2H copy for callers that need it
+        n = self.num_bins
+        self._out_f64 = torch.zeros((3, n), dtype=torch.float64, device=self.device)   # reward, ratio, ep_reward
+        self._out_i32 = torch.zeros((2, n), dtype=torch.int32, device=self.device)     # counter, ep_len
+        self._out_done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        self._step_out = _lib.IrbppStepOut(
+            reward_dev=self._out_f64[0].data_ptr(), ratio_dev=self._out_f64[1].data_ptr(),
+            ep_reward_dev=self._out_f64[2].data_ptr(), counter_dev=self._out_i32[0].data_ptr(),
+            ep_len_dev=self._out_i32[1].data_ptr(), done_dev=self._out_done.data_ptr())
+
+    # -- set-up ------------------------------------------------------------------------------
+    def _load_shapes(self, shapes: ShapeSet):
+        n, R = shapes.n_shapes, shapes.n_rot
+        dims = np.zeros((n, R, 2), dtype=np.int32)
+        offs = np.zeros((n, R), dtype=np.int64)
+        pools = [[], [], [], []]
+        pos = 0
+        for k in range(n):
+            for r in range(R):
+                T, B, mH, mB = shapes.tables[k][r]
+                dims[k, r] = T.shape
+                offs[k, r] = pos
+                pos += T.size
+                for pool, arr in zip(pools, (T, B, mH, mB)):
+                    pool.append(np.ascontiguousarray(arr, dtype=np.float64).reshape(-1))
+        T, B, mH, mB = (np.concatenate(p) for p in pools)
+        ext = np.ascontiguousarray(shapes.extents, dtype=np.float64)
+        vol = np.ascontiguousarray(shapes.volumes, dtype=np.float64)
+        f64 = lambda a: a.ctypes.data_as(_lib.c_f64_p)   # noqa: E731
+        _lib.check(self.lib.irbpp_load_shapes(
+            self._h, n, f64(ext), f64(vol), dims.ctypes.data_as(_lib.c_i32_p),
+            offs.ctypes.data_as(C.POINTER(C.c_int64)), pos, f64(T), f64(B), f64(mH), f64(mB)), "irbpp_load_shapes")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # -- transitions -------------------------------------------------------------------------
+    def reset(self) -> torch.Tensor:
+        obs = torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.irbpp_reset(self._h, _ptr(obs), self._stream()), "irbpp_reset")
+        return obs
+
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+        """actions: int32[N] on the device.  Returns (obs, reward f64[N], done u8[N]) device tensors;
+        the reward/done tensors are views of buffers overwritten by the next step."""
+        assert actions.dtype == torch.int32 and actions.is_cuda and actions.numel() == self.num_bins
+        obs = obs_out if obs_out is not None else \
+            torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.irbpp_step(self._h, _ptr(actions), _ptr(obs), C.byref(self._step_out), self._stream()),
+                   "irbpp_step")
+        return obs, self._out_f64[0], self._out_done
+
+    def get_action_candidates(self, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert order_actions.dtype == torch.int32 and order_actions.is_cuda
+        obs = obs_out if obs_out is not None else \
+            torch.empty((self.num_bins, self.loc_obs_len), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.irbpp_get_action_candidates(self._h, _ptr(order_actions), _ptr(obs), self._stream()),
+                   "irbpp_get_action_candidates")
+        return obs
+
+    def policy_minz(self, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        act = actions_out if actions_out is not None else \
+            torch.empty((self.num_bins,), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irbpp_policy_minz(self._h, _ptr(loc_obs), loc_obs.stride(0), _ptr(act), self._stream()),
+                   "irbpp_policy_minz")
+        return act
+
+    # -- stage-level access (tests, tooling) ---------------------------------------------------
+    def possible_position(self, item_ids: torch.Tensor):
+        posz = torch.empty((self.num_bins, self.n_rot, self.Ax, self.Ay), dtype=torch.float64, device=self.device)
+        mask = torch.empty((self.num_bins, self.n_rot, self.Ax, self.Ay), dtype=torch.uint8, device=self.device)
+        _lib.check(self.lib.irbpp_possible_position(self._h, _ptr(item_ids), _ptr(posz), _ptr(mask), self._stream()),
+                   "irbpp_possible_position")
+        return posz, mask
+
+    def convex_hull_actions(self, posz_valid: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+        """[G,R,Ax,Ay] float64 / uint8 -> uint32-as-int32 [G,R,16]: word ``row`` has bit ``col`` set."""
+        g = posz_valid.shape[0]
+        assert posz_valid.shape == (g, self.n_rot, self.Ax, self.Ay) and mask.shape == posz_valid.shape
+        out = torch.empty((g, self.n_rot, 16), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irbpp_convex_hull_actions(self._h, g, _ptr(posz_valid.contiguous()),
+                                                      _ptr(mask.contiguous()), _ptr(out), self._stream()),
+                   "irbpp_convex_hull_actions")
+        return out
+
+    def get_heightmaps(self) -> torch.Tensor:
+        hm = torch.empty((self.num_bins, self.Hx, self.Hy), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.irbpp_get_heightmaps(self._h, _ptr(hm), self._stream()), "irbpp_get_heightmaps")
+        return hm
+
+    def set_heightmaps(self, hm: torch.Tensor) -> None:
+        assert hm.dtype == torch.float64 and hm.shape == (self.num_bins, self.Hx, self.Hy)
+        _lib.check(self.lib.irbpp_set_heightmaps(self._h, _ptr(hm.contiguous()), self._stream()), "irbpp_set_heightmaps")
+
+    def episode_totals(self) -> torch.Tensor:
+        """float64[4] on device: finished episodes, sum ratio, sum counter, sum reward."""
+        out = torch.empty((4,), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.irbpp_episode_totals(self._h, _ptr(out), self._stream()), "irbpp_episode_totals")
+        return out
+
+    def check_device_error(self) -> None:
+        flags = C.c_int32(0)
+        _lib.check(self.lib.irbpp_device_error(self._h, self._stream(), C.byref(flags)),
+                   f"device error flags={flags.value}")
+
+    def step_info_host(self):
+        """One synchronising copy of the small per-step outputs -> dict of numpy arrays."""
+        f64 = self._out_f64.cpu().numpy()
+        i32 = self._out_i32.cpu().numpy()
+        done = self._out_done.cpu().numpy().astype(bool)
+        return dict(reward=f64[0], ratio=f64[1], ep_reward=f64[2], counter=i32[0], ep_len=i32[1], done=done)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.irbpp_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _Infos(Sequence):
+    """The ``infos`` sequence of step_wait, materialised lazily: N dicts per step would cost more
+    host time than the whole GPU step.  infos[i] -> {'Valid': True} plus, where done,
+    'counter', 'ratio' (binPhy.py:306-309) and 'episode': {'r','l','t'} (monitor.py:58-75)."""
+
+    def __init__(self, h, t):
+        self._h, self._t = h, t
+
+    def __len__(self):
+        return len(self._h["done"])
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        h = self._h
+        if not h["done"][i]:
+            return {"Valid": True}
+        return {"counter": int(h["counter"][i]), "ratio": float(h["ratio"][i]), "Valid": True,
+                "episode": {"r": round(float(h["ep_reward"][i]), 6), "l": int(h["ep_len"][i]), "t": self._t}}
+
+
+class GpuVecEnv(object):
+    """Drop-in for ``VecPyTorch(ShmemVecEnv(...))`` as the trainer uses it (trainer.py:148,165,267,281)."""
+
+    closed = False
+
+    def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0", **env_kw):
+        self.env = GpuPackingEnv(shapes, sequences, num_envs, device=device, **env_kw)
+        self.num_envs = num_envs
+        self.device = self.env.device
+        self.obs_len = self.env.obs_len
+        self.observation_space = Box(low=0.0, high=float(env_kw.get("bin_dimension", BIN_DIMENSION)[2]),
+                                     shape=(self.obs_len,))
+        self.action_space = Discrete(self.env.K if self.env.K > 1 else self.env.S)
+        self.waiting_step = False
+        self._pending = None
+        self.tstart = time.time()
+
+    def _actions_to_device(self, actions) -> torch.Tensor:
+        if isinstance(actions, torch.Tensor):
+            a = actions.reshape(-1)
+        else:
+            a = torch.from_numpy(np.ascontiguousarray(np.asarray(actions).reshape(-1)))
+        assert a.numel() == self.num_envs
+        return a.to(device=self.device, dtype=torch.int32, non_blocking=True)
+
+    def reset(self) -> torch.Tensor:
+        if self.waiting_step:
+            self.step_wait()
+        self.tstart = time.time()
+        return self.env.reset()
+
+    def step_async(self, actions) -> None:
+        if self.waiting_step:
+            raise RuntimeError("already running an async step")          # vec_env.py:7-16
+        obs, _, _ = self.env.step(self._actions_to_device(actions))
+        self._pending = obs
+        self.waiting_step = True
+
+    def step_wait(self):
+        if not self.waiting_step:
+            raise RuntimeError("not running an async step")              # vec_env.py:19-27
+        obs = self._pending
+        h = self.env.step_info_host()                                    # the only sync point of a step
+        self.env.check_device_error()                                    # kernels raise an error word; fail loudly
+        self._pending = None
+        self.waiting_step = False
+        reward = torch.from_numpy(h["reward"]).unsqueeze(dim=1).float()   # envs.py:164
+        return obs, reward, h["done"], _Infos(h, round(time.time() - self.tstart, 6))
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def get_action_candidates(self, order_actions) -> torch.Tensor:
+        """Location observations [N, 5S+9+Hc].  The trainer wraps the return value with
+        ``torch.from_numpy(np.array(..))`` (trainer.py:267-268); a device tensor also supports
+        ``np.array`` after ``.cpu()``, and callers that accept tensors can skip the round trip."""
+        return self.env.get_action_candidates(self._actions_to_device(order_actions))
+
+    def close(self):
+        if not self.closed:
+            self.env.close()
+            self.closed = True
+
+    def get_images(self):
+        raise NotImplementedError("rendering belongs to the pybullet path, which is out of scope")
+
+
+def make_vec_envs(args, log_dir=None, allow_early_resets=False):
+    """Same triple as envs.make_vec_envs (envs.py:67-99): (envs, [obs_space, act_space], obs_len).
+    ``args`` is the reference's namespace plus ``args.sequences`` (pre-drawn item ids) and either
+    ``args.shapes`` (a ShapeSet) or the reference's ``args.shotInfo``/``args.infoDict``."""
+    shapes = getattr(args, "shapes", None)
+    if shapes is None:
+        shapes = shape_set_from_reference(args.shotInfo, args.infoDict)
+    dev = args.device if isinstance(args.device, (str, torch.device)) else f"cuda:{int(args.device)}"
+    envs = GpuVecEnv(shapes, args.sequences, args.num_processes, device=dev,
+                     resolutionA=args.resolutionA, resolutionH=args.resolutionH,
+                     resolutionZ=getattr(args, "resolutionZ", 0.01),
+                     bin_dimension=tuple(getattr(args, "bin_dimension", BIN_DIMENSION)),
+                     selectedAction=args.selectedAction, bufferSize=args.bufferSize,
+                     scale_z=float(getattr(args, "scale", [100, 100, 100])[2]))
+    return envs, [envs.observation_space, envs.action_space], envs.obs_len
+
+
+def shape_set_from_reference(shotInfo, infoDict) -> ShapeSet:
+    """Build a ShapeSet from the reference's in-memory containers (tools.py:227-279)."""
+    ids = sorted(shotInfo.keys())
+    assert ids == list(range(len(ids))), "shape ids must be 0..n-1"
+    extents = np.array([[np.asarray(infoDict[k][r]["extents"], dtype=np.float64) for r in range(len(shotInfo[k]))]
+                        for k in ids])
+    volumes = np.array([float(infoDict[k][0]["volume"]) for k in ids])
+    tables = [[tuple(np.asarray(a, dtype=np.float64) for a in shotInfo[k][r]) for r in range(len(shotInfo[k]))]
+              for k in ids]
+    return ShapeSet(extents, volumes, tables, name="reference")

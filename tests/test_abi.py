@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/irbpp.h declares.  No compute calls (there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()
+    return _lib.load()
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "irbpp.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(irbpp_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/irbpp.h but not exported"
+    assert set(names) == set(_lib.SIGNATURES), "ctypes binding and header disagree"
+
+
+def test_status_strings_and_version(lib):
+    assert lib.irbpp_version() >= 100
+    assert lib.irbpp_status_string(0) == b"ok"
+    assert b"argument" in lib.irbpp_status_string(-1)
+
+
+def test_create_rejects_bad_config(lib):
+    cfg = _lib.IrbppConfig(num_bins=0, n_rot=4, selected=500, buffer_size=1, resolution_a=0.02,
+                           resolution_h=0.01, resolution_z=0.01, bin=(ctypes.c_double * 3)(0.32, 0.32, 0.3),
+                           scale_z=100.0)
+    h = ctypes.c_void_p()
+    assert lib.irbpp_create(ctypes.byref(cfg), ctypes.byref(h)) == -1       # IRBPP_ERR_ARG before any HIP call
+    cfg.num_bins, cfg.n_rot = 4, 9
+    assert lib.irbpp_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "ir-bpp_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f

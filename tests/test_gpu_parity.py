@@ -1,0 +1,240 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle and
+the committed golden vectors.  Integer/index/heightmap/mask results bit-exact; float32
+observations equal to the float64 oracle after the same final cast; reward within 1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd import synthetic
+from irbpp_amd.vec_env import GpuPackingEnv, GpuVecEnv
+from oracle import cvtools
+from oracle.packing import OracleVecEnv
+from oracle.space import Space
+from helpers import golden_scenario, minz_action
+
+pytestmark = pytest.mark.gpu
+S = 500
+DEV = "cuda:0"
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+def _run_online(shapes, seqs, n, steps, **kw):
+    genv = GpuVecEnv(shapes, seqs, n, device=DEV, **kw)
+    oenv = OracleVecEnv(n, shapes, seqs, **kw)
+    gobs = genv.reset()
+    oobs = _f32(oenv.reset())
+    np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+    ndone = 0
+    for t in range(steps):
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        ref_act = np.array([minz_action(o, S) for o in oobs])
+        np.testing.assert_array_equal(act, ref_act)
+        gobs, grew, gdone, ginfo = genv.step(act)
+        oobs, orew, odone, oinfo = oenv.step(act)
+        oobs = _f32(oobs)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), oobs, err_msg=f"obs step {t}")
+        np.testing.assert_array_equal(gdone, odone)
+        np.testing.assert_allclose(grew.numpy()[:, 0], orew, atol=1e-5, rtol=0)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], orew.astype(np.float32))
+        for i in range(n):
+            gi, oi = ginfo[i], oinfo[i]
+            assert gi["Valid"] is True
+            if odone[i]:
+                ndone += 1
+                assert gi["counter"] == oi["counter"] and gi["ratio"] == oi["ratio"]
+                assert gi["episode"]["r"] == oi["episode"]["r"] and gi["episode"]["l"] == oi["episode"]["l"]
+            else:
+                assert "episode" not in gi
+        hm = genv.env.get_heightmaps().cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(hm[i], oenv.envs[i].space.heightmapC)
+    genv.env.check_device_error()
+    genv.close()
+    return ndone
+
+
+def test_online_cube_matches_oracle():
+    sh = synthetic.cube_shapes()
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 64, 60, seed=123), 6, 45) >= 3
+
+
+def test_online_blockout_matches_oracle():
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5), 6, 60) >= 2
+
+
+def test_online_general_r8_matches_oracle():
+    sh = synthetic.general_shapes(n_shapes=24, n_rot=8, seed=1)
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 64, 60, seed=9), 5, 30) >= 3
+
+
+def test_online_fine_heightmap_matches_oracle():
+    sh = synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=4)
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 32, 60, seed=2), 3, 14, resolutionH=0.005) >= 1
+
+
+def test_exhausted_trajectory_ends_episode():
+    sh = synthetic.blockout_shapes(n_shapes=8, n_rot=4, cube=0.04, seed=2)
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 16, 5, seed=1), 3, 16) >= 3
+
+
+def test_hierarchical_matches_oracle():
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    n, k = 4, 5
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k)
+    oenv = OracleVecEnv(n, sh, seqs, bufferSize=k)
+    gord = genv.reset()
+    oord = _f32(oenv.reset())
+    np.testing.assert_array_equal(gord.cpu().numpy(), oord)
+    ndone = 0
+    for t in range(70):
+        oa = np.array([(t * 7 + 3 + i) % k for i in range(n)])
+        gloc = genv.get_action_candidates(oa)
+        oloc = _f32(oenv.get_action_candidates(oa))
+        np.testing.assert_array_equal(gloc.cpu().numpy(), oloc)
+        act = genv.env.policy_minz(gloc).cpu().numpy()
+        gord, grew, gdone, ginfo = genv.step(act)
+        oord, orew, odone, oinfo = oenv.step(act)
+        np.testing.assert_array_equal(gord.cpu().numpy(), _f32(oord))
+        np.testing.assert_array_equal(gdone, odone)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], orew.astype(np.float32))
+        ndone += int(odone.sum())
+    genv.close()
+    assert ndone >= 2
+
+
+@pytest.mark.parametrize("name", ["online_cube", "online_blockout", "online_general"])
+def test_online_matches_reference_golden(golden_dir, name):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    genv = GpuVecEnv(golden_scenario(name), g["seq"], 1, device=DEV)
+    obs = genv.reset().cpu().numpy()[0]
+    np.testing.assert_array_equal(obs, _f32(g["obs"][0]))
+    for t in range(len(g["act"])):
+        a = minz_action(obs, S)
+        assert a == g["act"][t]
+        o, r, d, info = genv.step(np.array([a]))
+        obs = o.cpu().numpy()[0]
+        assert d[0] == g["done"][t] and r.numpy()[0, 0] == np.float32(g["rew"][t])
+        if d[0]:
+            assert info[0]["counter"] == g["counter"][t] and info[0]["ratio"] == g["ratio"][t]
+            assert info[0]["episode"]["r"] == g["ep_r"][t]
+        ref = _f32(g["obs"][t + 1])
+        np.testing.assert_array_equal(obs[5 * S:], ref[5 * S:])
+        if (ref[:5 * S].reshape(S, 5)[:, 4] == 1).any():
+            np.testing.assert_array_equal(obs, ref)
+    genv.close()
+
+
+def test_possible_position_random_heightmaps():
+    sh = synthetic.general_shapes(n_shapes=20, n_rot=8, seed=6)
+    n = 32
+    env = GpuPackingEnv(sh, synthetic.make_sequences(sh.n_shapes, 8, 8), n, device=DEV)
+    rng = np.random.RandomState(0)
+    hm = np.zeros((n, 32, 32))
+    for b in range(n):
+        kind = b % 4
+        if kind == 0:
+            hm[b] = np.kron(rng.randint(0, 8, (8, 8)), np.ones((4, 4))) * 0.04
+        elif kind == 1:
+            hm[b] = rng.uniform(0, 0.3, (32, 32))
+        elif kind == 2:
+            hm[b] = np.round(rng.uniform(0, 0.29, (32, 32)), 2)
+        # kind 3: empty bin
+    ids = rng.randint(0, sh.n_shapes, n).astype(np.int32)
+    env.set_heightmaps(torch.from_numpy(hm).to(DEV))
+    posz, mask = env.possible_position(torch.from_numpy(ids).to(DEV))
+    posz, mask = posz.cpu().numpy(), mask.cpu().numpy()
+    sp = Space(np.round([0.32, 0.32, 0.30], 6), 0.02, 0.01, sh.n_rot, sh.shot_info(), sh.extents)
+    for b in range(n):
+        sp.heightmapC[:] = hm[b]
+        m = sp.get_possible_position(int(ids[b]))
+        np.testing.assert_array_equal(mask[b], m.astype(np.uint8))
+        np.testing.assert_array_equal(posz[b], sp.posZmap)
+    env.check_device_error()
+    env.close()
+
+
+def _vertex_rows_to_candidates(rows, posz, n_rot):
+    out = []
+    for r in range(n_rot):
+        pts = [(x, y) for x in range(16) for y in range(16) if (int(rows[r, y]) >> x) & 1]
+        for x, y in pts:                          # ordered by (col, row) like np.unique
+            out.append([r, y, x, posz[r, y, x], 1.0])
+    return np.array(out) if out else None
+
+
+def test_convex_hull_actions_golden_and_random(golden_dir):
+    g = np.load(os.path.join(golden_dir, "cvtools_cases.npz"))
+    sh = synthetic.cube_shapes()
+    rng = np.random.RandomState(3)
+    for R in (2, 4, 8):
+        env = GpuPackingEnv(synthetic.blockout_shapes(8, n_rot=R) if R > 2 else sh,
+                            synthetic.make_sequences(8, 4, 4), 1, device=DEV)
+        idx = [i for i in range(len(g["n_rot"])) if g["n_rot"][i] == R]
+        posz = [g["posz"][i][:R] for i in idx]
+        mask = [g["mask"][i][:R] for i in idx]
+        for _ in range(40):                       # adversarial random images: dense, sparse, diagonal
+            m = (rng.uniform(size=(R, 16, 16)) < rng.choice([0.3, 0.5, 0.7, 0.95])).astype(np.float64)
+            z = np.where(m > 0, rng.randint(0, rng.choice([1, 2, 4, 30]), (R, 16, 16)) * 0.01, 1e3)
+            posz.append(z)
+            mask.append(m)
+        posz, mask = np.array(posz), np.array(mask)
+        rows = env.convex_hull_actions(torch.from_numpy(posz).to(DEV),
+                                       torch.from_numpy(mask.astype(np.uint8)).to(DEV)).cpu().numpy()
+        for i in range(len(posz)):
+            ref = cvtools.getConvexHullActions(posz[i], mask[i], 0.01)
+            got = _vertex_rows_to_candidates(rows[i], posz[i], R)
+            if ref is None:
+                assert got is None
+            else:
+                np.testing.assert_array_equal(got, ref)
+            if i < len(idx):                      # and the reference-generated golden rows
+                n = int(g["cand_len"][idx[i]])
+                if n:
+                    np.testing.assert_array_equal(got, g["cand"][idx[i]][:n])
+        env.check_device_error()
+        env.close()
+
+
+def test_full_size_properties_and_sharding_invariance():
+    """BASELINE config 2 at full width: size-independent properties instead of an oracle run."""
+    sh = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 10000, 160, seed=123)
+    n = 4096
+    env = GpuPackingEnv(sh, seqs, n, device=DEV)
+    half = [GpuPackingEnv(sh, seqs, n // 2, device=DEV, global_offset=o, global_bins=n) for o in (0, n // 2)]
+    obs = env.reset()
+    hobs = [h.reset() for h in half]
+    vol = torch.from_numpy(sh.volumes).to(DEV)
+    prev_hm = env.get_heightmaps().clone()
+    placed_vol = torch.zeros(n, dtype=torch.float64, device=DEV)
+    for t in range(40):
+        act = env.policy_minz(obs)
+        item = obs[:, 5 * S].to(torch.int64)
+        obs, rew, done = env.step(act)
+        hacts = [h.policy_minz(o) for h, o in zip(half, hobs)]
+        hobs = [h.step(a)[0] for h, a in zip(half, hacts)]
+        assert torch.equal(torch.cat(hobs), obs), "result depends on how bins are sharded"
+        hm = env.get_heightmaps()
+        d = done.bool()
+        assert bool((hm[d] == 0).all())                                   # auto-reset leaves an empty bin
+        assert bool((hm[~d] >= prev_hm[~d]).all())                        # heights only grow inside an episode
+        assert float(hm.max()) <= 0.30 + 1e-9
+        assert torch.equal(obs[:, 5 * S + 9:], hm.reshape(n, -1).float())  # obs carries the heightmap
+        exp_rew = torch.where(d, torch.zeros_like(rew), vol[item.clamp(min=0)] / 0.03072 * 10)
+        assert torch.allclose(rew, exp_rew, atol=1e-12, rtol=0)
+        placed_vol = torch.where(d, torch.zeros_like(placed_vol), placed_vol + vol[item.clamp(min=0)])
+        assert bool((placed_vol <= 0.03072 + 1e-12).all())                # never more volume than the bin holds
+        prev_hm = hm.clone()
+    tot = env.episode_totals().cpu().numpy()
+    assert tot[0] >= 0 and tot[1] <= tot[0]                               # ratios are in [0,1]
+    env.check_device_error()
+    for e in [env] + half:
+        e.close()
