@@ -74,12 +74,31 @@ def algorithmic_bytes_per_step(shapes, hc, k=1):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the oracle (a restatement of the reference's numpy path) on the host cores
 # ---------------------------------------------------------------------------------------------
+def usable_cores():
+    """Cores this process may really use: affinity mask and cgroup quota, not just cpu_count()."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def _cpu_worker(args):
-    name, rank, envs_per_proc, steps = args
+    """One OS process = one bin, like wrapper/shmem_vec_env.py:120-157.  Runs for a fixed wall time."""
+    name, rank, seconds = args
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
     sys.path.insert(0, ROOT)
     from oracle.packing import OracleVecEnv
     shapes, seqs, kw = make_workload(name)
-    env = OracleVecEnv(envs_per_proc, shapes, seqs, global_offset=rank * envs_per_proc, global_num=1 << 20, **kw)
+    env = OracleVecEnv(1, shapes, seqs, global_offset=rank, global_num=1 << 20, **kw)
     obs = env.reset()
 
     def minz(o):
@@ -87,27 +106,24 @@ def _cpu_worker(args):
         v = c[:, 4] == 1
         return int(np.argmin(np.where(v, c[:, 3], np.inf))) if v.any() else 0
 
+    n = 0
     t0 = time.perf_counter()
-    for _ in range(steps):
+    while time.perf_counter() - t0 < seconds:
         obs, _, _, _ = env.step([minz(o) for o in obs])
-    return time.perf_counter() - t0
+        n += 1
+    return n, time.perf_counter() - t0
 
 
 def cpu_baseline(name, budget_s=15.0):
-    cores = os.cpu_count() or 1
-    envs_per_proc = 1
-    probe = _cpu_worker((name, 0, 1, 3)) / 3.0                  # seconds per env-step on one core
-    steps = max(4, int(budget_s / max(probe, 1e-4)))
-    steps = min(steps, 2000)
+    cores = usable_cores()
     ctx = mp.get_context("fork")
     with ctx.Pool(cores) as pool:
-        t0 = time.perf_counter()
-        pool.map(_cpu_worker, [(name, r, envs_per_proc, steps) for r in range(cores)])
-        wall = time.perf_counter() - t0
-    total = cores * envs_per_proc * steps
-    return {"value": total / wall, "unit": "placement-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x {envs_per_proc} bin x {steps} steps of the python/numpy oracle "
-                      f"(process-per-bin like shmem_vec_env; no physics, which flatters the CPU side)"}
+        res = pool.map(_cpu_worker, [(name, r, budget_s) for r in range(cores)])
+    rate = sum(n / t for n, t in res)
+    return {"value": rate, "unit": "placement-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{cores} processes x 1 bin x {budget_s:.0f} s of the python/numpy oracle, "
+                      f"{sum(n for n, _ in res)} steps in total (process-per-bin like shmem_vec_env; "
+                      f"no physics, which flatters the CPU side)"}
 
 
 def main():

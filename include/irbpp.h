@@ -133,8 +133,9 @@ int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev,
 
 /* getConvexHullActions (cvTools.py:61-102) on caller-supplied grids, independent of the
  * environment state: posz_valid_dev float64[n_grids][n_rot][Ax][Ay], mask_dev
- * uint8[n_grids][n_rot][Ax][Ay].  vertex_rows_dev: uint32[n_grids][n_rot][Ax], bit y of word
- * x... see DESIGN.md: word `row` has bit `col` set iff (row, col) is a candidate. */
+ * uint8[n_grids][n_rot][Ax][Ay].  vertex_rows_dev: uint32[n_grids][n_rot][16]; word `row` has
+ * bit `col` set iff (row, col) is a candidate of that rotation (np.unique makes the candidate
+ * list a set, cvTools.py:101, so the bit grid is its exact representation). */
 int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev,
                               const uint8_t* mask_dev, uint32_t* vertex_rows_dev, void* stream);
 
@@ -146,6 +147,11 @@ int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream);
  * (trainer.py:215-222): out_dev float64[4] = {episodes, sum ratio, sum counter, sum reward}.
  * The multi-GPU runner all-reduces these four numbers (RCCL). */
 int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream);
+
+/* Tooling: when cycles_dev != NULL every later transition launch stores, per bin, eight
+ * shader-clock stamps int64[num_bins][8]: 0 start, 1 action applied, 2 overlap test done,
+ * 3 contour stage done, 4 observation written (5..7 unused).  NULL switches it off. */
+int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
 
 /* Device-side error word raised by kernels (0 = none).  Synchronises the stream. */
 int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);

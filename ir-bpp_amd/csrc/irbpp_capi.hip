@@ -24,6 +24,7 @@ struct irbpp_env {
     Tables T;
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
+    long long* phase_cycles = nullptr;
     std::vector<void*> allocs;
 };
 
@@ -255,7 +256,8 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
     return which == 0 ? env->P.obs_len0 : env->P.obs_len1;
 }
 
-static int launch_env(irbpp_env* env, const StepIO& io, int mode, void* stream) {
+static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream) {
+    io.phase_cycles = env->phase_cycles;
     hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                        env->P, env->T, env->S, io, mode);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
@@ -350,6 +352,12 @@ int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream) {
     if (!env || !out_dev) return IRBPP_ERR_ARG;
     hipLaunchKernelGGL(irbpp_totals_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, env->S.totals, env->P.N, out_dev);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
+    if (!env) return IRBPP_ERR_ARG;
+    env->phase_cycles = (long long*)cycles_dev;
+    return IRBPP_OK;
 }
 
 int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out) {

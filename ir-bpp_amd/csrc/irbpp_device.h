@@ -81,6 +81,7 @@ struct StepIO {
     int32_t* ep_len;
     double* posz_out;           // MODE_POSSIBLE
     uint8_t* mask_out;
+    long long* phase_cycles;    // optional [N][8] shader-clock stamps per phase (tooling)
 };
 
 }  // namespace irbpp

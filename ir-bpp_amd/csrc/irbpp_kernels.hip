@@ -98,6 +98,11 @@ __device__ inline int fetch_item(const Params& P, const Tables& T, const State& 
     return id < 0 ? -1 : id;
 }
 
+// optional per-phase shader-clock stamps (s_memtime), one row of 8 per bin
+__device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
+    if (io.phase_cycles && threadIdx.x == 0) io.phase_cycles[(size_t)b * 8 + k] = (long long)clock64();
+}
+
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
     SlotMem m;
     m.lab = (uint32_t*)base;
@@ -262,8 +267,10 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     const int nvalid = block_sum_int(my_valid, L.redi);      // np.sum(naiveMask) for prejudge
     if (debug_out) return;
     __syncthreads();
+    stamp(io, b, 2);
 
     contour_stage(P, S, L);
+    stamp(io, b, 3);
 
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
@@ -359,6 +366,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         S.cur_item[b] = item;
         S.nvalid[b] = nvalid;
     }
+    stamp(io, b, 4);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -374,6 +382,7 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
     int32_t* q = S.queue + (size_t)b * P.K;
     float* obs = io.obs ? io.obs + (size_t)b * io.obs_stride : nullptr;
 
+    stamp(io, b, 0);
     // stage the heightmap tile
     if (mode == MODE_RESET) {
         for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }
@@ -508,6 +517,7 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         __syncthreads();
     }
 
+    stamp(io, b, 1);
     if (P.K == 1) {                      // online: cur_observation with a fresh item (binPhy.py:188-227)
         const int item = L.redi[16];
         __syncthreads();

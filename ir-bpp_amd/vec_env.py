@@ -185,6 +185,12 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_episode_totals(self._h, _ptr(out), self._stream()), "irbpp_episode_totals")
         return out
 
+    def enable_phase_cycles(self, on: bool = True) -> Optional[torch.Tensor]:
+        """Tooling: int64[N,8] shader-clock stamps written by every later transition launch."""
+        self._cycles = torch.zeros((self.num_bins, 8), dtype=torch.int64, device=self.device) if on else None
+        _lib.check(self.lib.irbpp_debug_phase_cycles(self._h, _ptr(self._cycles)), "irbpp_debug_phase_cycles")
+        return self._cycles
+
     def check_device_error(self) -> None:
         flags = C.c_int32(0)
         _lib.check(self.lib.irbpp_device_error(self._h, self._stream(), C.byref(flags)),

@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""Tooling: where do the cycles of the transition kernel go?  Runs a workload into steady state,
+then switches on the per-bin phase stamps (irbpp_debug_phase_cycles) and prints, per phase, the
+mean and the maximum over bins in shader-clock cycles."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import irbpp_amd  # noqa: E402,F401
+from bench import make_workload  # noqa: E402
+from irbpp_amd.vec_env import GpuPackingEnv  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="blockout")
+ap.add_argument("--bins", type=int, default=4096)
+ap.add_argument("--warm", type=int, default=120)
+ap.add_argument("--steps", type=int, default=8)
+ap.add_argument("--slots", type=int, default=0)
+a = ap.parse_args()
+
+shapes, seqs, kw = make_workload(a.workload)
+env = GpuPackingEnv(shapes, seqs, a.bins, device="cuda:0", contour_slots=a.slots, **kw)
+obs = env.reset()
+for _ in range(a.warm):
+    obs, _, _ = env.step(env.policy_minz(obs))
+cyc = env.enable_phase_cycles(True)
+names = ["apply", "overlap", "contour", "emit"]
+acc = []
+for _ in range(a.steps):
+    obs, _, _ = env.step(env.policy_minz(obs))
+    torch.cuda.synchronize()
+    c = cyc.cpu().numpy()
+    acc.append(np.diff(c[:, :5], axis=1))
+d = np.concatenate(acc)
+ncand = (obs[:, :2500].reshape(a.bins, 500, 5)[:, :, 4] == 1).sum(1).float()
+out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
+       "mean_cycles": {n: float(d[:, i].mean()) for i, n in enumerate(names)},
+       "p99_cycles": {n: float(np.percentile(d[:, i], 99)) for i, n in enumerate(names)},
+       "max_cycles": {n: float(d[:, i].max()) for i, n in enumerate(names)},
+       "total_mean": float(d.sum(1).mean()), "mean_candidates": float(ncand.mean())}
+print(json.dumps(out))
