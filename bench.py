@@ -138,23 +138,19 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from irbpp_amd import distributed as D
     cpu = None
-    if world == 1 and not a.no_cpu_baseline:
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline:
         cpu = cpu_baseline(a.workload, a.cpu_budget)       # before HIP is initialised: the pool forks
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+    rank, world, local_rank = D.init_from_env("nccl")       # nccl == RCCL on ROCm
     assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     from irbpp_amd.vec_env import GpuPackingEnv
     shapes, seqs, kw = make_workload(a.workload)
-    env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, global_offset=rank * a.bins,
-                        global_bins=world * a.bins, contour_slots=a.slots, **kw)
+    env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, contour_slots=a.slots,
+                        **D.shard(rank, world, a.bins), **kw)
     hc = env.Hx * env.Hy
     obs_a = env.reset()
     obs_b = torch.empty_like(obs_a)
@@ -175,9 +171,7 @@ def main():
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
 
     def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+        D.barrier(dev)
 
     barrier()
     t0 = time.perf_counter()
@@ -189,13 +183,8 @@ def main():
     env.check_device_error()
 
     kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))     # transition kernel only
-    tot = env.episode_totals()
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if world > 1:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)       # the only exchange: 4 doubles of episode statistics
-    elapsed = float(t_max.item())
-    tot = tot.cpu().numpy()
+    elapsed = D.max_over_ranks(elapsed, dev)
+    tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
 
     if rank == 0:
         total_steps = a.bins * world * a.steps

@@ -1,0 +1,53 @@
+"""Multi-GPU sharding of bins: one process per GPU, no data-path collective.
+
+Bins are independent, so rank r simply owns the global bins
+[r*n, (r+1)*n).  The trajectory of global bin g in episode e is
+(traj_start + g + e*global_bins) % n_traj, which makes every result independent of the world
+size.  The only exchange is the episode statistics for logging (trainer.py:215-222): one
+all-reduce of four doubles over RCCL (backend "nccl" on ROCm; "gloo" in the CPU tests)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str = "nccl"):
+    """(rank, world, local_rank) from the torchrun environment; initialises the process group
+    when WORLD_SIZE > 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, world, local_rank
+
+
+def shard(rank: int, world: int, bins_per_rank: int):
+    """-> dict(global_offset, global_bins) for GpuPackingEnv / irbpp_config."""
+    assert 0 <= rank < world
+    return {"global_offset": rank * bins_per_rank, "global_bins": world * bins_per_rank}
+
+
+def reduce_totals(totals: torch.Tensor) -> torch.Tensor:
+    """Sum [episodes, sum ratio, sum counter, sum reward] over ranks (in place)."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    return totals
+
+
+def max_over_ranks(value: float, device) -> float:
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def barrier(device=None):
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+    if device is not None and torch.device(device).type == "cuda":
+        torch.cuda.synchronize(device)
