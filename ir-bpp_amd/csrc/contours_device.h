@@ -9,9 +9,12 @@
 // and ORs the surviving vertices into a per-rotation 16x16 bit grid (np.unique at
 // cvTools.py:101 makes the result a set, so a bit grid is its exact representation).
 //
-// The label image keeps 2 bits per pixel: 0 background, 1 untouched foreground, 2 visited,
-// 3 visited + "right bound" (OpenCV's nbd|0x80).  Only those classes steer the scan
-// (contours.cpp, cvFindNextContour), so the per-contour label values are not needed.
+// Representation: the image is 16 rows of 16 bits (bit x of row y = pixel (x,y)), read-only.
+// OpenCV's label image only ever distinguishes 0 / 1 (untouched) / visited / visited with the
+// "right bound" sign bit (nbd|0x80) in its raster scan (contours.cpp, cvFindNextContour), so the
+// labels are two more bit planes per slot: `vis` and `neg`.  A border-following step looks at
+// the 3x3 neighbourhood as one 8-bit mask and finds the next direction with a rotate + bit
+// scan instead of up to eight probes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -19,7 +22,8 @@
 namespace irbpp {
 
 struct SlotMem {
-    uint32_t* lab;      // [16] 2-bit label rows
+    uint16_t* vis;      // [16] visited plane (label != 1)
+    uint16_t* neg;      // [16] right-bound plane (label < 0)
     uint8_t*  pts;      // [cap] contour points, x | y<<4
     uint8_t*  dst;      // [cap] approximated polygon
     uint32_t* stk;      // [cap_stk] Douglas-Peucker slices, start | end<<16
@@ -31,68 +35,74 @@ struct SlotMem {
 __device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
 __device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
 
-__device__ __forceinline__ int lab_get(const uint32_t* lab, int x, int y) {
-    return ((unsigned)x < 16u && (unsigned)y < 16u) ? (int)((lab[y] >> (2 * x)) & 3u) : 0;
-}
-__device__ __forceinline__ void lab_set(uint32_t* lab, int x, int y, uint32_t v) {
-    lab[y] = (lab[y] & ~(3u << (2 * x))) | (v << (2 * x));
-}
-
-// spread the low 16 bits of v to the even bit positions (pixel x -> bit 2x)
-__device__ __forceinline__ uint32_t spread16(uint32_t v) {
-    v &= 0xFFFFu;
-    v = (v | (v << 8)) & 0x00FF00FFu;
-    v = (v | (v << 4)) & 0x0F0F0F0Fu;
-    v = (v | (v << 2)) & 0x33333333u;
-    v = (v | (v << 1)) & 0x55555555u;
-    return v;
+// 8-bit neighbour mask of pixel (x,y): bit s set iff the neighbour in direction s is foreground
+__device__ __forceinline__ uint32_t neighbours(const uint32_t* img, int x, int y) {
+    const uint32_t a = y > 0 ? img[y - 1] : 0u;
+    const uint32_t b = img[y];
+    const uint32_t c = y < 15 ? img[y + 1] : 0u;
+    const uint32_t ta = ((a << 1) >> x) & 7u;      // bit0 = x-1, bit1 = x, bit2 = x+1
+    const uint32_t tb = ((b << 1) >> x) & 7u;
+    const uint32_t tc = ((c << 1) >> x) & 7u;
+    return (tb >> 2) | ((ta >> 2) << 1) | (((ta >> 1) & 1u) << 2) | ((ta & 1u) << 3) |
+           ((tb & 1u) << 4) | ((tc & 1u) << 5) | (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
 }
 
-// icvFetchContourEx with CHAIN_APPROX_SIMPLE.  Returns the number of points produced
-// (stored only while they fit in cap), or -1 if the iteration guard tripped.
-__device__ inline int trace_border(uint32_t* lab, int x0, int y0, bool is_hole, bool store,
-                                   uint8_t* pts, int cap) {
-    int s_end = is_hole ? 0 : 4;
-    int s = s_end;
-    int x1, y1;
-    do {
-        s = (s - 1) & 7;
-        x1 = x0 + dir_dx(s);
-        y1 = y0 + dir_dy(s);
-    } while (lab_get(lab, x1, y1) == 0 && s != s_end);
-    if (s == s_end) {                       // isolated pixel
-        lab_set(lab, x0, y0, 3u);
-        if (store && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
-        return 1;
-    }
-    int x3 = x0, y3 = y0, x4 = x0, y4 = y0;
-    int prev_s = s ^ 4;
-    int px = x0, py = y0;
-    int n = 0;
-    for (int guard = 0; guard < 4096; ++guard) {
-        s_end = s;
-        while (s < 15) {
-            ++s;
-            x4 = x3 + dir_dx(s & 7);
-            y4 = y3 + dir_dy(s & 7);
-            if (lab_get(lab, x4, y4) != 0) break;
+// icvFetchContourEx with CHAIN_APPROX_SIMPLE.  img rows hold the 16-bit foreground rows.
+// Returns the number of points produced (stored only while they fit in cap), or -1 if the
+// iteration guard tripped.
+__device__ inline int trace_border(const uint32_t* img, uint16_t* vis, uint16_t* neg, int x0, int y0,
+                                   bool is_hole, bool store, uint8_t* pts, int cap) {
+    const int s_first = is_hole ? 0 : 4;
+    uint32_t nb = neighbours(img, x0, y0);
+    // clockwise search s_first-1, s_first-2, ... for the first foreground neighbour
+    {
+        const int k = (s_first - 1) & 7;                          // first direction probed
+        const uint32_t rot = ((nb << (7 - k)) | (nb >> (k + 1))) & 0xFFu;   // direction k -> bit 7
+        if (rot == 0u) {                                          // isolated pixel
+            vis[y0] |= (uint16_t)(1u << x0);
+            neg[y0] |= (uint16_t)(1u << x0);
+            if (store && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
+            return 1;
         }
-        s &= 7;
-        if ((unsigned)(s - 1) < (unsigned)s_end) lab_set(lab, x3, y3, 3u);
-        else if (lab_get(lab, x3, y3) == 1) lab_set(lab, x3, y3, 2u);
-        if (s != prev_s) {
-            if (store && n < cap) pts[n] = (uint8_t)(px | (py << 4));
-            ++n;
+        const int p = 31 - __clz((int)rot);                       // highest set bit, 7 = direction k
+        const int s = (k - (7 - p)) & 7;
+        // fallthrough with s
+        int x3 = x0, y3 = y0;
+        const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+        int prev_s = s ^ 4;
+        int cur_s = s;
+        int px = x0, py = y0;
+        int n = 0;
+        for (int guard = 0; guard < 4096; ++guard) {
+            const int s_end = cur_s;
+            // counter-clockwise search s_end+1, s_end+2, ... for the next border pixel
+            const int k2 = (s_end + 1) & 7;
+            const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
+            const int t = __ffs((int)r2) - 1;
+            const int s2 = (k2 + t) & 7;
+            const int x4 = x3 + dir_dx(s2), y4 = y3 + dir_dy(s2);
+            const uint16_t bit = (uint16_t)(1u << x3);
+            if ((unsigned)(s2 - 1) < (unsigned)s_end) {           // the east neighbour was probed empty
+                vis[y3] |= bit;
+                neg[y3] |= bit;
+            } else {
+                vis[y3] |= bit;                                   // 1 -> nbd; other labels unchanged
+            }
+            if (s2 != prev_s) {                                   // CHAIN_APPROX_SIMPLE
+                if (store && n < cap) pts[n] = (uint8_t)(px | (py << 4));
+                ++n;
+            }
+            prev_s = s2;
+            px += dir_dx(s2);
+            py += dir_dy(s2);
+            if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
+            x3 = x4;
+            y3 = y4;
+            cur_s = (s2 + 4) & 7;
+            nb = neighbours(img, x3, y3);
         }
-        prev_s = s;
-        px += dir_dx(s);
-        py += dir_dy(s);
-        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-        x3 = x4;
-        y3 = y4;
-        s = (s + 4) & 7;
+        return -1;
     }
-    return -1;
 }
 
 #define IRBPP_PX(p) ((int)((p) & 15))
@@ -110,21 +120,24 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     uint8_t start_pt = 0;
     for (int it = 0; it < 3; ++it) {
         int max_dist = 0;
-        pos = (pos + right_start) % count;
+        pos += right_start;
+        if (pos >= count) pos -= count;
         start_pt = pts[pos];
         if (++pos >= count) pos = 0;
+        const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
         for (int j = 1; j < count; ++j) {
             const uint8_t pt = pts[pos];
             if (++pos >= count) pos = 0;
-            const int dx = IRBPP_PX(pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
+            const int dx = IRBPP_PX(pt) - sx, dy = IRBPP_PY(pt) - sy;
             const int dist = dx * dx + dy * dy;
             if (dist > max_dist) { max_dist = dist; right_start = j; }
         }
         le_eps = max_dist <= 1;
     }
     if (!le_eps) {
-        const int s0 = pos % count;
-        const int far = (right_start + s0) % count;
+        const int s0 = pos;                          // pos < count always
+        int far = right_start + s0;
+        if (far >= count) far -= count;
         if (cap_stk < 2) return false;
         stk[top++] = (uint32_t)far | ((uint32_t)s0 << 16);       // right slice
         stk[top++] = (uint32_t)s0 | ((uint32_t)far << 16);       // slice, processed first
@@ -142,14 +155,15 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
         bool le;
         int split = 0;
         if (pos != s_end) {
-            const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
+            const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
+            const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
             int max_dist = 0;
             while (pos != s_end) {
                 const uint8_t pt = pts[pos];
-                if (++pos >= count) pos = 0;
-                int dist = (IRBPP_PY(pt) - IRBPP_PY(start_pt)) * dx - (IRBPP_PX(pt) - IRBPP_PX(start_pt)) * dy;
+                int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
                 dist = dist < 0 ? -dist : dist;
-                if (dist > max_dist) { max_dist = dist; split = (pos + count - 1) % count; }
+                if (dist > max_dist) { max_dist = dist; split = pos; }
+                if (++pos >= count) pos = 0;
             }
             le = max_dist * max_dist <= dx * dx + dy * dy;
         } else {
@@ -196,42 +210,41 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     }
     // find_convex_vetex
     const int m = new_count;
-    for (int i = 0; i < m; ++i) {
-        const uint8_t b = dst[i];
-        bool keep = true;
-        if (m > 3) {
-            const uint8_t a = dst[i == 0 ? m - 1 : i - 1];
+    if (m <= 3) {
+        for (int i = 0; i < m; ++i) atomicOr(&vrows[IRBPP_PY(dst[i])], 1u << IRBPP_PX(dst[i]));
+    } else {
+        uint8_t a = dst[m - 1], b = dst[0];
+        for (int i = 0; i < m; ++i) {
             const uint8_t c = dst[i == m - 1 ? 0 : i + 1];
             const int cross = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
                               (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a));
-            keep = cross < 0;
+            if (cross < 0) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
+            a = b;
+            b = c;
         }
-        if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
     }
     return true;
 }
 
 // Whole level image: raster scan (cvFindNextContour) + per-outer-border approximation.
-// img_rows[y] bit x = foreground.  Returns 0 ok, 1 capacity overflow (caller retries with a
-// bigger slot), 2 iteration guard.
-__device__ inline int level_image_vertices(const uint32_t* img_rows, const SlotMem& m, uint32_t* vrows) {
-    for (int y = 0; y < 16; ++y) m.lab[y] = spread16(img_rows[y]);
+// img[y] bit x = foreground.  Returns 0 ok, 1 capacity overflow (caller retries with a bigger
+// slot), 2 iteration guard.
+__device__ inline int level_image_vertices(const uint32_t* img, const SlotMem& m, uint32_t* vrows) {
+    for (int y = 0; y < 16; ++y) { m.vis[y] = 0; m.neg[y] = 0; }
     for (int y = 0; y < 16; ++y) {
+        const uint32_t nz = img[y] & 0xFFFFu;
+        if (!nz) continue;
         int cur = 0;
         while (cur < 16) {
-            const uint32_t w = m.lab[y];
-            const uint32_t lo = w & 0x55555555u, hi = (w >> 1) & 0x55555555u;
-            const uint32_t nz = lo | hi;
-            const uint32_t untouched = lo & ~hi;                 // value 1
-            const uint32_t pos_lab = (hi & ~lo) | untouched;     // value >= 1 and not right-bound
-            const uint32_t outer = untouched & ~(nz << 2);       // prev == 0 && p == 1
-            const uint32_t hole = (~nz & 0x55555555u) & (pos_lab << 2);   // p == 0 && prev >= 1
-            uint32_t cand = (outer | hole) & ~((1u << (2 * cur)) - 1u);
+            const uint32_t vis = m.vis[y], neg = m.neg[y];
+            const uint32_t outer = nz & ~vis & ~(nz << 1);                    // prev == 0 && p == 1
+            const uint32_t hole = ~nz & (nz << 1) & ~(neg << 1) & 0xFFFFu;    // p == 0 && prev >= 1
+            const uint32_t cand = (outer | hole) & ~((1u << cur) - 1u);
             if (!cand) break;
-            const int x = (__ffs((int)cand) - 1) >> 1;
-            const bool is_hole = ((hole >> (2 * x)) & 1u) != 0;
+            const int x = __ffs((int)cand) - 1;
+            const bool is_hole = ((hole >> x) & 1u) != 0;
             const int ox = is_hole ? x - 1 : x;
-            const int n = trace_border(m.lab, ox, y, is_hole, !is_hole, m.pts, m.cap);
+            const int n = trace_border(img, m.vis, m.neg, ox, y, is_hole, !is_hole, m.pts, m.cap);
             if (n < 0) return 2;
             if (!is_hole) {
                 if (n > m.cap) return 1;

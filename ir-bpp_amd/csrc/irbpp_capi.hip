@@ -65,7 +65,7 @@ void layout_lds(Params& P, int want_slots) {
     if (P.nslot > 256) P.nslot = 256;
     P.slot_cap = 96;
     P.slot_stk = 24;
-    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk;              // 352, multiple of 16
+    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk + 4;          // 356 B = 89 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_hm = off;        off += align16(P.Hc * 8);
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
@@ -140,6 +140,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.Hc = P.Hx * P.Hy;
     P.AC = P.Ax * P.Ay;
     if (P.Ax > 16 || P.Ay > 16 || P.Ax < 1 || P.Ay < 1 || P.Hc > 128 * 128) { delete env; return IRBPP_ERR_ARG; }
+    if (P.Hx != P.Ax * P.step || P.Hy != P.Ay * P.step) { delete env; return IRBPP_ERR_ARG; }   // phase-plane tile layout
     P.traj_start = cfg->traj_start;
     P.goff = cfg->global_offset;
     P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
@@ -200,10 +201,12 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     HIP_TRY(hipSetDevice(env->cfg.device));
     const int R = P.R;
     std::vector<ShapeRot> sr((size_t)n_shapes * R);
+    std::vector<Cell> bcell, tcell;
     for (int k = 0; k < n_shapes; ++k) {
         for (int r = 0; r < R; ++r) {
             const size_t i = (size_t)k * R + r;
             ShapeRot& s = sr[i];
+            memset(&s, 0, sizeof(s));
             s.ext_x = extents[i * 3 + 0];
             s.ext_y = extents[i * 3 + 1];
             s.ext_z = extents[i * 3 + 2];
@@ -213,25 +216,36 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             s.fy = (int32_t)ceil(by / P.res_h);
             s.ax = (int32_t)ceil(bx / P.res_a);                                   // space.py:106
             s.ay = (int32_t)ceil(by / P.res_a);
-            s.off = offsets[i];
+            const int64_t off = offsets[i];
             if (s.fx != dims[i * 2] || s.fy != dims[i * 2 + 1]) return IRBPP_ERR_ARG;   // table shape must match
             if (s.fx < 1 || s.fy < 1 || s.fx > s.ax * P.step || s.fy > s.ay * P.step) return IRBPP_ERR_ARG;
-            if (s.off < 0 || s.off + (int64_t)s.fx * s.fy > pool_len) return IRBPP_ERR_ARG;
+            if (off < 0 || off + (int64_t)s.fx * s.fy > pool_len) return IRBPP_ERR_ARG;
+            // compact lists of the masked-in cells, row-major, with phase-plane tile offsets
+            s.ob = (int32_t)bcell.size();
+            s.ot = (int32_t)tcell.size();
+            for (int ci = 0; ci < s.fx; ++ci) {
+                for (int cj = 0; cj < s.fy; ++cj) {
+                    const int64_t e = off + (int64_t)ci * s.fy + cj;
+                    const double mt = mask_top[e], mb = mask_bottom[e];
+                    if ((mt != 0.0 && mt != 1.0) || (mb != 0.0 && mb != 1.0)) return IRBPP_ERR_ARG;
+                    const int32_t toff = ((ci % P.step) * P.step + (cj % P.step)) * P.AC + (ci / P.step) * P.Ay +
+                                         (cj / P.step);
+                    if (mb != 0.0) bcell.push_back(Cell{height_bottom[e], toff, 0});
+                    else s.has_out = 1;
+                    if (mt != 0.0) tcell.push_back(Cell{height_top[e], toff, 0});
+                }
+            }
+            s.nb = (int32_t)bcell.size() - s.ob;
+            s.nt = (int32_t)tcell.size() - s.ot;
+            if (s.nb == 0 && !s.has_out) return IRBPP_ERR_ARG;
         }
     }
-    std::vector<uint8_t> mt((size_t)pool_len), mb((size_t)pool_len);
-    for (int64_t i = 0; i < pool_len; ++i) {
-        if ((mask_top[i] != 0.0 && mask_top[i] != 1.0) || (mask_bottom[i] != 0.0 && mask_bottom[i] != 1.0))
-            return IRBPP_ERR_ARG;
-        mt[i] = mask_top[i] != 0.0;
-        mb[i] = mask_bottom[i] != 0.0;
-    }
+    if (bcell.empty()) bcell.push_back(Cell{0.0, 0, 0});
+    if (tcell.empty()) tcell.push_back(Cell{0.0, 0, 0});
     Tables& T = env->T;
     int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.top, height_top, (size_t)pool_len);
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.bot, height_bottom, (size_t)pool_len);
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.mtop, (const uint8_t*)mt.data(), mt.size());
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.mbot, (const uint8_t*)mb.data(), mb.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.bcell, (const Cell*)bcell.data(), bcell.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.tcell, (const Cell*)tcell.data(), tcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
     T.n_shapes = n_shapes;

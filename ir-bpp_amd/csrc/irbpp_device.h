@@ -6,8 +6,8 @@
 //   cand      u32 [N][S]         (rot<<16 | lx<<8 | ly) of the candidate rows handed out last
 //   scalars   i32/f64 [N]        cursor, episode, cur_item, nvalid, order_action, item_idx,
 //                                ratio_acc, ep_reward, ep_len, totals
-//   ShapeRot  48 B per (shape, rot) + pooled f64 height tables and u8 masks (read-only, shared
-//                                by all bins -> L2 / Infinity-Cache resident)
+//   ShapeRot  72 B per (shape, rot) + compact lists (u16 tile offset, f64 height) of the masked-in
+//                                footprint cells (read-only, shared by all bins -> L2 resident)
 //   seq       i32 [n_traj][L]    pre-drawn item ids
 #pragma once
 #include <stdint.h>
@@ -17,17 +17,29 @@ namespace irbpp {
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
     int32_t ax, ay;        // footprint in action cells:    ceil(round(extents,6)/resA)  (space.py:106)
-    int64_t off;           // offset of the [fx][fy] tables in the pools
+    int32_t nb, nt;        // number of maskB==1 / maskH==1 cells
+    int32_t ob, ot;        // offsets of this (shape, rot) in the bottom / top cell lists
+    int32_t has_out;       // 1 iff some maskB==0 cell exists: the window max then includes (H-B)*0 = 0
+    int32_t pad;
     double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
     double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
 };
 
+// Footprint tables are stored as compact lists of the masked-in cells only.  A masked-out cell
+// contributes (H-B)*0 = +-0 to np.max at space.py:118-119, i.e. the constant 0 (has_out), and
+// (T+z)*0 = +-0 to np.maximum at space.py:213, a no-op on a non-negative heightmap.
+// `off` addresses the LDS heightmap tile relative to the action cell's own entry, in the
+// phase-plane layout described in irbpp_kernels.hip.
+struct Cell {              // 16 B: one s_load_dwordx4 per cell when the list index is wave-uniform
+    double v;              // heightMapB / heightMapT value
+    int32_t off;           // LDS tile offset relative to the action cell's own entry
+    int32_t pad;
+};
+
 struct Tables {
     const ShapeRot* sr;    // [n_shapes][R]
-    const double* top;     // heightMapT pool
-    const double* bot;     // heightMapB pool
-    const uint8_t* mtop;   // maskH pool (0/1)
-    const uint8_t* mbot;   // maskB pool (0/1)
+    const Cell* bcell;     // bottom cells (maskB == 1)
+    const Cell* tcell;     // top cells    (maskH == 1)
     const double* volume;  // [n_shapes]
     const int32_t* seq;    // [n_traj][seq_len]
     int32_t n_shapes, n_traj, seq_len;

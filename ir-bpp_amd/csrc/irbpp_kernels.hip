@@ -14,6 +14,12 @@
 // row out and ~2 KiB of candidate keys.  Arithmetic is float64 in the reference's operation
 // order (compile with -ffp-contract=off), so results are bit-identical to the numpy code.
 // No MFMA: this is subtract/max/compare and integer border following, not a contraction.
+//
+// LDS heightmap tile layout ("phase planes"): heightmap cell (row, col) with row = X*step + ri,
+// col = Y*step + rj lives at plane (ri*step + rj), entry X*Ay + Y.  For a fixed footprint cell
+// (i, j) all lanes (X, Y) of a wave read ONE plane at consecutive entries, so the per-lane
+// ds_read_b64 of the overlap test is bank-conflict-free (16 lanes x 8 B = 32 banks, the next
+// X row lands on the other 32), and the footprint cell's tile offset is a wave-uniform scalar.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -98,6 +104,25 @@ __device__ inline int fetch_item(const Params& P, const Tables& T, const State& 
     return id < 0 ? -1 : id;
 }
 
+// linear heightmap index (row*Hy + col) <-> LDS tile index in the phase-plane layout
+__device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
+    const int row = g / P.Hy, col = g - row * P.Hy;
+    const int X = row / P.step, ri = row - X * P.step;
+    const int Y = col / P.step, rj = col - Y * P.step;
+    return (ri * P.step + rj) * P.AC + X * P.Ay + Y;
+}
+__device__ __forceinline__ int linear_of_tile(const Params& P, int t) {
+    const int plane = t / P.AC, rem = t - plane * P.AC;
+    const int X = rem / P.Ay, Y = rem - X * P.Ay;
+    const int ri = plane / P.step, rj = plane - ri * P.step;
+    return (X * P.step + ri) * P.Hy + Y * P.step + rj;
+}
+
+// Read-only tables are addressed through the constant address space so that wave-uniform
+// reads become scalar loads (s_load_dwordx4 per Cell) instead of per-lane vector loads.
+typedef const __attribute__((address_space(4))) Cell* ConstCellPtr;
+__device__ __forceinline__ ConstCellPtr as_const(const Cell* p) { return (ConstCellPtr)(unsigned long long)p; }
+
 // optional per-phase shader-clock stamps (s_memtime), one row of 8 per bin
 __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
     if (io.phase_cycles && threadIdx.x == 0) io.phase_cycles[(size_t)b * 8 + k] = (long long)clock64();
@@ -105,7 +130,8 @@ __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
 
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
     SlotMem m;
-    m.lab = (uint32_t*)base;
+    m.vis = (uint16_t*)base;
+    m.neg = (uint16_t*)(base + 32);
     m.pts = base + 64;
     m.dst = m.pts + cap;
     m.stk = (uint32_t*)(m.dst + cap);
@@ -229,17 +255,15 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         if (item >= 0 && tid < AC) {
             const ShapeRot sr = T.sr[item * R + r];
             if (X <= Ax - sr.ax && Y <= Ay - sr.ay) {
-                const double* bp = T.bot + sr.off;
-                const uint8_t* mp = T.mbot + sr.off;
-                const double* h0 = L.hm + (X * P.step) * P.Hy + Y * P.step;
-                double m = -INFINITY;
-                for (int i = 0; i < sr.fx; ++i) {
-                    for (int j = 0; j < sr.fy; ++j) {
-                        const double d = h0[i * P.Hy + j] - bp[i * sr.fy + j];
-                        const double v = d * (double)mp[i * sr.fy + j];
-                        m = fmax(m, v);
-                    }
+                const ConstCellPtr cells = as_const(T.bcell + sr.ob);
+                const double* h0 = L.hm + X * Ay + Y;
+                double m = sr.has_out ? 0.0 : -1e300;
+                int e = 0;
+                for (; e + 8 <= sr.nb; e += 8) {
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) m = fmax(m, h0[cells[e + u].off] - cells[e + u].v);
                 }
+                for (; e < sr.nb; ++e) m = fmax(m, h0[cells[e].off] - cells[e].v);
                 z = m;
                 valid = round6(z + sr.ext_z_r - P.bin_z) <= 0.0;
             }
@@ -361,7 +385,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     }
     for (int i = tid; i < P.S; i += BLOCK) S.cand[(size_t)b * P.S + i] = i < nrows ? rows[i] : 0u;
     if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
-    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[i];
+    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[tile_of_linear(P, i)];
     if (tid == 0) {
         S.cur_item[b] = item;
         S.nvalid[b] = nvalid;
@@ -387,7 +411,7 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
     if (mode == MODE_RESET) {
         for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }
     } else {
-        for (int i = tid; i < P.Hc; i += BLOCK) L.hm[i] = ghm[i];
+        for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     }
     __syncthreads();
 
@@ -438,16 +462,10 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)
         if (ok) {
             if (lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay) {
-                const double* bp = T.bot + sr.off;
-                const uint8_t* mp = T.mbot + sr.off;
-                const double* h0 = L.hm + (lx * P.step) * P.Hy + ly * P.step;
-                double m = -INFINITY;
-                const int F = sr.fx * sr.fy;
-                for (int e = tid; e < F; e += BLOCK) {
-                    const int i = e / sr.fy, j = e - i * sr.fy;
-                    const double d = h0[i * P.Hy + j] - bp[e];
-                    m = fmax(m, d * (double)mp[e]);
-                }
+                const Cell* cells = T.bcell + sr.ob;
+                const double* h0 = L.hm + lx * P.Ay + ly;
+                double m = sr.has_out ? 0.0 : -1e300;
+                for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, h0[cells[e].off] - cells[e].v);
                 z = block_max_f64(m, L.redd);
             }
             // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
@@ -456,17 +474,13 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         }
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
-            const double* tp = T.top + sr.off;
-            const uint8_t* mh = T.mtop + sr.off;
-            const int base = (lx * P.step) * P.Hy + ly * P.step;
-            const int F = sr.fx * sr.fy;
-            for (int e = tid; e < F; e += BLOCK) {
-                const int i = e / sr.fy, j = e - i * sr.fy;
-                const int c = base + i * P.Hy + j;
-                const double v = (tp[e] + z) * (double)mh[e];
-                const double h = fmax(L.hm[c], v);
+            const Cell* cells = T.tcell + sr.ot;
+            const int base = lx * P.Ay + ly;
+            for (int e = tid; e < sr.nt; e += BLOCK) {
+                const int c = base + cells[e].off;
+                const double h = fmax(L.hm[c], cells[e].v + z);
                 L.hm[c] = h;
-                ghm[c] = h;
+                ghm[linear_of_tile(P, c)] = h;
             }
         } else {
             for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }   // Space.reset (space.py:49-52)
@@ -524,7 +538,7 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         observe_location(P, T, S, io, L, b, item, obs, false);
     } else {                             // buffer branch (binPhy.py:228-230): [k ids | heightmap]
         for (int i = tid; i < P.K; i += BLOCK) obs[i] = (float)L.redi[16 + i];
-        for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[i];
+        for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
     }
 }
 
