@@ -12,7 +12,7 @@
 // Representation: the image is 16 rows of 16 bits (bit x of row y = pixel (x,y)), read-only.
 // OpenCV's label image only ever distinguishes 0 / 1 (untouched) / visited / visited with the
 // "right bound" sign bit (nbd|0x80) in its raster scan (contours.cpp, cvFindNextContour), so the
-// labels are two more bit planes per slot: `vis` and `neg`.  A border-following step looks at
+// labels are two more bit planes per slot (visited, right-bound), packed into one word per row.  A border-following step looks at
 // the 3x3 neighbourhood as one 8-bit mask and finds the next direction with a rotate + bit
 // scan instead of up to eight probes.
 #pragma once
@@ -22,8 +22,7 @@
 namespace irbpp {
 
 struct SlotMem {
-    uint16_t* vis;      // [16] visited plane (label != 1)
-    uint16_t* neg;      // [16] right-bound plane (label < 0)
+    uint32_t* lab;      // [16] label planes per row: bits 0-15 visited (label != 1), bits 16-31 right-bound (label < 0)
     uint8_t*  pts;      // [cap] contour points, x | y<<4
     uint8_t*  dst;      // [cap] approximated polygon
     uint32_t* stk;      // [cap_stk] Douglas-Peucker slices, start | end<<16
@@ -35,11 +34,12 @@ struct SlotMem {
 __device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
 __device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
 
-// 8-bit neighbour mask of pixel (x,y): bit s set iff the neighbour in direction s is foreground
-__device__ __forceinline__ uint32_t neighbours(const uint32_t* img, int x, int y) {
-    const uint32_t a = y > 0 ? img[y - 1] : 0u;
-    const uint32_t b = img[y];
-    const uint32_t c = y < 15 ? img[y + 1] : 0u;
+// icvFetchContourEx with CHAIN_APPROX_SIMPLE.  img rows hold the 16-bit foreground rows.
+// The 3-row window around the current pixel stays in registers and slides with the walk (one
+// LDS row read per vertical move, off the critical path); label bits are ORed into LDS with
+// non-returning atomics.  Returns the number of points produced (stored only while they fit
+// in cap), or -1 if the iteration guard tripped.
+__device__ __forceinline__ uint32_t nb_mask(uint32_t a, uint32_t b, uint32_t c, int x) {
     const uint32_t ta = ((a << 1) >> x) & 7u;      // bit0 = x-1, bit1 = x, bit2 = x+1
     const uint32_t tb = ((b << 1) >> x) & 7u;
     const uint32_t tc = ((c << 1) >> x) & 7u;
@@ -47,62 +47,50 @@ __device__ __forceinline__ uint32_t neighbours(const uint32_t* img, int x, int y
            ((tb & 1u) << 4) | ((tc & 1u) << 5) | (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
 }
 
-// icvFetchContourEx with CHAIN_APPROX_SIMPLE.  img rows hold the 16-bit foreground rows.
-// Returns the number of points produced (stored only while they fit in cap), or -1 if the
-// iteration guard tripped.
-__device__ inline int trace_border(const uint32_t* img, uint16_t* vis, uint16_t* neg, int x0, int y0,
+__device__ inline int trace_border(const uint32_t* img, uint32_t* lab, int x0, int y0,
                                    bool is_hole, bool store, uint8_t* pts, int cap) {
     const int s_first = is_hole ? 0 : 4;
-    uint32_t nb = neighbours(img, x0, y0);
+    uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
+    uint32_t nb = nb_mask(ra, rb, rc, x0);
     // clockwise search s_first-1, s_first-2, ... for the first foreground neighbour
-    {
-        const int k = (s_first - 1) & 7;                          // first direction probed
-        const uint32_t rot = ((nb << (7 - k)) | (nb >> (k + 1))) & 0xFFu;   // direction k -> bit 7
-        if (rot == 0u) {                                          // isolated pixel
-            vis[y0] |= (uint16_t)(1u << x0);
-            neg[y0] |= (uint16_t)(1u << x0);
-            if (store && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
-            return 1;
-        }
-        const int p = 31 - __clz((int)rot);                       // highest set bit, 7 = direction k
-        const int s = (k - (7 - p)) & 7;
-        // fallthrough with s
-        int x3 = x0, y3 = y0;
-        const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
-        int prev_s = s ^ 4;
-        int cur_s = s;
-        int px = x0, py = y0;
-        int n = 0;
-        for (int guard = 0; guard < 4096; ++guard) {
-            const int s_end = cur_s;
-            // counter-clockwise search s_end+1, s_end+2, ... for the next border pixel
-            const int k2 = (s_end + 1) & 7;
-            const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
-            const int t = __ffs((int)r2) - 1;
-            const int s2 = (k2 + t) & 7;
-            const int x4 = x3 + dir_dx(s2), y4 = y3 + dir_dy(s2);
-            const uint16_t bit = (uint16_t)(1u << x3);
-            if ((unsigned)(s2 - 1) < (unsigned)s_end) {           // the east neighbour was probed empty
-                vis[y3] |= bit;
-                neg[y3] |= bit;
-            } else {
-                vis[y3] |= bit;                                   // 1 -> nbd; other labels unchanged
-            }
-            if (s2 != prev_s) {                                   // CHAIN_APPROX_SIMPLE
-                if (store && n < cap) pts[n] = (uint8_t)(px | (py << 4));
-                ++n;
-            }
-            prev_s = s2;
-            px += dir_dx(s2);
-            py += dir_dy(s2);
-            if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-            x3 = x4;
-            y3 = y4;
-            cur_s = (s2 + 4) & 7;
-            nb = neighbours(img, x3, y3);
-        }
-        return -1;
+    const int k = (s_first - 1) & 7;                              // first direction probed
+    const uint32_t rot = ((nb << (7 - k)) | (nb >> (k + 1))) & 0xFFu;   // direction k -> bit 7
+    if (rot == 0u) {                                              // isolated pixel
+        atomicOr(&lab[y0], 0x10001u << x0);
+        if (store && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
+        return 1;
     }
+    const int p = 31 - __clz((int)rot);                           // highest set bit, 7 = direction k
+    const int s = (k - (7 - p)) & 7;
+    int x3 = x0, y3 = y0;
+    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
+    int prev_s = s ^ 4;
+    int cur_s = s;
+    int n = 0;
+    for (int guard = 0; guard < 4096; ++guard) {
+        const int s_end = cur_s;
+        // counter-clockwise search s_end+1, s_end+2, ... for the next border pixel
+        const int k2 = (s_end + 1) & 7;
+        const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
+        const int s2 = (k2 + __ffs((int)r2) - 1) & 7;
+        const int dx = dir_dx(s2), dy = dir_dy(s2);
+        const int x4 = x3 + dx, y4 = y3 + dy;
+        // east neighbour probed empty -> right bound (sign bit); else 1 -> nbd, other labels unchanged
+        atomicOr(&lab[y3], ((unsigned)(s2 - 1) < (unsigned)s_end ? 0x10001u : 0x1u) << x3);
+        if (s2 != prev_s) {                                       // CHAIN_APPROX_SIMPLE
+            if (store && n < cap) pts[n] = (uint8_t)(x3 | (y3 << 4));
+            ++n;
+        }
+        prev_s = s2;
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
+        if (dy > 0) { ra = rb; rb = rc; rc = y4 < 15 ? img[y4 + 1] : 0u; }
+        else if (dy < 0) { rc = rb; rb = ra; ra = y4 > 0 ? img[y4 - 1] : 0u; }
+        x3 = x4;
+        y3 = y4;
+        cur_s = (s2 + 4) & 7;
+        nb = nb_mask(ra, rb, rc, x3);
+    }
+    return -1;
 }
 
 #define IRBPP_PX(p) ((int)((p) & 15))
@@ -230,13 +218,14 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
 // img[y] bit x = foreground.  Returns 0 ok, 1 capacity overflow (caller retries with a bigger
 // slot), 2 iteration guard.
 __device__ inline int level_image_vertices(const uint32_t* img, const SlotMem& m, uint32_t* vrows) {
-    for (int y = 0; y < 16; ++y) { m.vis[y] = 0; m.neg[y] = 0; }
+    for (int y = 0; y < 16; ++y) m.lab[y] = 0u;
     for (int y = 0; y < 16; ++y) {
         const uint32_t nz = img[y] & 0xFFFFu;
         if (!nz) continue;
         int cur = 0;
         while (cur < 16) {
-            const uint32_t vis = m.vis[y], neg = m.neg[y];
+            const uint32_t l = m.lab[y];
+            const uint32_t vis = l & 0xFFFFu, neg = l >> 16;
             const uint32_t outer = nz & ~vis & ~(nz << 1);                    // prev == 0 && p == 1
             const uint32_t hole = ~nz & (nz << 1) & ~(neg << 1) & 0xFFFFu;    // p == 0 && prev >= 1
             const uint32_t cand = (outer | hole) & ~((1u << cur) - 1u);
@@ -244,7 +233,7 @@ __device__ inline int level_image_vertices(const uint32_t* img, const SlotMem& m
             const int x = __ffs((int)cand) - 1;
             const bool is_hole = ((hole >> x) & 1u) != 0;
             const int ox = is_hole ? x - 1 : x;
-            const int n = trace_border(img, m.vis, m.neg, ox, y, is_hole, !is_hole, m.pts, m.cap);
+            const int n = trace_border(img, m.lab, ox, y, is_hole, !is_hole, m.pts, m.cap);
             if (n < 0) return 2;
             if (!is_hole) {
                 if (n > m.cap) return 1;

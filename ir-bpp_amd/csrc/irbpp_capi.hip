@@ -61,13 +61,12 @@ inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 // dynamic-LDS carve-up of the transition kernel
 void layout_lds(Params& P, int want_slots) {
-    P.nslot = want_slots > 0 ? want_slots : 64;
+    P.nslot = want_slots > 0 ? want_slots : 32;
     if (P.nslot > 256) P.nslot = 256;
-    P.slot_cap = 96;
-    P.slot_stk = 24;
-    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk + 4;          // 356 B = 89 dwords: odd stride, lanes hit distinct LDS banks
+    P.slot_cap = 48;
+    P.slot_stk = 16;
+    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk + 4;          // 228 B = 57 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
-    P.o_hm = off;        off += align16(P.Hc * 8);
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
     P.o_lev = off;       off += align16(P.R * P.AC);
     P.o_present = off;   off += align16(P.R * 8);
@@ -76,10 +75,13 @@ void layout_lds(Params& P, int want_slots) {
     P.o_img = off;       off += align16(P.nslot * 16 * 4);
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 256;
+    // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
+    // and the candidate keys: the tile's float32 copy is written out before the slots reuse it
     int32_t scratch = P.nslot * P.slot_bytes;
-    const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;                 // candidate keys alias the slots
+    const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
-    if (scratch < 4096) scratch = 4096;
+    if (scratch < P.Hc * 8) scratch = P.Hc * 8;
+    P.o_hm = off;
     P.o_scratch = off;
     P.scratch_bytes = align16(scratch);
     off += P.scratch_bytes;
@@ -164,15 +166,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(hm, N * P.Hc);
     ALLOC(queue, N * P.K);
     ALLOC(cand, N * P.S);
-    ALLOC(cursor, N);
-    ALLOC(episode, N);
-    ALLOC(cur_item, N);
-    ALLOC(nvalid, N);
-    ALLOC(order_action, N);
-    ALLOC(item_idx, N);
-    ALLOC(ratio_acc, N);
-    ALLOC(ep_reward, N);
-    ALLOC(ep_len, N);
+    ALLOC(bs, N);
     ALLOC(totals, N * 4);
     ALLOC(err, 1);
 #undef ALLOC

@@ -4,8 +4,8 @@
 //   hm        f64 [N][Hc]        Space.heightmapC of every bin (space.py:26), contiguous per bin
 //   queue     i32 [N][K]         ItemCreator.item_list (IRcreator.py:6-24), always full
 //   cand      u32 [N][S]         (rot<<16 | lx<<8 | ly) of the candidate rows handed out last
-//   scalars   i32/f64 [N]        cursor, episode, cur_item, nvalid, order_action, item_idx,
-//                                ratio_acc, ep_reward, ep_len, totals
+//   bs        BinState [N]       64-byte line of per-bin scalars (cursor, episode, cur_item, nvalid,
+//                                order_action, item_idx, ep_len, ratio_acc, ep_reward); totals f64 [N][4]
 //   ShapeRot  72 B per (shape, rot) + compact lists (u16 tile offset, f64 height) of the masked-in
 //                                footprint cells (read-only, shared by all bins -> L2 resident)
 //   seq       i32 [n_traj][L]    pre-drawn item ids
@@ -45,19 +45,26 @@ struct Tables {
     int32_t n_shapes, n_traj, seq_len;
 };
 
+// Per-bin scalars, one 64-byte line per bin: a transition touches exactly one line of it.
+struct alignas(64) BinState {
+    int32_t cursor;        // next index into the bin's trajectory (LoadItemCreator.item_index)
+    int32_t episode;       // episodes started by this bin minus one
+    int32_t cur_item;      // item the last location observation was built for (next_item_ID)
+    int32_t nvalid;        // np.sum(naiveMask) of that observation (prejudge, binPhy.py:243)
+    int32_t order_action;  // buffer slot chosen by get_action_candidates (binPhy.py:168)
+    int32_t item_idx;      // items packed in this episode (info['counter'])
+    int32_t ep_len;        // steps in this episode (Monitor 'l')
+    int32_t pad0;
+    double ratio_acc;      // sequential sum of packed volumes (get_ratio, binPhy.py:149-153)
+    double ep_reward;      // sequential sum of rewards (Monitor 'r')
+    double pad1[2];
+};
+
 struct State {
-    double* hm;
-    int32_t* queue;
-    uint32_t* cand;
-    int32_t* cursor;
-    int32_t* episode;
-    int32_t* cur_item;
-    int32_t* nvalid;
-    int32_t* order_action;
-    int32_t* item_idx;
-    double* ratio_acc;
-    double* ep_reward;
-    int32_t* ep_len;
+    double* hm;            // [N][Hc]
+    int32_t* queue;        // [N][K]
+    uint32_t* cand;        // [N][S]
+    BinState* bs;          // [N]
     double* totals;        // [N][4]: episodes, sum ratio, sum counter, sum reward
     int32_t* err;          // [1] device error word
 };

@@ -130,8 +130,7 @@ __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
 
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
     SlotMem m;
-    m.vis = (uint16_t*)base;
-    m.neg = (uint16_t*)(base + 32);
+    m.lab = (uint32_t*)base;
     m.pts = base + 64;
     m.dst = m.pts + cap;
     m.stk = (uint32_t*)(m.dst + cap);
@@ -258,12 +257,27 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
                 const ConstCellPtr cells = as_const(T.bcell + sr.ob);
                 const double* h0 = L.hm + X * Ay + Y;
                 double m = sr.has_out ? 0.0 : -1e300;
-                int e = 0;
-                for (; e + 8 <= sr.nb; e += 8) {
+                // 8 cells per trip; the next trip's scalar loads are issued before this trip's math
+                constexpr int U = 8;
+                const int nfull = sr.nb / U;
+                double cv[U];
+                int co[U];
+                if (nfull > 0) {
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) m = fmax(m, h0[cells[e + u].off] - cells[e + u].v);
+                    for (int u = 0; u < U; ++u) { cv[u] = cells[u].v; co[u] = cells[u].off; }
                 }
-                for (; e < sr.nb; ++e) m = fmax(m, h0[cells[e].off] - cells[e].v);
+                for (int t = 0; t < nfull; ++t) {
+                    double nv[U];
+                    int no[U];
+                    const int nxt = (t + 1 < nfull ? t + 1 : t) * U;       // last trip reloads itself (harmless)
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { nv[u] = cells[nxt + u].v; no[u] = cells[nxt + u].off; }
+#pragma unroll
+                    for (int u = 0; u < U; ++u) m = fmax(m, h0[co[u]] - cv[u]);
+#pragma unroll
+                    for (int u = 0; u < U; ++u) { cv[u] = nv[u]; co[u] = no[u]; }
+                }
+                for (int e = nfull * U; e < sr.nb; ++e) m = fmax(m, h0[cells[e].off] - cells[e].v);
                 z = m;
                 valid = round6(z + sr.ext_z_r - P.bin_z) <= 0.0;
             }
@@ -290,6 +304,10 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     }
     const int nvalid = block_sum_int(my_valid, L.redi);      // np.sum(naiveMask) for prejudge
     if (debug_out) return;
+    // the tile is done with: write its float32 copy and the item vector now, because the
+    // contour scratch and the candidate keys reuse the tile's LDS
+    if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
+    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[tile_of_linear(P, i)];
     __syncthreads();
     stamp(io, b, 2);
 
@@ -384,11 +402,9 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         obs[e] = v;
     }
     for (int i = tid; i < P.S; i += BLOCK) S.cand[(size_t)b * P.S + i] = i < nrows ? rows[i] : 0u;
-    if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
-    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[tile_of_linear(P, i)];
     if (tid == 0) {
-        S.cur_item[b] = item;
-        S.nvalid[b] = nvalid;
+        S.bs[b].cur_item = item;
+        S.bs[b].nvalid = nvalid;
     }
     stamp(io, b, 4);
 }
@@ -426,21 +442,27 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         int oa = io.actions[b];
         oa = oa < 0 ? 0 : (oa >= P.K ? P.K - 1 : oa);
         const int item = q[oa];
-        if (tid == 0) S.order_action[b] = oa;
+        if (tid == 0) S.bs[b].order_action = oa;
         observe_location(P, T, S, io, L, b, item, obs, false);
         return;
     }
 
     if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
         if (tid == 0) {
-            S.episode[b] = 0;
+            BinState st;
+            st.episode = 0;
             for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, 0, i);
-            S.cursor[b] = P.K;
-            S.item_idx[b] = 0;
-            S.ratio_acc[b] = 0.0;
-            S.ep_reward[b] = 0.0;
-            S.ep_len[b] = 0;
-            S.order_action[b] = 0;
+            st.cursor = P.K;
+            st.cur_item = -1;
+            st.nvalid = 0;
+            st.order_action = 0;
+            st.item_idx = 0;
+            st.ep_len = 0;
+            st.pad0 = 0;
+            st.ratio_acc = 0.0;
+            st.ep_reward = 0.0;
+            st.pad1[0] = st.pad1[1] = 0.0;
+            S.bs[b] = st;
             for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
@@ -450,9 +472,10 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
         const uint32_t key = S.cand[(size_t)b * P.S + a];            // action_to_position (:234-236)
         const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
-        const int item0 = S.cur_item[b];
-        const int oa = S.order_action[b];
-        bool ok = item0 >= 0 && S.nvalid[b] > 0 && rot < P.R;        // prejudge (:238-245)
+        const BinState st0 = S.bs[b];                                // one 64-byte line, wave-uniform
+        const int item0 = st0.cur_item;
+        const int oa = st0.order_action;
+        bool ok = item0 >= 0 && st0.nvalid > 0 && rot < P.R;         // prejudge (:238-245)
         ShapeRot sr = {};
         if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
         if (ok) {
@@ -486,28 +509,28 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
             for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }   // Space.reset (space.py:49-52)
         }
         if (tid == 0) {
+            BinState st = st0;
             if (ok) {
                 const double vol = T.volume[item0];
                 const double reward = (vol / P.bin_vol) * 10.0;      // binPhy.py:321-322
-                S.ep_reward[b] += reward;
-                S.ep_len[b] += 1;
-                S.item_idx[b] += 1;
-                S.ratio_acc[b] += vol;
-                int cursor = S.cursor[b];
+                st.ep_reward += reward;
+                st.ep_len += 1;
+                st.item_idx += 1;
+                st.ratio_acc += vol;
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
-                q[P.K - 1] = fetch_item(P, T, S, b, S.episode[b], cursor);   // generate_item (:325)
-                S.cursor[b] = cursor + 1;
+                q[P.K - 1] = fetch_item(P, T, S, b, st.episode, st.cursor);   // generate_item (:325)
+                st.cursor += 1;
                 if (io.reward) io.reward[b] = reward;
                 if (io.done) io.done[b] = 0;
                 if (io.counter) io.counter[b] = -1;
                 if (io.ratio) io.ratio[b] = -1.0;
-                if (io.ep_reward) io.ep_reward[b] = S.ep_reward[b];
-                if (io.ep_len) io.ep_len[b] = S.ep_len[b];
+                if (io.ep_reward) io.ep_reward[b] = st.ep_reward;
+                if (io.ep_len) io.ep_len[b] = st.ep_len;
             } else {
-                const int counter = S.item_idx[b];                   // info (binPhy.py:306-309)
-                const double ratio = S.ratio_acc[b] / P.bin_vol;     // get_ratio (:149-153)
-                const double epr = S.ep_reward[b] + 0.0;
-                const int epl = S.ep_len[b] + 1;
+                const int counter = st.item_idx;                     // info (binPhy.py:306-309)
+                const double ratio = st.ratio_acc / P.bin_vol;       // get_ratio (:149-153)
+                const double epr = st.ep_reward + 0.0;
+                const int epl = st.ep_len + 1;
                 if (io.reward) io.reward[b] = 0.0;
                 if (io.done) io.done[b] = 1;
                 if (io.counter) io.counter[b] = counter;
@@ -517,15 +540,15 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
                 double* tot = S.totals + (size_t)b * 4;
                 tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
                 // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset
-                const int ep = S.episode[b] + 1;
-                S.episode[b] = ep;
-                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
-                S.cursor[b] = P.K;
-                S.item_idx[b] = 0;
-                S.ratio_acc[b] = 0.0;
-                S.ep_reward[b] = 0.0;
-                S.ep_len[b] = 0;
+                st.episode += 1;
+                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, st.episode, i);
+                st.cursor = P.K;
+                st.item_idx = 0;
+                st.ratio_acc = 0.0;
+                st.ep_reward = 0.0;
+                st.ep_len = 0;
             }
+            S.bs[b] = st;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
         __syncthreads();
