@@ -1,20 +1,23 @@
-// contours_device.h -- candidate-vertex extraction from one binary level image, per lane.
+// contours_device.h -- candidate vertices of the outer borders of a binary level image.
 //
-// One lane owns one (rotation, height-level) image of the <=16x16 action grid and runs,
-// serially, what the reference does per level in convexHulls (cvTools.py:83-96):
+// What the reference does per height level in convexHulls (cvTools.py:83-96):
 //   cv2.findContours(RETR_TREE, CHAIN_APPROX_SIMPLE)  -> Suzuki-Abe border following
 //   find_out_contour (cvTools.py:7-38)                -> keep outer borders, drop hole borders
 //   cv2.approxPolyDP(c, 1, True)                      -> Douglas-Peucker, eps = 1
 //   find_convex_vetex (cvTools.py:40-59)              -> vertices with cross(B-A, C-A) < 0
-// and ORs the surviving vertices into a per-rotation 16x16 bit grid (np.unique at
-// cvTools.py:101 makes the result a set, so a bit grid is its exact representation).
+// and np.unique (cvTools.py:101) turns the result into a set, kept here as a 16x16 bit grid.
 //
-// Representation: the image is 16 rows of 16 bits (bit x of row y = pixel (x,y)), read-only.
-// OpenCV's label image only ever distinguishes 0 / 1 (untouched) / visited / visited with the
-// "right bound" sign bit (nbd|0x80) in its raster scan (contours.cpp, cvFindNextContour), so the
-// labels are two more bit planes per slot (visited, right-bound), packed into one word per row.  A border-following step looks at
-// the 3x3 neighbourhood as one 8-bit mask and finds the next direction with a rotate + bit
-// scan instead of up to eight probes.
+// Decomposition used on the GPU (results identical to the sequential algorithm):
+//   * Suzuki-Abe starts exactly one outer border per 8-connected foreground component, at the
+//     component's first pixel in raster order (its west neighbour is background and it is still
+//     unlabelled when the scan reaches it; every other such pixel has already been labelled by
+//     the outer or a hole border).  Hole borders are discarded by find_out_contour and border
+//     following itself only tests "non-zero", so neither hole tracing nor label state is
+//     needed: component_start() finds the start pixels with a row-parallel bit flood fill.
+//   * one lane then owns one outer border: trace_border() (icvFetchContourEx, SIMPLE
+//     approximation) followed by approx_and_convex() (approxPolyDP_ + the convexity test).  All
+//     lanes of a wave run the same code, so divergence is limited to loop trip counts.
+// The image is 16 rows of 16 bits (bit x of row y = pixel (x,y)).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -22,7 +25,6 @@
 namespace irbpp {
 
 struct SlotMem {
-    uint32_t* lab;      // [16] label planes per row: bits 0-15 visited (label != 1), bits 16-31 right-bound (label < 0)
     uint8_t*  pts;      // [cap] contour points, x | y<<4
     uint8_t*  dst;      // [cap] approximated polygon
     uint32_t* stk;      // [cap_stk] Douglas-Peucker slices, start | end<<16
@@ -34,11 +36,8 @@ struct SlotMem {
 __device__ __forceinline__ int dir_dx(int s) { return (int)((0x901Au >> (2 * s)) & 3u) - 1; }
 __device__ __forceinline__ int dir_dy(int s) { return (int)((0xA901u >> (2 * s)) & 3u) - 1; }
 
-// icvFetchContourEx with CHAIN_APPROX_SIMPLE.  img rows hold the 16-bit foreground rows.
-// The 3-row window around the current pixel stays in registers and slides with the walk (one
-// LDS row read per vertical move, off the critical path); label bits are ORed into LDS with
-// non-returning atomics.  Returns the number of points produced (stored only while they fit
-// in cap), or -1 if the iteration guard tripped.
+// 8-bit neighbour mask from the three rows around a pixel: bit s set iff the neighbour in
+// direction s is foreground
 __device__ __forceinline__ uint32_t nb_mask(uint32_t a, uint32_t b, uint32_t c, int x) {
     const uint32_t ta = ((a << 1) >> x) & 7u;      // bit0 = x-1, bit1 = x, bit2 = x+1
     const uint32_t tb = ((b << 1) >> x) & 7u;
@@ -47,38 +46,63 @@ __device__ __forceinline__ uint32_t nb_mask(uint32_t a, uint32_t b, uint32_t c, 
            ((tb & 1u) << 4) | ((tc & 1u) << 5) | (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
 }
 
-__device__ inline int trace_border(const uint32_t* img, uint32_t* lab, int x0, int y0,
-                                   bool is_hole, bool store, uint8_t* pts, int cap) {
-    const int s_first = is_hole ? 0 : 4;
+// One round of component extraction for the image whose row `y` (0..15) this lane holds in
+// `rem` (the not-yet-extracted foreground pixels); the 16 rows of an image sit in 16 consecutive
+// lanes.  Finds the raster-first remaining pixel (x0,y0), flood-fills its 8-connected component
+// with row-parallel bit operations and removes it from `rem`.  Returns true in every lane of a
+// group that extracted a component.  Must be called by all 64 lanes of the wave.
+__device__ inline bool component_start(uint32_t& rem, int y, int& x0, int& y0) {
+    const int lane = threadIdx.x & 63, gbase = lane & 48;
+    const unsigned long long bal = __ballot(rem != 0u);
+    const uint32_t gmask = (uint32_t)(bal >> gbase) & 0xFFFFu;
+    const bool active = gmask != 0u;
+    y0 = active ? __ffs((int)gmask) - 1 : 0;
+    const uint32_t rem_y0 = (uint32_t)__shfl((int)rem, gbase + y0);
+    x0 = active ? __ffs((int)rem_y0) - 1 : 0;
+    uint32_t fill = (active && y == y0) ? (1u << x0) : 0u;
+    for (int it = 0; it < 256; ++it) {
+        const uint32_t h = fill | (fill << 1) | (fill >> 1);
+        uint32_t up = (uint32_t)__shfl_up((int)h, 1, 16);
+        uint32_t dn = (uint32_t)__shfl_down((int)h, 1, 16);
+        if (y == 0) up = 0u;
+        if (y == 15) dn = 0u;
+        const uint32_t nf = (h | up | dn) & rem;
+        const bool changed = nf != fill;
+        fill = nf;
+        if (!__any(changed)) break;
+    }
+    rem &= ~fill;
+    return active;
+}
+
+// icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border starting at (x0,y0).  The
+// 3-row window around the current pixel stays in registers and slides with the walk.  Returns
+// the number of points produced (stored only while they fit in cap), or -1 if the iteration
+// guard tripped.
+__device__ inline int trace_border(const uint32_t* img, int x0, int y0, uint8_t* pts, int cap) {
     uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
     uint32_t nb = nb_mask(ra, rb, rc, x0);
-    // clockwise search s_first-1, s_first-2, ... for the first foreground neighbour
-    const int k = (s_first - 1) & 7;                              // first direction probed
-    const uint32_t rot = ((nb << (7 - k)) | (nb >> (k + 1))) & 0xFFu;   // direction k -> bit 7
+    // clockwise search 3,2,1,0,7,6,5 (s_end = 4: the west pixel is background) for the first neighbour
+    const uint32_t rot = ((nb << 4) | (nb >> 4)) & 0xFFu;         // direction 3 -> bit 7
     if (rot == 0u) {                                              // isolated pixel
-        atomicOr(&lab[y0], 0x10001u << x0);
-        if (store && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
+        if (cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
         return 1;
     }
-    const int p = 31 - __clz((int)rot);                           // highest set bit, 7 = direction k
-    const int s = (k - (7 - p)) & 7;
+    const int s = (3 - (7 - (31 - __clz((int)rot)))) & 7;
     int x3 = x0, y3 = y0;
     const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
     int prev_s = s ^ 4;
     int cur_s = s;
     int n = 0;
     for (int guard = 0; guard < 4096; ++guard) {
-        const int s_end = cur_s;
-        // counter-clockwise search s_end+1, s_end+2, ... for the next border pixel
-        const int k2 = (s_end + 1) & 7;
+        // counter-clockwise search cur_s+1, cur_s+2, ... for the next border pixel
+        const int k2 = (cur_s + 1) & 7;
         const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
         const int s2 = (k2 + __ffs((int)r2) - 1) & 7;
-        const int dx = dir_dx(s2), dy = dir_dy(s2);
-        const int x4 = x3 + dx, y4 = y3 + dy;
-        // east neighbour probed empty -> right bound (sign bit); else 1 -> nbd, other labels unchanged
-        atomicOr(&lab[y3], ((unsigned)(s2 - 1) < (unsigned)s_end ? 0x10001u : 0x1u) << x3);
+        const int dy = dir_dy(s2);
+        const int x4 = x3 + dir_dx(s2), y4 = y3 + dy;
         if (s2 != prev_s) {                                       // CHAIN_APPROX_SIMPLE
-            if (store && n < cap) pts[n] = (uint8_t)(x3 | (y3 << 4));
+            if (n < cap) pts[n] = (uint8_t)(x3 | (y3 << 4));
             ++n;
         }
         prev_s = s2;
@@ -132,37 +156,47 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     } else {
         dst[new_count++] = start_pt;
     }
-    // 3. Douglas-Peucker
-    while (top > 0) {
-        const uint32_t sl = stk[--top];
-        const int s_start = (int)(sl & 0xFFFFu), s_end = (int)(sl >> 16);
-        const uint8_t end_pt = pts[s_end];
-        pos = s_start;
-        start_pt = pts[pos];
-        if (++pos >= count) pos = 0;
-        bool le;
-        int split = 0;
-        if (pos != s_end) {
-            const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
-            const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
-            int max_dist = 0;
-            while (pos != s_end) {
-                const uint8_t pt = pts[pos];
-                int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
-                dist = dist < 0 ? -dist : dist;
-                if (dist > max_dist) { max_dist = dist; split = pos; }
+    // 3. Douglas-Peucker as ONE flat loop (pop a slice | visit one point) so that lanes working
+    //    on different contours stay converged
+    {
+        bool in_slice = false;
+        int s_start = 0, s_end = 0, sx = 0, sy = 0, dx = 0, dy = 0, max_dist = 0, split = 0;
+        for (int guard = 0; guard < 65536; ++guard) {
+            if (!in_slice) {
+                if (top == 0) break;
+                const uint32_t sl = stk[--top];
+                s_start = (int)(sl & 0xFFFFu);
+                s_end = (int)(sl >> 16);
+                pos = s_start;
+                start_pt = pts[pos];
                 if (++pos >= count) pos = 0;
+                if (pos == s_end) {                  // no interior point: accept
+                    dst[new_count++] = start_pt;
+                    continue;
+                }
+                const uint8_t end_pt = pts[s_end];
+                sx = IRBPP_PX(start_pt);
+                sy = IRBPP_PY(start_pt);
+                dx = IRBPP_PX(end_pt) - sx;
+                dy = IRBPP_PY(end_pt) - sy;
+                max_dist = 0;
+                in_slice = true;
             }
-            le = max_dist * max_dist <= dx * dx + dy * dy;
-        } else {
-            le = true;
-        }
-        if (le) {
-            dst[new_count++] = start_pt;
-        } else {
-            if (top + 2 > cap_stk) return false;
-            stk[top++] = (uint32_t)split | ((uint32_t)s_end << 16);
-            stk[top++] = (uint32_t)s_start | ((uint32_t)split << 16);
+            const uint8_t pt = pts[pos];
+            int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
+            dist = dist < 0 ? -dist : dist;
+            if (dist > max_dist) { max_dist = dist; split = pos; }
+            if (++pos >= count) pos = 0;
+            if (pos == s_end) {
+                in_slice = false;
+                if (max_dist * max_dist <= dx * dx + dy * dy) {
+                    dst[new_count++] = start_pt;
+                } else {
+                    if (top + 2 > cap_stk) return false;
+                    stk[top++] = (uint32_t)split | ((uint32_t)s_end << 16);
+                    stk[top++] = (uint32_t)s_start | ((uint32_t)split << 16);
+                }
+            }
         }
     }
     // 4. clean-up of [almost] collinear points, in place as OpenCV does
@@ -214,35 +248,13 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     return true;
 }
 
-// Whole level image: raster scan (cvFindNextContour) + per-outer-border approximation.
-// img[y] bit x = foreground.  Returns 0 ok, 1 capacity overflow (caller retries with a bigger
-// slot), 2 iteration guard.
-__device__ inline int level_image_vertices(const uint32_t* img, const SlotMem& m, uint32_t* vrows) {
-    for (int y = 0; y < 16; ++y) m.lab[y] = 0u;
-    for (int y = 0; y < 16; ++y) {
-        const uint32_t nz = img[y] & 0xFFFFu;
-        if (!nz) continue;
-        int cur = 0;
-        while (cur < 16) {
-            const uint32_t l = m.lab[y];
-            const uint32_t vis = l & 0xFFFFu, neg = l >> 16;
-            const uint32_t outer = nz & ~vis & ~(nz << 1);                    // prev == 0 && p == 1
-            const uint32_t hole = ~nz & (nz << 1) & ~(neg << 1) & 0xFFFFu;    // p == 0 && prev >= 1
-            const uint32_t cand = (outer | hole) & ~((1u << cur) - 1u);
-            if (!cand) break;
-            const int x = __ffs((int)cand) - 1;
-            const bool is_hole = ((hole >> x) & 1u) != 0;
-            const int ox = is_hole ? x - 1 : x;
-            const int n = trace_border(img, m.lab, ox, y, is_hole, !is_hole, m.pts, m.cap);
-            if (n < 0) return 2;
-            if (!is_hole) {
-                if (n > m.cap) return 1;
-                if (!approx_and_convex(m.pts, n, m.dst, m.stk, m.cap_stk, vrows)) return 1;
-            }
-            cur = x + 1;
-        }
-    }
-    return 0;
+// One outer border: trace, approximate, mark convex vertices.  Returns 0 ok, 1 capacity
+// overflow (caller retries with a bigger slot), 2 iteration guard.
+__device__ inline int contour_vertices(const uint32_t* img, int x0, int y0, const SlotMem& m, uint32_t* vrows) {
+    const int n = trace_border(img, x0, y0, m.pts, m.cap);
+    if (n < 0) return 2;
+    if (n > m.cap) return 1;
+    return approx_and_convex(m.pts, n, m.dst, m.stk, m.cap_stk, vrows) ? 0 : 1;
 }
 
 }  // namespace irbpp

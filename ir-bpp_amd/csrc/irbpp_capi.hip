@@ -61,18 +61,20 @@ inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 // dynamic-LDS carve-up of the transition kernel
 void layout_lds(Params& P, int want_slots) {
-    P.nslot = want_slots > 0 ? want_slots : 32;
-    if (P.nslot > 256) P.nslot = 256;
+    P.nslot = want_slots > 0 ? want_slots : 64;                       // outer borders traced per pass
+    if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
+    if (P.nslot < 16) P.nslot = 16;                                   // one extraction round yields up to 16
     P.slot_cap = 48;
     P.slot_stk = 16;
-    P.slot_bytes = 64 + 2 * P.slot_cap + 4 * P.slot_stk + 4;          // 228 B = 57 dwords: odd stride, lanes hit distinct LDS banks
+    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 164 B = 41 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
     P.o_lev = off;       off += align16(P.R * P.AC);
     P.o_present = off;   off += align16(P.R * 8);
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
-    P.o_img = off;       off += align16(P.nslot * 16 * 4);
+    P.o_img = off;       off += align16(16 * 16 * 4);
+    P.o_clist = off;     off += align16(P.nslot * 4);
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 256;
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
@@ -85,6 +87,7 @@ void layout_lds(Params& P, int want_slots) {
     P.o_scratch = off;
     P.scratch_bytes = align16(scratch);
     off += P.scratch_bytes;
+    if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tuning: caps workgroups per CU
     P.lds_bytes = off;
 }
 

@@ -77,7 +77,7 @@ struct Params {
     int32_t traj_start, goff, gbins;
     int32_t obs_len0, obs_len1;
     // dynamic-LDS carve-up (byte offsets, all multiples of 16)
-    int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_vmask, o_scratch, o_red;
+    int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red;
     int32_t nslot, slot_cap, slot_stk, slot_bytes, scratch_bytes, lds_bytes;
 };
 

@@ -130,8 +130,7 @@ __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
 
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
     SlotMem m;
-    m.lab = (uint32_t*)base;
-    m.pts = base + 64;
+    m.pts = base;
     m.dst = m.pts + cap;
     m.stk = (uint32_t*)(m.dst + cap);
     m.cap = cap;
@@ -146,7 +145,8 @@ struct Lds {
     unsigned long long* present;
     uint16_t* taskidx;      // [R][64] level code -> task index
     uint16_t* tasklist;     // [ntasks] rot<<8 | level code
-    uint32_t* img;
+    uint32_t* img;          // [16][16] level images of the current batch, one 16-bit row per word
+    uint32_t* clist;        // [nslot] outer borders to trace: image | x0<<8 | y0<<12
     uint32_t* vmask;
     unsigned char* scratch;
     double* redd;
@@ -162,6 +162,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.taskidx = (uint16_t*)(smem + P.o_taskidx);
     L.tasklist = (uint16_t*)(smem + P.o_tasklist);
     L.img = (uint32_t*)(smem + P.o_img);
+    L.clist = (uint32_t*)(smem + P.o_clist);
     L.vmask = (uint32_t*)(smem + P.o_vmask);
     L.scratch = smem + P.o_scratch;
     L.redd = (double*)(smem + P.o_red);
@@ -192,43 +193,69 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         }
     }
     const int X = tid / P.Ay, Y = tid % P.Ay;
-    for (int base = 0; base < ntasks; base += P.nslot) {
-        for (int i = tid; i < P.nslot * 16; i += BLOCK) L.img[i] = 0u;
-        if (tid == 0) L.redi[8] = 0;
+    const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's image g
+    constexpr int IMGS = BLOCK / 16;                 // 16 level images per batch
+    for (int base = 0; base < ntasks; base += IMGS) {
+        for (int i = tid; i < IMGS * 16; i += BLOCK) L.img[i] = 0u;
         __syncthreads();
         if (tid < AC) {
             for (int r = 0; r < R; ++r) {
                 const int code = L.lev[r * AC + tid];
                 if (code != 255) {
                     const int ti = (int)L.taskidx[r * 64 + code] - base;
-                    if (ti >= 0 && ti < P.nslot) atomicOr(&L.img[ti * 16 + X], 1u << Y);
+                    if (ti >= 0 && ti < IMGS) atomicOr(&L.img[ti * 16 + X], 1u << Y);
                 }
             }
         }
         __syncthreads();
-        {   // one lane per level image, slots spread over the four waves
-            const int lane = tid & 63, w = tid >> 6;
-            const int slot = lane * WAVES + w;
-            if (slot < P.nslot && base + slot < ntasks) {
-                const int r = L.tasklist[base + slot] >> 8;
-                const SlotMem m = carve_slot(L.scratch + slot * P.slot_bytes, P.slot_cap, P.slot_stk);
-                const int rc = level_image_vertices(L.img + slot * 16, m, L.vmask + r * 16);
-                if (rc == 1) atomicOr(&L.redi[8], 1);
-                if (rc == 2) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
-            }
-        }
-        __syncthreads();
-        if (L.redi[8]) {        // a contour outgrew its slot: redo this batch serially in one big slot
-            if (tid == 0) {
-                const int cap = ((P.scratch_bytes - 64) / 6) & ~3;
-                const SlotMem m = carve_slot(L.scratch, cap, cap);
-                for (int slot = 0; slot < P.nslot && base + slot < ntasks; ++slot) {
-                    const int r = L.tasklist[base + slot] >> 8;
-                    const int rc = level_image_vertices(L.img + slot * 16, m, L.vmask + r * 16);
-                    if (rc != 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+        uint32_t rem = base + g < ntasks ? (L.img[tid] & 0xFFFFu) : 0u;
+        // Alternate (a) component extraction -- every image gives up its raster-first remaining
+        // component per round, the start pixels go to the border list -- and (b) one lane per
+        // listed border: trace + approximate + convexity test, all lanes running the same code.
+        for (int guard = 0; guard < 4096; ++guard) {
+            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[10] = 0; }
+            __syncthreads();
+            for (int round = 0; round < 256; ++round) {
+                const int more = __syncthreads_or(rem != 0u);
+                if (!more || L.redi[10] + IMGS > P.nslot) break;
+                int x0, y0;
+                const bool got = component_start(rem, y, x0, y0);
+                if (got && y == y0) {
+                    const int idx = atomicAdd(&L.redi[10], 1);
+                    L.clist[idx] = (uint32_t)g | ((uint32_t)x0 << 8) | ((uint32_t)y0 << 12);
                 }
             }
             __syncthreads();
+            const int count = L.redi[10];
+            if (count == 0) break;
+            // pass 0: one lane per border, packed into as few waves as possible.  pass 1 (only if a
+            // border outgrew its slot): lane 0 redoes the flagged ones in one big slot, so the slot
+            // capacity never changes results.
+            for (int pass = 0; pass < 2; ++pass) {
+                const unsigned long long redo = ((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8];
+                if (pass == 1 && redo == 0ull) break;
+                int c = tid, c_end = tid + 1;
+                int cap = P.slot_cap, stk = P.slot_stk;
+                unsigned char* base_mem = L.scratch + tid * P.slot_bytes;
+                if (pass == 1) {
+                    c = tid == 0 ? 0 : count;
+                    c_end = count;
+                    cap = (P.scratch_bytes / 6) & ~3;
+                    stk = cap;
+                    base_mem = L.scratch;
+                }
+                for (; c < c_end && c < count; ++c) {
+                    if (pass == 1 && !((redo >> c) & 1ull)) continue;
+                    const uint32_t e = L.clist[c];
+                    const int gi = e & 255u;
+                    const int r = L.tasklist[base + gi] >> 8;
+                    const SlotMem m = carve_slot(base_mem, cap, stk);
+                    const int rc = contour_vertices(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, m, L.vmask + r * 16);
+                    if (rc == 1 && pass == 0) atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
+                    if (rc == 2 || (rc == 1 && pass == 1)) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                }
+                __syncthreads();
+            }
         }
     }
 }
@@ -431,38 +458,33 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
     }
     __syncthreads();
 
-    if (mode == MODE_POSSIBLE) {
-        int item = io.actions[b];
-        if (item >= T.n_shapes) item = -1;
-        observe_location(P, T, S, io, L, b, item, nullptr, true);
-        return;
-    }
+    // every mode ends in at most one call of observe_location (single call site: small code)
+    int obs_item = -1;
+    bool do_observe = true, debug_out = false;
 
-    if (mode == MODE_CANDS) {            // PackingGame.get_action_candidates (binPhy.py:161-169)
+    if (mode == MODE_POSSIBLE) {
+        obs_item = io.actions[b];
+        if (obs_item >= T.n_shapes) obs_item = -1;
+        debug_out = true;
+    } else if (mode == MODE_CANDS) {     // PackingGame.get_action_candidates (binPhy.py:161-169)
         int oa = io.actions[b];
         oa = oa < 0 ? 0 : (oa >= P.K ? P.K - 1 : oa);
-        const int item = q[oa];
+        obs_item = q[oa];
         if (tid == 0) S.bs[b].order_action = oa;
-        observe_location(P, T, S, io, L, b, item, obs, false);
-        return;
-    }
-
+    } else
     if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
         if (tid == 0) {
-            BinState st;
-            st.episode = 0;
+            BinState* ps = S.bs + b;
             for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, 0, i);
-            st.cursor = P.K;
-            st.cur_item = -1;
-            st.nvalid = 0;
-            st.order_action = 0;
-            st.item_idx = 0;
-            st.ep_len = 0;
-            st.pad0 = 0;
-            st.ratio_acc = 0.0;
-            st.ep_reward = 0.0;
-            st.pad1[0] = st.pad1[1] = 0.0;
-            S.bs[b] = st;
+            ps->episode = 0;
+            ps->cursor = P.K;
+            ps->cur_item = -1;
+            ps->nvalid = 0;
+            ps->order_action = 0;
+            ps->item_idx = 0;
+            ps->ep_len = 0;
+            ps->ratio_acc = 0.0;
+            ps->ep_reward = 0.0;
             for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
@@ -472,10 +494,9 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
         const uint32_t key = S.cand[(size_t)b * P.S + a];            // action_to_position (:234-236)
         const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
-        const BinState st0 = S.bs[b];                                // one 64-byte line, wave-uniform
-        const int item0 = st0.cur_item;
-        const int oa = st0.order_action;
-        bool ok = item0 >= 0 && st0.nvalid > 0 && rot < P.R;         // prejudge (:238-245)
+        const int item0 = S.bs[b].cur_item;                          // same 64-byte line, wave-uniform
+        const int oa = S.bs[b].order_action;
+        bool ok = item0 >= 0 && S.bs[b].nvalid > 0 && rot < P.R;     // prejudge (:238-245)
         ShapeRot sr = {};
         if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
         if (ok) {
@@ -509,28 +530,31 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
             for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }   // Space.reset (space.py:49-52)
         }
         if (tid == 0) {
-            BinState st = st0;
+            BinState* ps = S.bs + b;                                 // field-wise: no struct copy (keeps scratch at 0)
             if (ok) {
                 const double vol = T.volume[item0];
                 const double reward = (vol / P.bin_vol) * 10.0;      // binPhy.py:321-322
-                st.ep_reward += reward;
-                st.ep_len += 1;
-                st.item_idx += 1;
-                st.ratio_acc += vol;
+                const double epr = ps->ep_reward + reward;
+                const int epl = ps->ep_len + 1;
+                const int cursor = ps->cursor;
+                ps->ep_reward = epr;
+                ps->ep_len = epl;
+                ps->item_idx += 1;
+                ps->ratio_acc += vol;
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
-                q[P.K - 1] = fetch_item(P, T, S, b, st.episode, st.cursor);   // generate_item (:325)
-                st.cursor += 1;
+                q[P.K - 1] = fetch_item(P, T, S, b, ps->episode, cursor);   // generate_item (:325)
+                ps->cursor = cursor + 1;
                 if (io.reward) io.reward[b] = reward;
                 if (io.done) io.done[b] = 0;
                 if (io.counter) io.counter[b] = -1;
                 if (io.ratio) io.ratio[b] = -1.0;
-                if (io.ep_reward) io.ep_reward[b] = st.ep_reward;
-                if (io.ep_len) io.ep_len[b] = st.ep_len;
+                if (io.ep_reward) io.ep_reward[b] = epr;
+                if (io.ep_len) io.ep_len[b] = epl;
             } else {
-                const int counter = st.item_idx;                     // info (binPhy.py:306-309)
-                const double ratio = st.ratio_acc / P.bin_vol;       // get_ratio (:149-153)
-                const double epr = st.ep_reward + 0.0;
-                const int epl = st.ep_len + 1;
+                const int counter = ps->item_idx;                    // info (binPhy.py:306-309)
+                const double ratio = ps->ratio_acc / P.bin_vol;      // get_ratio (:149-153)
+                const double epr = ps->ep_reward + 0.0;
+                const int epl = ps->ep_len + 1;
                 if (io.reward) io.reward[b] = 0.0;
                 if (io.done) io.done[b] = 1;
                 if (io.counter) io.counter[b] = counter;
@@ -540,29 +564,32 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
                 double* tot = S.totals + (size_t)b * 4;
                 tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
                 // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset
-                st.episode += 1;
-                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, st.episode, i);
-                st.cursor = P.K;
-                st.item_idx = 0;
-                st.ratio_acc = 0.0;
-                st.ep_reward = 0.0;
-                st.ep_len = 0;
+                const int ep = ps->episode + 1;
+                ps->episode = ep;
+                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
+                ps->cursor = P.K;
+                ps->item_idx = 0;
+                ps->ratio_acc = 0.0;
+                ps->ep_reward = 0.0;
+                ps->ep_len = 0;
             }
-            S.bs[b] = st;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
         __syncthreads();
     }
 
-    stamp(io, b, 1);
-    if (P.K == 1) {                      // online: cur_observation with a fresh item (binPhy.py:188-227)
-        const int item = L.redi[16];
-        __syncthreads();
-        observe_location(P, T, S, io, L, b, item, obs, false);
-    } else {                             // buffer branch (binPhy.py:228-230): [k ids | heightmap]
-        for (int i = tid; i < P.K; i += BLOCK) obs[i] = (float)L.redi[16 + i];
-        for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
+    if (mode == MODE_RESET || mode == MODE_STEP) {
+        stamp(io, b, 1);
+        if (P.K == 1) {                  // online: cur_observation with a fresh item (binPhy.py:188-227)
+            obs_item = L.redi[16];
+            __syncthreads();
+        } else {                         // buffer branch (binPhy.py:228-230): [k ids | heightmap]
+            do_observe = false;
+            for (int i = tid; i < P.K; i += BLOCK) obs[i] = (float)L.redi[16 + i];
+            for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
+        }
     }
+    if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out);
 }
 
 // getConvexHullActions on caller-supplied grids (parity tests of the contour stage).

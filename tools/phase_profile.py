@@ -43,5 +43,7 @@ out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
        "mean_cycles": {n: float(d[:, i].mean()) for i, n in enumerate(names)},
        "p99_cycles": {n: float(np.percentile(d[:, i], 99)) for i, n in enumerate(names)},
        "max_cycles": {n: float(d[:, i].max()) for i, n in enumerate(names)},
-       "total_mean": float(d.sum(1).mean()), "mean_candidates": float(ncand.mean())}
+       "total_mean": float(d.sum(1).mean()),
+       "total_pct": {str(q): float(np.percentile(d.sum(1), q)) for q in (50, 90, 99, 99.9, 100)},
+       "mean_candidates": float(ncand.mean())}
 print(json.dumps(out))
