@@ -248,13 +248,162 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     return true;
 }
 
-// One outer border: trace, approximate, mark convex vertices.  Returns 0 ok, 1 capacity
-// overflow (caller retries with a bigger slot), 2 iteration guard.
+// One outer border, serially: trace, approximate, mark convex vertices.  Returns 0 ok,
+// 1 capacity overflow (caller retries with a bigger slot), 2 iteration guard.
 __device__ inline int contour_vertices(const uint32_t* img, int x0, int y0, const SlotMem& m, uint32_t* vrows) {
     const int n = trace_border(img, x0, y0, m.pts, m.cap);
     if (n < 0) return 2;
     if (n > m.cap) return 1;
     return approx_and_convex(m.pts, n, m.dst, m.stk, m.cap_stk, vrows) ? 0 : 1;
+}
+
+// ---------------------------------------------------------------------------------------
+// Wave-cooperative approxPolyDP + convexity test for ONE (long) border: all 64 lanes of the
+// calling wave take part; the point distances of a pass / slice are computed one point per lane
+// and the arg-max ("first strict maximum in traversal order", as the sequential loops find it)
+// comes from a wave reduction.  Same results as approx_and_convex().
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uint8_t* dst, uint32_t* stk,
+                                              int cap_stk, uint32_t* vrows) {
+    const int lane = threadIdx.x & 63;
+    int new_count = 0, top = 0;
+    // 1. three farthest-point hops; key = dist<<12 | (4095 - j): max dist, then smallest j
+    int pos = 0, right_start = 0;
+    bool le_eps = false;
+    uint8_t start_pt = 0;
+    for (int it = 0; it < 3; ++it) {
+        pos += right_start;
+        if (pos >= count) pos -= count;
+        start_pt = pts[pos];
+        const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
+        uint32_t best = 0u;
+        for (int j = 1 + lane; j < count; j += 64) {
+            int idx = pos + j;
+            if (idx >= count) idx -= count;
+            const uint8_t pt = pts[idx];
+            const int dx = IRBPP_PX(pt) - sx, dy = IRBPP_PY(pt) - sy;
+            const uint32_t key = ((uint32_t)(dx * dx + dy * dy) << 12) | (uint32_t)(4095 - j);
+            best = key > best ? key : best;
+        }
+        best = wave_max_u32(best);
+        const int max_dist = (int)(best >> 12);
+        if (max_dist > 0) right_start = 4095 - (int)(best & 4095u);
+        le_eps = max_dist <= 1;
+        // the sequential loop leaves pos back on the start index after count reads
+    }
+    if (!le_eps) {
+        const int s0 = pos;
+        int far = right_start + s0;
+        if (far >= count) far -= count;
+        if (cap_stk < 2) return false;
+        if (lane == 0) {
+            stk[0] = (uint32_t)far | ((uint32_t)s0 << 16);
+            stk[1] = (uint32_t)s0 | ((uint32_t)far << 16);
+        }
+        top = 2;
+    } else {
+        if (lane == 0) dst[0] = start_pt;
+        new_count = 1;
+    }
+    // 3. Douglas-Peucker: one slice per iteration, its interior points spread over the lanes
+    while (top > 0) {
+        const uint32_t sl = stk[--top];
+        const int s_start = (int)(sl & 0xFFFFu), s_end = (int)(sl >> 16);
+        start_pt = pts[s_start];
+        int len = s_end - s_start;                  // points from start to end along the closed curve
+        if (len <= 0) len += count;
+        bool le = true;
+        int split = 0;
+        if (len > 1) {
+            const uint8_t end_pt = pts[s_end];
+            const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
+            const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
+            uint32_t best = 0u;
+            for (int t = 1 + lane; t < len; t += 64) {
+                int idx = s_start + t;
+                if (idx >= count) idx -= count;
+                const uint8_t pt = pts[idx];
+                int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
+                dist = dist < 0 ? -dist : dist;
+                const uint32_t key = ((uint32_t)dist << 12) | (uint32_t)(4095 - t);
+                best = key > best ? key : best;
+            }
+            best = wave_max_u32(best);
+            const int max_dist = (int)(best >> 12);
+            if (max_dist > 0) {
+                split = s_start + 4095 - (int)(best & 4095u);
+                if (split >= count) split -= count;
+            }
+            le = max_dist * max_dist <= dx * dx + dy * dy;
+        }
+        if (le) {
+            if (lane == 0) dst[new_count] = start_pt;
+            ++new_count;
+        } else {
+            if (top + 2 > cap_stk) return false;
+            if (lane == 0) {
+                stk[top] = (uint32_t)split | ((uint32_t)s_end << 16);
+                stk[top + 1] = (uint32_t)s_start | ((uint32_t)split << 16);
+            }
+            top += 2;
+        }
+    }
+    // 4. clean-up (inherently sequential): every lane runs it redundantly on the same data, only
+    //    lane 0 stores; dst is re-read through LDS, so stores must be visible to the later loads
+    {
+        const int cnt = new_count;
+        int p2 = cnt - 1;
+        start_pt = dst[p2];
+        if (++p2 >= cnt) p2 = 0;
+        int wpos = p2;
+        uint8_t pt = dst[p2];
+        if (++p2 >= cnt) p2 = 0;
+        for (int i = 0; i < cnt && new_count > 2; ++i) {
+            const uint8_t end_pt = dst[p2];
+            if (++p2 >= cnt) p2 = 0;
+            const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
+            const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
+            int dist = ux * dy - uy * dx;
+            dist = dist < 0 ? -dist : dist;
+            const int inner = ux * (IRBPP_PX(end_pt) - IRBPP_PX(pt)) + uy * (IRBPP_PY(end_pt) - IRBPP_PY(pt));
+            if (2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0) {
+                --new_count;
+                start_pt = end_pt;
+                if (lane == 0) dst[wpos] = end_pt;
+                if (++wpos >= cnt) wpos = 0;
+                pt = dst[p2];
+                if (++p2 >= cnt) p2 = 0;
+                ++i;
+                continue;
+            }
+            start_pt = pt;
+            if (lane == 0) dst[wpos] = pt;
+            if (++wpos >= cnt) wpos = 0;
+            pt = end_pt;
+        }
+    }
+    // find_convex_vetex, one vertex per lane
+    const int m = new_count;
+    for (int i = lane; i < m; i += 64) {
+        const uint8_t b = dst[i];
+        bool keep = true;
+        if (m > 3) {
+            const uint8_t a = dst[i == 0 ? m - 1 : i - 1];
+            const uint8_t c = dst[i == m - 1 ? 0 : i + 1];
+            keep = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
+                   (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a)) < 0;
+        }
+        if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
+    }
+    return true;
 }
 
 }  // namespace irbpp

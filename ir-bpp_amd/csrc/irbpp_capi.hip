@@ -64,9 +64,9 @@ void layout_lds(Params& P, int want_slots) {
     P.nslot = want_slots > 0 ? want_slots : 64;                       // outer borders traced per pass
     if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
     if (P.nslot < 16) P.nslot = 16;                                   // one extraction round yields up to 16
-    P.slot_cap = 48;
+    P.slot_cap = 64;
     P.slot_stk = 16;
-    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 164 B = 41 dwords: odd stride, lanes hit distinct LDS banks
+    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 196 B = 49 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
     P.o_lev = off;       off += align16(P.R * P.AC);

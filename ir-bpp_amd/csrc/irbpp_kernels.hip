@@ -32,6 +32,7 @@ namespace irbpp {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
+constexpr int LONG_BORDER = 12;     // borders with more points go to the wave-cooperative Douglas-Peucker
 
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
@@ -175,7 +176,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
 // invalid), `valid` given per thread/rotation through L.lev (255 = masked).  On return
 // L.vmask[r*16 + row] has bit col set for every candidate (row, col) of rotation r.
 // ---------------------------------------------------------------------------------------
-__device__ inline void contour_stage(const Params& P, const State& S, const Lds& L) {
+__device__ inline void contour_stage(const Params& P, const State& S, const Lds& L, long long* prof) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC;
     // task list: one task per (rotation, present level)
@@ -213,7 +214,8 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         // component per round, the start pixels go to the border list -- and (b) one lane per
         // listed border: trace + approximate + convexity test, all lanes running the same code.
         for (int guard = 0; guard < 4096; ++guard) {
-            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[10] = 0; }
+            const long long t_a = prof ? (long long)clock64() : 0;
+            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[10] = 0; L.redi[11] = 0; L.redi[12] = 0; }
             __syncthreads();
             for (int round = 0; round < 256; ++round) {
                 const int more = __syncthreads_or(rem != 0u);
@@ -227,35 +229,68 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             }
             __syncthreads();
             const int count = L.redi[10];
+            const long long t_b = prof ? (long long)clock64() : 0;
+            if (prof && tid == 0) { prof[5] += t_b - t_a; prof[7] += count; }
             if (count == 0) break;
-            // pass 0: one lane per border, packed into as few waves as possible.  pass 1 (only if a
-            // border outgrew its slot): lane 0 redoes the flagged ones in one big slot, so the slot
-            // capacity never changes results.
-            for (int pass = 0; pass < 2; ++pass) {
-                const unsigned long long redo = ((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8];
-                if (pass == 1 && redo == 0ull) break;
-                int c = tid, c_end = tid + 1;
-                int cap = P.slot_cap, stk = P.slot_stk;
-                unsigned char* base_mem = L.scratch + tid * P.slot_bytes;
-                if (pass == 1) {
-                    c = tid == 0 ? 0 : count;
-                    c_end = count;
-                    cap = (P.scratch_bytes / 6) & ~3;
-                    stk = cap;
-                    base_mem = L.scratch;
-                }
-                for (; c < c_end && c < count; ++c) {
-                    if (pass == 1 && !((redo >> c) & 1ull)) continue;
-                    const uint32_t e = L.clist[c];
-                    const int gi = e & 255u;
-                    const int r = L.tasklist[base + gi] >> 8;
-                    const SlotMem m = carve_slot(base_mem, cap, stk);
-                    const int rc = contour_vertices(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, m, L.vmask + r * 16);
-                    if (rc == 1 && pass == 0) atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
-                    if (rc == 2 || (rc == 1 && pass == 1)) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
-                }
-                __syncthreads();
+            // (b1) trace: one lane per listed border, all in lockstep (packed into the first wave)
+            uint8_t* llist = (uint8_t*)(L.redi + 32);            // borders too long for the lockstep DP
+            int my_n = 0, my_r = 0;
+            const SlotMem mine = carve_slot(L.scratch + tid * P.slot_bytes, P.slot_cap, P.slot_stk);
+            if (tid < count) {
+                const uint32_t e = L.clist[tid];
+                const int gi = e & 255u;
+                my_r = L.tasklist[base + gi] >> 8;
+                const int n = trace_border(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, mine.pts, mine.cap);
+                if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                else if (n > mine.cap) atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
+                else if (n > LONG_BORDER) {
+                    llist[atomicAdd(&L.redi[11], 1)] = (uint8_t)tid;
+                    L.clist[tid] = e | ((uint32_t)n << 16);
+                } else my_n = n;
             }
+            __syncthreads();
+            // (b2) short borders: Douglas-Peucker + convexity per lane, still in lockstep
+            if (my_n > 0 && !approx_and_convex(mine.pts, my_n, mine.dst, mine.stk, mine.cap_stk, L.vmask + my_r * 16))
+                atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
+            // (b3) long borders: each wave pulls one at a time and works on it with all 64 lanes
+            {
+                const int nlong = L.redi[11];
+                for (int guard2 = 0; guard2 < 64; ++guard2) {
+                    int li = 0;
+                    if ((tid & 63) == 0) li = atomicAdd(&L.redi[12], 1);
+                    li = __shfl(li, 0);
+                    if (li >= nlong) break;
+                    const int c = llist[li];
+                    const uint32_t e = L.clist[c];
+                    const int r = L.tasklist[base + (e & 255u)] >> 8;
+                    const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
+                    if (!approx_and_convex_wave(m.pts, (int)(e >> 16), m.dst, m.stk, m.cap_stk, L.vmask + r * 16) &&
+                        (tid & 63) == 0)
+                        atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
+                }
+            }
+            __syncthreads();
+            // (b4) a border that outgrew its slot (points or stack): lane 0 redoes it in one big slot,
+            // so slot capacity never changes results
+            {
+                const unsigned long long redo = ((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8];
+                if (redo != 0ull) {
+                    if (tid == 0) {
+                        const int cap = (P.scratch_bytes / 6) & ~3;
+                        const SlotMem m = carve_slot(L.scratch, cap, cap);
+                        for (int c = 0; c < count; ++c) {
+                            if (!((redo >> c) & 1ull)) continue;
+                            const uint32_t e = L.clist[c];
+                            const int gi = e & 255u;
+                            const int r = L.tasklist[base + gi] >> 8;
+                            if (contour_vertices(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, m, L.vmask + r * 16) != 0)
+                                atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
+            if (prof && tid == 0) prof[6] += (long long)clock64() - t_b;
         }
     }
 }
@@ -338,7 +373,8 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     __syncthreads();
     stamp(io, b, 2);
 
-    contour_stage(P, S, L);
+    if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * 8 + 5] = 0; io.phase_cycles[(size_t)b * 8 + 6] = 0; io.phase_cycles[(size_t)b * 8 + 7] = 0; }
+    contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * 8 : nullptr);
     stamp(io, b, 3);
 
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
@@ -623,7 +659,7 @@ irbpp_hull_kernel(const Params P, const State S, const double* posz_valid, const
         }
     }
     __syncthreads();
-    contour_stage(P, S, L);
+    contour_stage(P, S, L, nullptr);
     for (int i = tid; i < R * 16; i += BLOCK) vertex_rows[(size_t)g * R * 16 + i] = L.vmask[i];
 }
 

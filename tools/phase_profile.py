@@ -32,11 +32,13 @@ for _ in range(a.warm):
 cyc = env.enable_phase_cycles(True)
 names = ["apply", "overlap", "contour", "emit"]
 acc = []
+extra = []
 for _ in range(a.steps):
     obs, _, _ = env.step(env.policy_minz(obs))
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
     acc.append(np.diff(c[:, :5], axis=1))
+    extra.append(c[:, 5:8].copy())
 d = np.concatenate(acc)
 ncand = (obs[:, :2500].reshape(a.bins, 500, 5)[:, :, 4] == 1).sum(1).float()
 out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
@@ -46,4 +48,8 @@ out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
        "total_mean": float(d.sum(1).mean()),
        "total_pct": {str(q): float(np.percentile(d.sum(1), q)) for q in (50, 90, 99, 99.9, 100)},
        "mean_candidates": float(ncand.mean())}
+ex = np.concatenate(extra)
+out["contour_detail"] = {"extract_mean": float(ex[:, 0].mean()), "extract_max": float(ex[:, 0].max()),
+                         "process_mean": float(ex[:, 1].mean()), "process_max": float(ex[:, 1].max()),
+                         "borders_mean": float(ex[:, 2].mean()), "borders_max": float(ex[:, 2].max())}
 print(json.dumps(out))
