@@ -134,6 +134,8 @@ def main():
     ap.add_argument("--bins", type=int, default=4096, help="bins per GPU")
     ap.add_argument("--workload", default="blockout")
     ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--pipeline-streams", type=int, default=4,
+                    help="also measure the bins split into this many independently stepping sub-batches (0 = skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     a = ap.parse_args()
@@ -186,6 +188,44 @@ def main():
     elapsed = D.max_over_ranks(elapsed, dev)
     tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
 
+    # Extra measurement (not `value`): the same bins as S sub-batches on S HIP streams, each
+    # stepping on its own; one sub-batch's straggler workgroups overlap the next one's start.
+    pipelined = None
+    if a.pipeline_streams > 1 and a.bins % a.pipeline_streams == 0:
+        ns, per = a.pipeline_streams, a.bins // a.pipeline_streams
+        env.close()
+        sh = D.shard(rank, world, a.bins)
+        subs = [GpuPackingEnv(shapes, seqs, per, device=dev, contour_slots=a.slots,
+                              global_offset=sh["global_offset"] + i * per, global_bins=sh["global_bins"], **kw)
+                for i in range(ns)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(ns)]
+        so, sn, sa = [], [], []
+        for e, st in zip(subs, streams):
+            with torch.cuda.stream(st):
+                o = e.reset()
+                so.append(o); sn.append(torch.empty_like(o))
+                sa.append(torch.empty((per,), dtype=torch.int32, device=dev))
+
+        def sub_step():
+            for i, (e, st) in enumerate(zip(subs, streams)):
+                with torch.cuda.stream(st):
+                    e.policy_minz(so[i], actions_out=sa[i])
+                    e.step(sa[i], obs_out=sn[i])
+                    so[i], sn[i] = sn[i], so[i]
+
+        for _ in range(a.warmup):
+            sub_step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(a.steps):
+            sub_step()
+        barrier()
+        t_pipe = D.max_over_ranks(time.perf_counter() - t1, dev)
+        for e in subs:
+            e.check_device_error()
+            e.close()
+        pipelined = {"streams": ns, "value": a.bins * world * a.steps / t_pipe, "ms_per_step": t_pipe / a.steps * 1e3}
+
     if rank == 0:
         total_steps = a.bins * world * a.steps
         bps = algorithmic_bytes_per_step(shapes, hc, 1)
@@ -213,6 +253,8 @@ def main():
             "episodes": {"finished": float(tot[0]), "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
                          "mean_items": float(tot[2] / tot[0]) if tot[0] else None},
         }
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -75,11 +75,30 @@ __device__ inline bool component_start(uint32_t& rem, int y, int& x0, int& y0) {
     return active;
 }
 
+// Straight runs.  After a step in an axis direction d the walk keeps going straight exactly
+// while the three neighbours probed before d (directions d+5, d+6, d+7) are background and the
+// neighbour in direction d is foreground; no point is emitted inside a run (CHAIN_APPROX_SIMPLE
+// keeps direction changes only).  For a horizontal run those are bits of the row below/above,
+// for a vertical run bits of the column left/right (imgT holds the transposed image), so the
+// run length is one bit scan.  `line` = the row/column being walked, `side` = the row/column
+// whose three bits must be clear, `p` = current position along the line.
+__device__ __forceinline__ int run_forward(uint32_t line, uint32_t side, int p) {      // towards higher bits
+    const uint32_t clear = ~(side | (side << 1) | (side >> 1));
+    const uint32_t m = (clear & (line >> 1) & 0xFFFFu) >> p;
+    return __ffs((int)~m) - 1;                                                          // consecutive ones from bit p
+}
+__device__ __forceinline__ int run_backward(uint32_t line, uint32_t side, int p) {     // towards lower bits
+    const uint32_t clear = ~(side | (side << 1) | (side >> 1));
+    const uint32_t m = clear & (line << 1) & 0xFFFFu;
+    const uint32_t z = ~m & ((2u << p) - 1u);                                           // zero bits at or below p
+    return z ? p - (31 - __clz((int)z)) : p + 1;
+}
+
 // icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border starting at (x0,y0).  The
-// 3-row window around the current pixel stays in registers and slides with the walk.  Returns
-// the number of points produced (stored only while they fit in cap), or -1 if the iteration
-// guard tripped.
-__device__ inline int trace_border(const uint32_t* img, int x0, int y0, uint8_t* pts, int cap) {
+// 3-row window around the current pixel stays in registers; axis-aligned runs are jumped in one
+// go.  img = 16 row words, imgT = 16 column words (bit y of word x).  Returns the number of
+// points produced (stored only while they fit in cap), or -1 if the iteration guard tripped.
+__device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
     uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
     uint32_t nb = nb_mask(ra, rb, rc, x0);
     // clockwise search 3,2,1,0,7,6,5 (s_end = 4: the west pixel is background) for the first neighbour
@@ -99,16 +118,37 @@ __device__ inline int trace_border(const uint32_t* img, int x0, int y0, uint8_t*
         const int k2 = (cur_s + 1) & 7;
         const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
         const int s2 = (k2 + __ffs((int)r2) - 1) & 7;
-        const int dy = dir_dy(s2);
-        const int x4 = x3 + dir_dx(s2), y4 = y3 + dy;
+        int x4 = x3 + dir_dx(s2), y4 = y3 + dir_dy(s2);
         if (s2 != prev_s) {                                       // CHAIN_APPROX_SIMPLE
             if (n < cap) pts[n] = (uint8_t)(x3 | (y3 << 4));
             ++n;
         }
         prev_s = s2;
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-        if (dy > 0) { ra = rb; rb = rc; rc = y4 < 15 ? img[y4 + 1] : 0u; }
-        else if (dy < 0) { rc = rb; rb = ra; ra = y4 > 0 ? img[y4 - 1] : 0u; }
+        // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run
+        bool reload = false;
+        if (s2 == 0 || s2 == 4) {
+            if (y4 != y3) reload = true;                          // (not possible for E/W, kept for symmetry)
+            const uint32_t line = img[y4];
+            const int L = s2 == 0 ? run_forward(line, y4 < 15 ? img[y4 + 1] : 0u, x4)
+                                  : run_backward(line, y4 > 0 ? img[y4 - 1] : 0u, x4);
+            x4 += s2 == 0 ? L : -L;
+        } else if (s2 == 6 || s2 == 2) {
+            const uint32_t line = imgT[x4];
+            const int L = s2 == 6 ? run_forward(line, x4 > 0 ? imgT[x4 - 1] : 0u, y4)
+                                  : run_backward(line, x4 < 15 ? imgT[x4 + 1] : 0u, y4);
+            y4 += s2 == 6 ? L : -L;
+            reload = true;
+        } else {
+            reload = y4 != y3;
+        }
+        // a run that ends on the start pixel, moving opposite to the first step, closes the border
+        if (x4 == x0 && y4 == y0 && s2 == (s ^ 4)) return n;
+        if (reload) {
+            ra = y4 > 0 ? img[y4 - 1] : 0u;
+            rb = img[y4];
+            rc = y4 < 15 ? img[y4 + 1] : 0u;
+        }
         x3 = x4;
         y3 = y4;
         cur_s = (s2 + 4) & 7;
@@ -250,8 +290,9 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
 
 // One outer border, serially: trace, approximate, mark convex vertices.  Returns 0 ok,
 // 1 capacity overflow (caller retries with a bigger slot), 2 iteration guard.
-__device__ inline int contour_vertices(const uint32_t* img, int x0, int y0, const SlotMem& m, uint32_t* vrows) {
-    const int n = trace_border(img, x0, y0, m.pts, m.cap);
+__device__ inline int contour_vertices(const uint32_t* img, const uint32_t* imgT, int x0, int y0, const SlotMem& m,
+                                       uint32_t* vrows) {
+    const int n = trace_border(img, imgT, x0, y0, m.pts, m.cap);
     if (n < 0) return 2;
     if (n > m.cap) return 1;
     return approx_and_convex(m.pts, n, m.dst, m.stk, m.cap_stk, vrows) ? 0 : 1;
@@ -263,78 +304,94 @@ __device__ inline int contour_vertices(const uint32_t* img, int x0, int y0, cons
 // and the arg-max ("first strict maximum in traversal order", as the sequential loops find it)
 // comes from a wave reduction.  Same results as approx_and_convex().
 // ---------------------------------------------------------------------------------------
+// wave64 max-reduction with DPP (no LDS crossbar): quad swaps, row mirrors, then row broadcasts;
+// the total lands in lane 63 and is read back as a wave-uniform scalar.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    for (int o = 32; o > 0; o >>= 1) {
-        const uint32_t w = (uint32_t)__shfl_xor((int)v, o);
-        v = w > v ? w : v;
-    }
-    return v;
+    v = umax(v, dpp_u32<0xB1, 0xF>(v));      // quad_perm [1,0,3,2]
+    v = umax(v, dpp_u32<0x4E, 0xF>(v));      // quad_perm [2,3,0,1]
+    v = umax(v, dpp_u32<0x141, 0xF>(v));     // row_half_mirror
+    v = umax(v, dpp_u32<0x140, 0xF>(v));     // row_mirror: every lane now holds its row's max
+    v = umax(v, dpp_u32<0x142, 0xA>(v));     // row_bcast15 into rows 1 and 3
+    v = umax(v, dpp_u32<0x143, 0xC>(v));     // row_bcast31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-__device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uint8_t* dst, uint32_t* stk,
-                                              int cap_stk, uint32_t* vrows) {
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// v_writelane equivalent: entry `idx` (wave-uniform) of the lane-indexed register `reg` := val
+__device__ __forceinline__ int put_lane(int reg, int idx, int val) { return (int)(threadIdx.x & 63) == idx ? val : reg; }
+
+// Points, the slice stack and the output polygon live in lane-indexed registers (entry i in
+// lane i), read and written with v_readlane / v_writelane at wave-uniform indices; only the
+// per-lane distance reads go to LDS.  Handles borders of up to 64 points.
+__device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uint32_t* vrows) {
     const int lane = threadIdx.x & 63;
+    count = uni(count);
+    const int pv = lane < count ? (int)pts[lane] : 0;            // pv: point j in lane j
+    int sv = 0;                                                  // slice stack, entry i in lane i
+    int dv = 0;                                                  // output polygon, vertex i in lane i
     int new_count = 0, top = 0;
     // 1. three farthest-point hops; key = dist<<12 | (4095 - j): max dist, then smallest j
     int pos = 0, right_start = 0;
     bool le_eps = false;
-    uint8_t start_pt = 0;
+    int start_pt = 0;
     for (int it = 0; it < 3; ++it) {
         pos += right_start;
         if (pos >= count) pos -= count;
-        start_pt = pts[pos];
+        start_pt = __builtin_amdgcn_readlane(pv, pos);
         const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
         uint32_t best = 0u;
-        for (int j = 1 + lane; j < count; j += 64) {
+        const int j = 1 + lane;
+        if (j < count) {
             int idx = pos + j;
             if (idx >= count) idx -= count;
-            const uint8_t pt = pts[idx];
+            const int pt = pts[idx];
             const int dx = IRBPP_PX(pt) - sx, dy = IRBPP_PY(pt) - sy;
-            const uint32_t key = ((uint32_t)(dx * dx + dy * dy) << 12) | (uint32_t)(4095 - j);
-            best = key > best ? key : best;
+            best = ((uint32_t)(dx * dx + dy * dy) << 12) | (uint32_t)(4095 - j);
         }
         best = wave_max_u32(best);
         const int max_dist = (int)(best >> 12);
         if (max_dist > 0) right_start = 4095 - (int)(best & 4095u);
         le_eps = max_dist <= 1;
-        // the sequential loop leaves pos back on the start index after count reads
     }
     if (!le_eps) {
         const int s0 = pos;
         int far = right_start + s0;
         if (far >= count) far -= count;
-        if (cap_stk < 2) return false;
-        if (lane == 0) {
-            stk[0] = (uint32_t)far | ((uint32_t)s0 << 16);
-            stk[1] = (uint32_t)s0 | ((uint32_t)far << 16);
-        }
+        sv = put_lane(sv, 0, far | (s0 << 16));     // right slice
+        sv = put_lane(sv, 1, s0 | (far << 16));     // slice, processed first
         top = 2;
     } else {
-        if (lane == 0) dst[0] = start_pt;
+        dv = put_lane(dv, 0, start_pt);
         new_count = 1;
     }
     // 3. Douglas-Peucker: one slice per iteration, its interior points spread over the lanes
     while (top > 0) {
-        const uint32_t sl = stk[--top];
-        const int s_start = (int)(sl & 0xFFFFu), s_end = (int)(sl >> 16);
-        start_pt = pts[s_start];
+        --top;
+        const int sl = __builtin_amdgcn_readlane(sv, top);
+        const int s_start = sl & 0xFFFF, s_end = (int)((unsigned)sl >> 16);
+        start_pt = __builtin_amdgcn_readlane(pv, s_start);
         int len = s_end - s_start;                  // points from start to end along the closed curve
         if (len <= 0) len += count;
         bool le = true;
         int split = 0;
         if (len > 1) {
-            const uint8_t end_pt = pts[s_end];
+            const int end_pt = __builtin_amdgcn_readlane(pv, s_end);
             const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
             const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
             uint32_t best = 0u;
-            for (int t = 1 + lane; t < len; t += 64) {
+            const int t = 1 + lane;
+            if (t < len) {
                 int idx = s_start + t;
                 if (idx >= count) idx -= count;
-                const uint8_t pt = pts[idx];
+                const int pt = pts[idx];
                 int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
                 dist = dist < 0 ? -dist : dist;
-                const uint32_t key = ((uint32_t)dist << 12) | (uint32_t)(4095 - t);
-                best = key > best ? key : best;
+                best = ((uint32_t)dist << 12) | (uint32_t)(4095 - t);
             }
             best = wave_max_u32(best);
             const int max_dist = (int)(best >> 12);
@@ -345,29 +402,26 @@ __device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uin
             le = max_dist * max_dist <= dx * dx + dy * dy;
         }
         if (le) {
-            if (lane == 0) dst[new_count] = start_pt;
+            dv = put_lane(dv, new_count, start_pt);
             ++new_count;
         } else {
-            if (top + 2 > cap_stk) return false;
-            if (lane == 0) {
-                stk[top] = (uint32_t)split | ((uint32_t)s_end << 16);
-                stk[top + 1] = (uint32_t)s_start | ((uint32_t)split << 16);
-            }
+            if (top + 2 > 64) return false;
+            sv = put_lane(sv, top, split | (s_end << 16));
+            sv = put_lane(sv, top + 1, s_start | (split << 16));
             top += 2;
         }
     }
-    // 4. clean-up (inherently sequential): every lane runs it redundantly on the same data, only
-    //    lane 0 stores; dst is re-read through LDS, so stores must be visible to the later loads
+    // 4. clean-up (inherently sequential, wave-uniform): in place on the register polygon
     {
         const int cnt = new_count;
         int p2 = cnt - 1;
-        start_pt = dst[p2];
+        start_pt = __builtin_amdgcn_readlane(dv, p2);
         if (++p2 >= cnt) p2 = 0;
         int wpos = p2;
-        uint8_t pt = dst[p2];
+        int pt = __builtin_amdgcn_readlane(dv, p2);
         if (++p2 >= cnt) p2 = 0;
         for (int i = 0; i < cnt && new_count > 2; ++i) {
-            const uint8_t end_pt = dst[p2];
+            const int end_pt = __builtin_amdgcn_readlane(dv, p2);
             if (++p2 >= cnt) p2 = 0;
             const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
             const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
@@ -377,31 +431,31 @@ __device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uin
             if (2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0) {
                 --new_count;
                 start_pt = end_pt;
-                if (lane == 0) dst[wpos] = end_pt;
+                dv = put_lane(dv, wpos, end_pt);
                 if (++wpos >= cnt) wpos = 0;
-                pt = dst[p2];
+                pt = __builtin_amdgcn_readlane(dv, p2);
                 if (++p2 >= cnt) p2 = 0;
                 ++i;
                 continue;
             }
             start_pt = pt;
-            if (lane == 0) dst[wpos] = pt;
+            dv = put_lane(dv, wpos, pt);
             if (++wpos >= cnt) wpos = 0;
             pt = end_pt;
         }
     }
-    // find_convex_vetex, one vertex per lane
+    // find_convex_vetex, one vertex per lane (neighbours through the cross-lane network)
     const int m = new_count;
-    for (int i = lane; i < m; i += 64) {
-        const uint8_t b = dst[i];
-        bool keep = true;
-        if (m > 3) {
-            const uint8_t a = dst[i == 0 ? m - 1 : i - 1];
-            const uint8_t c = dst[i == m - 1 ? 0 : i + 1];
-            keep = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
-                   (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a)) < 0;
+    {
+        const int ia = lane == 0 ? m - 1 : lane - 1, ic = lane == m - 1 ? 0 : lane + 1;
+        const int a = __shfl(dv, ia < 0 ? 0 : ia), c = __shfl(dv, ic > 63 ? 63 : ic), b = dv;
+        if (lane < m) {
+            bool keep = true;
+            if (m > 3)
+                keep = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
+                       (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a)) < 0;
+            if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
         }
-        if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
     }
     return true;
 }

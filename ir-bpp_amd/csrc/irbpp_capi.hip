@@ -64,8 +64,10 @@ void layout_lds(Params& P, int want_slots) {
     P.nslot = want_slots > 0 ? want_slots : 64;                       // outer borders traced per pass
     if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
     if (P.nslot < 16) P.nslot = 16;                                   // one extraction round yields up to 16
-    P.slot_cap = 64;
+    P.slot_cap = 64;                                                  // <= 64: the cooperative path keeps a border in one register per lane
     P.slot_stk = 16;
+    P.long_border = 8;
+    if (const char* lb = getenv("IRBPP_LONG_BORDER")) P.long_border = atoi(lb);   // tuning knob
     P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 196 B = 49 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
@@ -73,7 +75,7 @@ void layout_lds(Params& P, int want_slots) {
     P.o_present = off;   off += align16(P.R * 8);
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
-    P.o_img = off;       off += align16(16 * 16 * 4);
+    P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
     P.o_clist = off;     off += align16(P.nslot * 4);
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 256;

@@ -79,6 +79,7 @@ struct Params {
     // dynamic-LDS carve-up (byte offsets, all multiples of 16)
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red;
     int32_t nslot, slot_cap, slot_stk, slot_bytes, scratch_bytes, lds_bytes;
+    int32_t long_border;   // borders with more points than this use the wave-cooperative Douglas-Peucker
 };
 
 enum Mode : int32_t {

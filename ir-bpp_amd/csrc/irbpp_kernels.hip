@@ -32,7 +32,6 @@ namespace irbpp {
 
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
-constexpr int LONG_BORDER = 12;     // borders with more points go to the wave-cooperative Douglas-Peucker
 
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
@@ -197,14 +196,17 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's image g
     constexpr int IMGS = BLOCK / 16;                 // 16 level images per batch
     for (int base = 0; base < ntasks; base += IMGS) {
-        for (int i = tid; i < IMGS * 16; i += BLOCK) L.img[i] = 0u;
+        for (int i = tid; i < 2 * IMGS * 16; i += BLOCK) L.img[i] = 0u;       // rows, then transposed columns
         __syncthreads();
         if (tid < AC) {
             for (int r = 0; r < R; ++r) {
                 const int code = L.lev[r * AC + tid];
                 if (code != 255) {
                     const int ti = (int)L.taskidx[r * 64 + code] - base;
-                    if (ti >= 0 && ti < IMGS) atomicOr(&L.img[ti * 16 + X], 1u << Y);
+                    if (ti >= 0 && ti < IMGS) {
+                        atomicOr(&L.img[ti * 16 + X], 1u << Y);                    // row X, bit Y
+                        atomicOr(&L.img[(IMGS + ti) * 16 + Y], 1u << X);           // column Y, bit X
+                    }
                 }
             }
         }
@@ -240,10 +242,11 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                 const uint32_t e = L.clist[tid];
                 const int gi = e & 255u;
                 my_r = L.tasklist[base + gi] >> 8;
-                const int n = trace_border(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, mine.pts, mine.cap);
+                const int n = trace_border(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 8) & 15u, (e >> 12) & 15u,
+                                           mine.pts, mine.cap);
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                 else if (n > mine.cap) atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
-                else if (n > LONG_BORDER) {
+                else if (n > P.long_border) {
                     llist[atomicAdd(&L.redi[11], 1)] = (uint8_t)tid;
                     L.clist[tid] = e | ((uint32_t)n << 16);
                 } else my_n = n;
@@ -264,8 +267,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                     const uint32_t e = L.clist[c];
                     const int r = L.tasklist[base + (e & 255u)] >> 8;
                     const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
-                    if (!approx_and_convex_wave(m.pts, (int)(e >> 16), m.dst, m.stk, m.cap_stk, L.vmask + r * 16) &&
-                        (tid & 63) == 0)
+                    if (!approx_and_convex_wave(m.pts, (int)(e >> 16), L.vmask + r * 16) && (tid & 63) == 0)
                         atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
                 }
             }
@@ -283,7 +285,8 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                             const uint32_t e = L.clist[c];
                             const int gi = e & 255u;
                             const int r = L.tasklist[base + gi] >> 8;
-                            if (contour_vertices(L.img + gi * 16, (e >> 8) & 15u, (e >> 12) & 15u, m, L.vmask + r * 16) != 0)
+                            if (contour_vertices(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 8) & 15u, (e >> 12) & 15u, m,
+                                                 L.vmask + r * 16) != 0)
                                 atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                         }
                     }
