@@ -125,30 +125,30 @@ __device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, in
         }
         prev_s = s2;
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-        // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run
-        bool reload = false;
-        if (s2 == 0 || s2 == 4) {
-            if (y4 != y3) reload = true;                          // (not possible for E/W, kept for symmetry)
-            const uint32_t line = img[y4];
-            const int L = s2 == 0 ? run_forward(line, y4 < 15 ? img[y4 + 1] : 0u, x4)
-                                  : run_backward(line, y4 > 0 ? img[y4 - 1] : 0u, x4);
-            x4 += s2 == 0 ? L : -L;
-        } else if (s2 == 6 || s2 == 2) {
-            const uint32_t line = imgT[x4];
-            const int L = s2 == 6 ? run_forward(line, x4 > 0 ? imgT[x4 - 1] : 0u, y4)
-                                  : run_backward(line, x4 < 15 ? imgT[x4 + 1] : 0u, y4);
-            y4 += s2 == 6 ? L : -L;
-            reload = true;
-        } else {
-            reload = y4 != y3;
+        // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run.
+        // Branch-free on purpose: the lanes of a wave walk different borders in lockstep.
+        {
+            const bool horiz = (s2 & 3) == 0;                     // E or W: walk a row, else a column
+            const bool fwd = s2 == 0 || s2 == 6;                  // E or S: towards higher bits
+            const uint32_t* base = horiz ? img : imgT;
+            const int li = horiz ? y4 : x4;
+            const int si = (horiz == fwd) ? li + 1 : li - 1;      // E: row below, W: row above, S: column left, N: column right
+            int p = horiz ? x4 : y4;
+            const uint32_t line = base[li];
+            const uint32_t side = base[si & 15];
+            const uint32_t side_ok = (unsigned)si < 16u ? side : 0u;
+            const int lf = run_forward(line, side_ok, p), lb = run_backward(line, side_ok, p);
+            const int L = (s2 & 1) ? 0 : (fwd ? lf : -lb);
+            p += L;
+            x4 = horiz ? p : x4;
+            y4 = horiz ? y4 : p;
         }
         // a run that ends on the start pixel, moving opposite to the first step, closes the border
         if (x4 == x0 && y4 == y0 && s2 == (s ^ 4)) return n;
-        if (reload) {
-            ra = y4 > 0 ? img[y4 - 1] : 0u;
-            rb = img[y4];
-            rc = y4 < 15 ? img[y4 + 1] : 0u;
-        }
+        const uint32_t a = img[(y4 - 1) & 15], b = img[y4], c = img[(y4 + 1) & 15];
+        ra = y4 > 0 ? a : 0u;
+        rb = b;
+        rc = y4 < 15 ? c : 0u;
         x3 = x4;
         y3 = y4;
         cur_s = (s2 + 4) & 7;

@@ -173,6 +173,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(cand, N * P.S);
     ALLOC(bs, N);
     ALLOC(totals, N * 4);
+    ALLOC(cost, N);
+    ALLOC(order, N);
     ALLOC(err, 1);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
@@ -271,6 +273,9 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 
 static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream) {
     io.phase_cycles = env->phase_cycles;
+    if (mode == MODE_STEP || mode == MODE_CANDS)      // most expensive bins first (see irbpp_env_kernel)
+        hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, env->S.cost, env->S.order,
+                           env->P.N);
     hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                        env->P, env->T, env->S, io, mode);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;

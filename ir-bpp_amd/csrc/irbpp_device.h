@@ -66,6 +66,8 @@ struct State {
     uint32_t* cand;        // [N][S]
     BinState* bs;          // [N]
     double* totals;        // [N][4]: episodes, sum ratio, sum counter, sum reward
+    int32_t* cost;         // [N] shader cycles the bin's last transition took (scheduling hint)
+    int32_t* order;        // [N] launch order of the bins: most expensive first
     int32_t* err;          // [1] device error word
 };
 

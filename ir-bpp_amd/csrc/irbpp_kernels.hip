@@ -482,8 +482,12 @@ extern "C" __global__ void __launch_bounds__(BLOCK)
 irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds L = carve_lds(smem, P);
-    const int b = blockIdx.x;
+    // Bins are launched most-expensive-first (S.order, refreshed by irbpp_order_kernel from the
+    // cycle counts of the previous transition): with ~2.7 bins per resident workgroup slot the
+    // stragglers would otherwise decide the kernel's duration.
+    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
+    const long long t_begin = (long long)clock64();
     double* ghm = S.hm + (size_t)b * P.Hc;
     int32_t* q = S.queue + (size_t)b * P.K;
     float* obs = io.obs ? io.obs + (size_t)b * io.obs_stride : nullptr;
@@ -629,6 +633,37 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         }
     }
     if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out);
+    if (tid == 0 && mode != MODE_POSSIBLE) {
+        const long long dt = (long long)clock64() - t_begin;
+        S.cost[b] = dt > 0x7fffffffLL ? 0x7fffffff : (int)dt;
+    }
+}
+
+// Counting sort of the bins by descending cost bucket (64 buckets of 8192 cycles) -> S.order.
+// One workgroup; runs before every transition launch (a few microseconds).
+extern "C" __global__ void __launch_bounds__(1024)
+irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
+    __shared__ int hist[64];
+    __shared__ int start[64];
+    const int tid = threadIdx.x;
+    if (tid < 64) hist[tid] = 0;
+    __syncthreads();
+    for (int b = tid; b < N; b += 1024) {
+        int k = 63 - (cost[b] >> 13);
+        k = k < 0 ? 0 : k;                      // bucket 0 = most expensive
+        atomicAdd(&hist[k], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int acc = 0;
+        for (int k = 0; k < 64; ++k) { start[k] = acc; acc += hist[k]; }
+    }
+    __syncthreads();
+    for (int b = tid; b < N; b += 1024) {
+        int k = 63 - (cost[b] >> 13);
+        k = k < 0 ? 0 : k;
+        order[atomicAdd(&start[k], 1)] = b;
+    }
 }
 
 // getConvexHullActions on caller-supplied grids (parity tests of the contour stage).
