@@ -131,6 +131,12 @@ int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stri
 int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev,
                             double* posz_dev, uint8_t* mask_dev, void* stream);
 
+/* Space.get_heuristic_action (space.py:162-218) for the item of the last location observation on
+ * the current heightmaps: method 1 MINZ, 2 DBLF, 3 FIRSTFIT, 4 HM; dir_idx 0..3 = (Xflip, Yflip)
+ * as at space.py:163-166.  out_dev: int32[num_bins][3] = (rotIdx, lx, ly), the first minimum in C
+ * order of np.round(score, 6) with invalid cells at 1e6.  RANDOM is not provided. */
+int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int32_t* out_dev, void* stream);
+
 /* getConvexHullActions (cvTools.py:61-102) on caller-supplied grids, independent of the
  * environment state: posz_valid_dev float64[n_grids][n_rot][Ax][Ay], mask_dev
  * uint8[n_grids][n_rot][Ax][Ay].  vertex_rows_dev: uint32[n_grids][n_rot][16]; word `row` has

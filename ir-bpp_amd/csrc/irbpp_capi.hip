@@ -160,6 +160,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess) {
         delete env;
         return IRBPP_ERR_HIP;
@@ -231,9 +233,9 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                     if ((mt != 0.0 && mt != 1.0) || (mb != 0.0 && mb != 1.0)) return IRBPP_ERR_ARG;
                     const int32_t toff = ((ci % P.step) * P.step + (cj % P.step)) * P.AC + (ci / P.step) * P.Ay +
                                          (cj / P.step);
-                    if (mb != 0.0) bcell.push_back(Cell{height_bottom[e], toff, 0});
+                    if (mb != 0.0) bcell.push_back(Cell{height_bottom[e], toff, ci * s.fy + cj});
                     else s.has_out = 1;
-                    if (mt != 0.0) tcell.push_back(Cell{height_top[e], toff, 0});
+                    if (mt != 0.0) tcell.push_back(Cell{height_top[e], toff, ci * s.fy + cj});
                 }
             }
             s.nb = (int32_t)bcell.size() - s.ob;
@@ -342,6 +344,19 @@ int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double*
     io.posz_out = posz_dev;
     io.mask_out = mask_dev;
     return launch_env(env, io, MODE_POSSIBLE, stream);
+}
+
+int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int32_t* out_dev, void* stream) {
+    if (!env || !out_dev || method < 1 || method > 4 || dir_idx < 0 || dir_idx > 3) return IRBPP_ERR_ARG;
+    if (!env->was_reset) return IRBPP_ERR_STATE;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.heur_out = out_dev;
+    io.heur_method = method;
+    io.heur_dir = dir_idx;
+    hipLaunchKernelGGL(irbpp_heuristic_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream, env->P,
+                       env->T, env->S, io);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
 int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev, const uint8_t* mask_dev,

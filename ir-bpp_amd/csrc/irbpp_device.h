@@ -33,7 +33,7 @@ struct ShapeRot {
 struct Cell {              // 16 B: one s_load_dwordx4 per cell when the list index is wave-uniform
     double v;              // heightMapB / heightMapT value
     int32_t off;           // LDS tile offset relative to the action cell's own entry
-    int32_t pad;
+    int32_t pad;           // row-major index i*fy+j of the cell in its [fx][fy] table
 };
 
 struct Tables {
@@ -104,6 +104,9 @@ struct StepIO {
     double* posz_out;           // MODE_POSSIBLE
     uint8_t* mask_out;
     long long* phase_cycles;    // optional [N][8] shader-clock stamps per phase (tooling)
+    int32_t* heur_out;          // MODE_HEURISTIC: [N][3] = rot, lx, ly
+    int32_t heur_method;        // 1 MINZ, 2 DBLF, 3 FIRSTFIT, 4 HM (space.py:168-218)
+    int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
 };
 
 }  // namespace irbpp

@@ -298,12 +298,76 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     }
 }
 
-// ---------------------------------------------------------------------------------------
-// Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
-// ---------------------------------------------------------------------------------------
-__device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                        const Lds& L, int b, int item, float* obs, bool debug_out) {
-    item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
+// np.sum over the window of np.max(((heightMapT + posZ) * maskH, heightmapC[window]), axis=0)
+// (space.py:213-214) in numpy's own summation order: float64 pairwise sum with eight
+// accumulators per block of <= 128 elements, halves split at multiples of 8 (numpy
+// loops_utils.h.src, @TYPE@_pairwise_sum).  `at(i)` yields element i of the row-major window.
+template <typename F>
+__device__ double np_pairwise_sum(const F& at, int lo, int n) {
+    if (n < 8) {
+        double res = 0.0;
+        for (int i = 0; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        for (int k = 0; k < 8; ++k) r[k] = at(lo + k);
+        int i = 8;
+        for (; i < n - (n % 8); i += 8)
+            for (int k = 0; k < 8; ++k) r[k] += at(lo + i + k);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; ++i) res += at(lo + i);
+        return res;
+    }
+    int n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(at, lo, n2) + np_pairwise_sum(at, lo + n2, n - n2);
+}
+
+// Space.get_heuristic_action (space.py:162-218) for one action cell; invalid cells score 1e6.
+__device__ inline double heuristic_score(const Params& P, const Tables& T, const StepIO& io, const Lds& L,
+                                         const ShapeRot& sr, int r, int X, int Y) {
+    const double z = L.posz[r * P.AC + X * P.Ay + Y];
+    if (!(z < 1e3)) return 1e6;
+    const bool xf = (io.heur_dir & 2) != 0, yf = (io.heur_dir & 1) != 0;
+    const double cx = xf ? (double)(P.Ax - X) : (double)X, cy = yf ? (double)(P.Ay - Y) : (double)Y;
+    double score;
+    switch (io.heur_method) {
+        case 1: score = z; break;                                            // MINZ
+        case 2: score = (cx + cy) * P.res_a + 100.0 * z; break;              // DBLF
+        case 3: score = cx + cy; break;                                      // FIRSTFIT
+        default: {                                                           // HM
+            score = (cx + cy) * P.res_a;
+            const Cell* top = T.tcell + sr.ot;
+            const double* h0 = L.hm + X * P.Ay + Y;
+            // dense row-major walk over the fx x fy window; the compact top list is in the same order
+            auto at = [&](int e) -> double {
+                const int i = e / sr.fy, j = e - i * sr.fy;
+                const int off = ((i % P.step) * P.step + (j % P.step)) * P.AC + (i / P.step) * P.Ay + (j / P.step);
+                const double h = h0[off];
+                // binary search of the masked-in list for this offset's row-major rank
+                int lo = 0, hi = sr.nt - 1;
+                double v = 0.0;                                             // (T + z) * 0 for masked-out cells
+                bool in = false;
+                while (lo <= hi) {
+                    const int mid = (lo + hi) >> 1;
+                    const int oi = top[mid].pad;                            // row-major index of the list entry
+                    if (oi == e) { v = top[mid].v + z; in = true; break; }
+                    if (oi < e) lo = mid + 1; else hi = mid - 1;
+                }
+                (void)in;
+                return fmax(v, h);
+            };
+            score += np_pairwise_sum(at, 0, sr.fx * sr.fy) * 100.0;
+        }
+    }
+    return round6(score);
+}
+
+// Space.get_possible_position (space.py:98-129) for `item` on the tile in LDS: fills L.posz
+// (posZValid), L.lev (height-level codes), L.present and returns np.sum(naiveMask).
+__device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
+                                   const Lds& L, int b, int item, bool debug_out) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = tid / Ay, Y = tid % Ay;
@@ -367,7 +431,19 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
             if (code != 255) atomicOr(&L.present[r], 1ull << code);
         }
     }
-    const int nvalid = block_sum_int(my_valid, L.redi);      // np.sum(naiveMask) for prejudge
+    return block_sum_int(my_valid, L.redi);                  // np.sum(naiveMask) for prejudge
+}
+
+// ---------------------------------------------------------------------------------------
+// Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
+// ---------------------------------------------------------------------------------------
+__device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
+                                        const Lds& L, int b, int item, float* obs, bool debug_out) {
+    item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
+    const int tid = threadIdx.x;
+    const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
+    const int X = tid / Ay, Y = tid % Ay;
+    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
@@ -663,6 +739,48 @@ irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
         int k = 63 - (cost[b] >> 13);
         k = k < 0 ? 0 : k;
         order[atomicAdd(&start[k], 1)] = b;
+    }
+}
+
+// Space.get_heuristic_action (space.py:162-218) for the item of the last observation: its own
+// kernel, so that the recursion of numpy's pairwise sum (HM) costs the transition kernel nothing.
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const StepIO io) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Lds L = carve_lds(smem, P);
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int R = P.R, AC = P.AC, Ay = P.Ay;
+    const int X = tid / Ay, Y = tid % Ay;
+    const double* ghm = S.hm + (size_t)b * P.Hc;
+    for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
+    __syncthreads();
+    const int item = __builtin_amdgcn_readfirstlane(S.bs[b].cur_item);
+    overlap_test(P, T, S, io, L, b, item, false);
+    __syncthreads();
+    double best = 1e300;
+    int best_i = 0x7fffffff;
+    for (int r = 0; r < R; ++r) {
+        if (tid < AC) {
+            double sc = 1e6;
+            if (item >= 0) sc = heuristic_score(P, T, io, L, T.sr[item * R + r], r, X, Y);
+            const int idx = r * AC + tid;
+            if (sc < best || (sc == best && idx < best_i)) { best = sc; best_i = idx; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const double ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(best_i, o);
+        if (ob < best || (ob == best && oi < best_i)) { best = ob; best_i = oi; }
+    }
+    __syncthreads();
+    if ((tid & 63) == 0) { L.redd[tid >> 6] = best; L.redi[4 + (tid >> 6)] = best_i; }
+    __syncthreads();
+    if (tid == 0) {                      // np.argmin: the first minimum in C order (rot, X, Y)
+        for (int w = 1; w < WAVES; ++w)
+            if (L.redd[w] < best || (L.redd[w] == best && L.redi[4 + w] < best_i)) { best = L.redd[w]; best_i = L.redi[4 + w]; }
+        io.heur_out[b * 3 + 0] = best_i / AC;
+        io.heur_out[b * 3 + 1] = (best_i % AC) / Ay;
+        io.heur_out[b * 3 + 2] = best_i % Ay;
     }
 }
 

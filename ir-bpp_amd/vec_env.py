@@ -160,6 +160,15 @@ class GpuPackingEnv(object):
                    "irbpp_possible_position")
         return posz, mask
 
+    HEURISTICS = {"MINZ": 1, "DBLF": 2, "FIRSTFIT": 3, "HM": 4}
+
+    def heuristic_action(self, method: str, dir_idx: int = 0) -> torch.Tensor:
+        """Space.get_heuristic_action (space.py:162-218) per bin -> int32[N,3] = (rot, lx, ly)."""
+        out = torch.empty((self.num_bins, 3), dtype=torch.int32, device=self.device)
+        _lib.check(self.lib.irbpp_heuristic_action(self._h, self.HEURISTICS[method], dir_idx, _ptr(out), self._stream()),
+                   "irbpp_heuristic_action")
+        return out
+
     def convex_hull_actions(self, posz_valid: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
         """[G,R,Ax,Ay] float64 / uint8 -> uint32-as-int32 [G,R,16]: word ``row`` has bit ``col`` set."""
         g = posz_valid.shape[0]

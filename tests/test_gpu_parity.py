@@ -295,3 +295,28 @@ def test_cube_buffered_k10_matches_oracle():
         ndone += int(odone.sum())
     genv.close()
     assert ndone >= 2
+
+
+def test_heuristic_actions_match_oracle():
+    """Space.get_heuristic_action (space.py:162-218): MINZ / DBLF / FIRSTFIT / HM, all four flips."""
+    sh = synthetic.general_shapes(n_shapes=16, n_rot=4, seed=21)
+    seqs = synthetic.make_sequences(sh.n_shapes, 32, 60, seed=4)
+    n = 4
+    genv = GpuVecEnv(sh, seqs, n, device=DEV)
+    oenv = OracleVecEnv(n, sh, seqs)
+    gobs = genv.reset()
+    oobs = _f32(oenv.reset())
+    for t in range(7):
+        for method in ("MINZ", "DBLF", "FIRSTFIT", "HM"):
+            for d in ((0, 3) if t % 2 else (1, 2)):
+                got = genv.env.heuristic_action(method, d).cpu().numpy()
+                for i, e in enumerate(oenv.envs):
+                    if e.space.naiveMask.sum() == 0:
+                        continue
+                    ref = e.space.get_heuristic_action(method, e.next_item_ID, d)
+                    assert tuple(got[i]) == tuple(int(v) for v in ref), (t, method, d, i)
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        gobs, _, _, _ = genv.step(act)
+        oobs, _, _, _ = oenv.step(act)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs))
+    genv.close()
