@@ -154,6 +154,15 @@ int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream);
  * The multi-GPU runner all-reduces these four numbers (RCCL). */
 int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream);
 
+/* replaces: PackingGame.packed (binPhy.py:141,296), the per-episode placement record that
+ * tools.test saves to trajs.npy (tools.py:339-340).  While set, every successful placement of
+ * bin b, the i-th of its episode (i < capacity), stores meta_dev[b*capacity+i] =
+ * item | rot<<16 | lx<<20 | ly<<24 (item ids must be < 65536) and z_dev[b*capacity+i] = its drop
+ * height posZmap[rot,lx,ly].  A finished episode's entries stay readable until that bin's next
+ * placement overwrites them, so read them right after the step that reported done.  NULL, NULL
+ * switches the log off. */
+int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, int32_t capacity);
+
 /* Tooling: when cycles_dev != NULL every later transition launch stores, per bin, eight
  * shader-clock stamps int64[num_bins][8]: 0 start, 1 action applied, 2 overlap test done,
  * 3 contour stage done, 4 observation written (5..7 unused).  NULL switches it off. */

@@ -46,6 +46,7 @@ SIGNATURES = {
     "irbpp_get_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_set_placement_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "irbpp_device_error": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p]),
 }

@@ -387,6 +387,14 @@ int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream) {
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
+int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, int32_t capacity) {
+    if (!env || capacity < 0 || ((meta_dev == nullptr) != (z_dev == nullptr))) return IRBPP_ERR_ARG;
+    env->S.log_meta = meta_dev;
+    env->S.log_z = z_dev;
+    env->S.log_cap = meta_dev ? capacity : 0;
+    return IRBPP_OK;
+}
+
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
     env->phase_cycles = (long long*)cycles_dev;

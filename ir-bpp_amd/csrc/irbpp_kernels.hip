@@ -656,6 +656,12 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
                 const double epr = ps->ep_reward + reward;
                 const int epl = ps->ep_len + 1;
                 const int cursor = ps->cursor;
+                const int slot = ps->item_idx;                       // self.packed.append(...) (binPhy.py:296)
+                if (S.log_meta && slot < S.log_cap) {
+                    S.log_meta[(size_t)b * S.log_cap + slot] = (uint32_t)item0 | ((uint32_t)rot << 16) |
+                                                                ((uint32_t)lx << 20) | ((uint32_t)ly << 24);
+                    S.log_z[(size_t)b * S.log_cap + slot] = z;
+                }
                 ps->ep_reward = epr;
                 ps->ep_len = epl;
                 ps->item_idx += 1;

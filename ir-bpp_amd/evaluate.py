@@ -1,0 +1,87 @@
+"""Batched evaluation in the shape of the reference's ``tools.test`` (tools.py:303-358).
+
+The reference evaluates one environment, episode after episode, over the trajectories of
+``test_sequence.pt`` (LoadItemCreator, IRcreator.py:74-103: episode e reads trajectory e+1) and
+saves ``env.packed`` of every episode to ``trajs.npy`` (tools.py:339-340).  Here the episodes run
+side by side: bin g plays trajectory ``traj_start + g`` once, every finished bin is frozen, and the
+result carries the same statistics (avg/var of reward sum, length, ratio) plus the placement
+records in the reference's row format ``[item id, name, positionFLB, quaternion xyzw]``
+(binPhy.py:296).
+"""
+from __future__ import annotations
+
+from typing import Callable, Dict, Optional
+
+import numpy as np
+import torch
+
+from .synthetic import ROT_DEGREES
+from .vec_env import GpuPackingEnv
+
+
+def rotation_quaternion_xyzw(rot_idx: int) -> np.ndarray:
+    """The quaternion binPhy.py:77-78 stores for z-rotation ``rot_idx`` (mat2quat, saved as xyzw)."""
+    half = np.deg2rad(ROT_DEGREES[rot_idx]) / 2.0
+    w, z = np.cos(half), np.sin(half)
+    if w < 0:
+        w, z = -w, -z
+    return np.array([0.0, 0.0, z, w])
+
+
+def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] = None, device="cuda:0",
+             names: Optional[Dict[int, str]] = None, traj_start: int = 1, max_steps: int = 4096,
+             log_capacity: int = 256, **env_kw):
+    """Run ``n_episodes`` evaluation episodes, one per bin.
+
+    ``policy(env, obs) -> int32[N] device tensor`` picks the actions; default = the scripted MINZ
+    policy kernel.  Returns a dict with the statistics ``tools.test`` prints and ``trajs``: a list
+    over episodes of lists of ``[item_id, name, positionFLB(3), quaternion_xyzw(4)]``.
+    """
+    env = GpuPackingEnv(shapes, sequences, n_episodes, device=device, traj_start=traj_start,
+                        global_bins=n_episodes, **env_kw)
+    if env.K != 1:
+        raise ValueError("evaluate() drives the online (bufferSize=1) protocol of tools.test")
+    meta, logz = env.enable_placement_log(log_capacity)
+    res_a = env_kw.get("resolutionA", 0.02)
+    scale = np.array([100.0, 100.0, 100.0])
+    bin_z = float(np.round(np.asarray(env_kw.get("bin_dimension", (0.32, 0.32, 0.30)), dtype=np.float64), 6)[2])
+    obs = env.reset()
+    n = n_episodes
+    finished = np.zeros(n, dtype=bool)
+    ratio = np.zeros(n)
+    reward_sum = np.zeros(n)
+    length = np.zeros(n, dtype=np.int64)
+    trajs = [None] * n
+    pick = policy if policy is not None else (lambda e, o: e.policy_minz(o))
+    for _ in range(max_steps):
+        obs, _, _ = env.step(pick(env, obs))
+        h = env.step_info_host()
+        newly = h["done"] & ~finished
+        if newly.any():
+            idx = np.nonzero(newly)[0]
+            m = meta[idx].cpu().numpy().astype(np.uint32)
+            z = logz[idx].cpu().numpy()
+            for row, b in enumerate(idx):
+                k = int(h["counter"][b])
+                ratio[b], reward_sum[b], length[b] = h["ratio"][b], h["ep_reward"][b], h["ep_len"][b]
+                ep = []
+                for i in range(min(k, log_capacity)):
+                    w = int(m[row, i])
+                    item, rot, lx, ly = w & 0xFFFF, (w >> 16) & 15, (w >> 20) & 15, (w >> 24) & 15
+                    flb = np.round((lx * res_a, ly * res_a, bin_z), decimals=6) * scale     # addObject (Interface.py:201)
+                    flb[2] = z[row, i] * scale[2]                                           # adjustHeight (Interface.py:185-187)
+                    ep.append([item, names[item] if names else "%d.obj" % item, flb / scale, rotation_quaternion_xyzw(rot)])
+                trajs[b] = ep
+            finished |= newly
+        if finished.all():
+            break
+    env.check_device_error()
+    env.close()
+    done = finished
+    return {
+        "episodes": int(done.sum()), "unfinished": int((~done).sum()),
+        "avg_reward": float(reward_sum[done].mean()), "var_reward": float(reward_sum[done].var()),
+        "avg_length": float(length[done].mean()), "var_length": float(length[done].var()),
+        "mean_ratio": float(ratio[done].mean()), "var_ratio": float(ratio[done].var()),
+        "ratio": ratio, "reward_sum": reward_sum, "length": length, "trajs": trajs,
+    }

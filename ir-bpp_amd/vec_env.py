@@ -194,6 +194,14 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_episode_totals(self._h, _ptr(out), self._stream()), "irbpp_episode_totals")
         return out
 
+    def enable_placement_log(self, capacity: int = 256):
+        """Device-side PackingGame.packed: (meta uint32-as-int32 [N,cap], z float64 [N,cap])."""
+        self._log_meta = torch.zeros((self.num_bins, capacity), dtype=torch.int32, device=self.device)
+        self._log_z = torch.zeros((self.num_bins, capacity), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.irbpp_set_placement_log(self._h, _ptr(self._log_meta), _ptr(self._log_z), capacity),
+                   "irbpp_set_placement_log")
+        return self._log_meta, self._log_z
+
     def enable_phase_cycles(self, on: bool = True) -> Optional[torch.Tensor]:
         """Tooling: int64[N,8] shader-clock stamps written by every later transition launch."""
         self._cycles = torch.zeros((self.num_bins, 8), dtype=torch.int64, device=self.device) if on else None

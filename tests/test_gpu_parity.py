@@ -320,3 +320,35 @@ def test_heuristic_actions_match_oracle():
         oobs, _, _, _ = oenv.step(act)
         np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs))
     genv.close()
+
+
+def test_batched_evaluation_matches_sequential_reference_protocol():
+    """tools.test (tools.py:303-358): one env, episode e on trajectory e+1, env.packed per episode.
+    The batched driver plays the same episodes side by side; statistics and placement records
+    must equal the oracle run sequentially."""
+    from irbpp_amd.evaluate import evaluate, rotation_quaternion_xyzw
+    from oracle.packing import PackingGame
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 80, seed=1)
+    E = 6
+    out = evaluate(sh, seqs, E, device=DEV)
+    assert out["episodes"] == E and out["unfinished"] == 0
+    env = PackingGame(sh, seqs)                      # LoadItemCreator semantics: first reset -> trajectory 1
+    for ep in range(E):
+        obs = env.reset()
+        rsum, steps = 0.0, 0
+        while True:
+            obs, r, d, info = env.step(minz_action(_f32(obs), S))
+            rsum += r
+            steps += 1
+            if d:
+                break
+        assert out["ratio"][ep] == info["ratio"] and out["length"][ep] == steps
+        assert out["reward_sum"][ep] == rsum
+        placed = env.packed[:-1]                     # the last entry is the failed placement (binPhy.py:296-311)
+        assert len(out["trajs"][ep]) == len(placed) == info["counter"]
+        for got, (item, rot, lx, ly, height) in zip(out["trajs"][ep], placed):
+            assert got[0] == item and got[1] == "%d.obj" % item
+            np.testing.assert_allclose(got[2], [lx * 0.02, ly * 0.02, height], rtol=0, atol=1e-12)
+            np.testing.assert_array_equal(got[3], rotation_quaternion_xyzw(rot))
+    assert abs(out["mean_ratio"] - np.mean(out["ratio"])) < 1e-15
