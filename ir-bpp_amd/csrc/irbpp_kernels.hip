@@ -36,10 +36,22 @@ constexpr int WAVES = BLOCK / 64;
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
 
+// Exact C fmod(a, b) for b > 0 and |a/b| < 2^52 without ocml's generic loop: the true remainder
+// is always representable, so fma(-q, b, a) is exact once q is the truncated quotient; a/b is
+// correctly rounded, hence trunc(a/b) is off by at most one, which the sign/range test repairs.
+__device__ __forceinline__ double fmod_exact(double a, double b) {
+    const double x = fabs(a);
+    double q = trunc(x / b);
+    double r = fma(-q, b, x);
+    if (r < 0.0) { q -= 1.0; r = fma(-q, b, x); }
+    else if (r >= b) { q += 1.0; r = fma(-q, b, x); }
+    return copysign(r, a);
+}
+
 // numpy floor_divide on float64 (npy_divmod): decides which cells share a height level
 // (cvTools.py:78), e.g. 0.06 // 0.01 == 5.
 __device__ inline double np_floor_divide(double a, double b) {
-    double mod = fmod(a, b);
+    double mod = fmod_exact(a, b);
     double div = (a - mod) / b;
     if (mod != 0.0) {
         if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
@@ -380,33 +392,49 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int r = 0; r < R; ++r) {
         double z = 1e3;
         bool valid = false;
-        if (item >= 0 && tid < AC) {
+        if (item >= 0) {
             const ShapeRot sr = T.sr[item * R + r];
-            if (X <= Ax - sr.ax && Y <= Ay - sr.ay) {
-                const ConstCellPtr cells = as_const(T.bcell + sr.ob);
-                const double* h0 = L.hm + X * Ay + Y;
-                double m = sr.has_out ? 0.0 : -1e300;
-                // 8 cells per trip; the next trip's scalar loads are issued before this trip's math
-                constexpr int U = 8;
-                const int nfull = sr.nb / U;
-                double cv[U];
-                int co[U];
-                if (nfull > 0) {
+            const bool in_range = tid < AC && X <= Ax - sr.ax && Y <= Ay - sr.ay;
+            const double* h0 = L.hm + X * Ay + Y;
+            double m = sr.has_out ? 0.0 : -1e300;
+            // The footprint list is fetched 64 cells at a time, one 16-byte cell per lane (a
+            // coalesced vector load), and broadcast cell by cell with v_readlane: the loop then has
+            // only LDS reads in flight, which the hardware returns in order and the compiler can
+            // pipeline (scalar loads would share lgkmcnt with the LDS reads and force full drains).
+            const Cell* cells = T.bcell + sr.ob;
+            const int lane = tid & 63;
+            for (int base = 0; base < sr.nb; base += 64) {
+                const int idx = base + lane < sr.nb ? base + lane : sr.nb - 1;
+                const Cell c = cells[idx];
+                const int cnt = sr.nb - base < 64 ? sr.nb - base : 64;
+                int c_off = c.off;
+                int c_lo = (int)__double2loint(c.v), c_hi = (int)__double2hiint(c.v);
+                // every lane must really hold its cell (v_readlane reads lanes that are masked off
+                // below): keep the compiler from sinking the load into the in_range branch
+                asm volatile("" : "+v"(c_off), "+v"(c_lo), "+v"(c_hi));
+                if (in_range) {
+                    int u = 0;
+                    for (; u + 8 <= cnt; u += 8) {                  // 8 LDS reads in flight per trip
+                        double hv[8], vv[8];
 #pragma unroll
-                    for (int u = 0; u < U; ++u) { cv[u] = cells[u].v; co[u] = cells[u].off; }
+                        for (int k = 0; k < 8; ++k) {
+                            const int off = __builtin_amdgcn_readlane(c_off, u + k);
+                            vv[k] = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u + k),
+                                                     __builtin_amdgcn_readlane(c_lo, u + k));
+                            hv[k] = h0[off];
+                        }
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) m = fmax(m, hv[k] - vv[k]);
+                    }
+                    for (; u < cnt; ++u) {
+                        const int off = __builtin_amdgcn_readlane(c_off, u);
+                        const double v = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u),
+                                                          __builtin_amdgcn_readlane(c_lo, u));
+                        m = fmax(m, h0[off] - v);
+                    }
                 }
-                for (int t = 0; t < nfull; ++t) {
-                    double nv[U];
-                    int no[U];
-                    const int nxt = (t + 1 < nfull ? t + 1 : t) * U;       // last trip reloads itself (harmless)
-#pragma unroll
-                    for (int u = 0; u < U; ++u) { nv[u] = cells[nxt + u].v; no[u] = cells[nxt + u].off; }
-#pragma unroll
-                    for (int u = 0; u < U; ++u) m = fmax(m, h0[co[u]] - cv[u]);
-#pragma unroll
-                    for (int u = 0; u < U; ++u) { cv[u] = nv[u]; co[u] = no[u]; }
-                }
-                for (int e = nfull * U; e < sr.nb; ++e) m = fmax(m, h0[cells[e].off] - cells[e].v);
+            }
+            if (in_range) {
                 z = m;
                 valid = round6(z + sr.ext_z_r - P.bin_z) <= 0.0;
             }
