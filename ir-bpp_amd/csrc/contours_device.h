@@ -13,7 +13,12 @@
 //     unlabelled when the scan reaches it; every other such pixel has already been labelled by
 //     the outer or a hole border).  Hole borders are discarded by find_out_contour and border
 //     following itself only tests "non-zero", so neither hole tracing nor label state is
-//     needed: component_start() finds the start pixels with a row-parallel bit flood fill.
+//     needed.  The start pixels are found without any flood fill: a pixel whose W, NW, N and NE
+//     neighbours are background is a *candidate* (every component's raster-first pixel is one);
+//     the border traced from a candidate is kept iff no pixel on it has a smaller raster index
+//     than the candidate -- true for exactly the raster-first pixel of a component, false for
+//     other convex corners of the same outer border and for candidates that sit on a hole
+//     border (a hole's border always has pixels in rows above it).
 //   * one lane then owns one outer border: trace_border() (icvFetchContourEx, SIMPLE
 //     approximation) followed by approx_and_convex() (approxPolyDP_ + the convexity test).  All
 //     lanes of a wave run the same code, so divergence is limited to loop trip counts.
@@ -46,33 +51,9 @@ __device__ __forceinline__ uint32_t nb_mask(uint32_t a, uint32_t b, uint32_t c, 
            ((tb & 1u) << 4) | ((tc & 1u) << 5) | (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
 }
 
-// One round of component extraction for the image whose row `y` (0..15) this lane holds in
-// `rem` (the not-yet-extracted foreground pixels); the 16 rows of an image sit in 16 consecutive
-// lanes.  Finds the raster-first remaining pixel (x0,y0), flood-fills its 8-connected component
-// with row-parallel bit operations and removes it from `rem`.  Returns true in every lane of a
-// group that extracted a component.  Must be called by all 64 lanes of the wave.
-__device__ inline bool component_start(uint32_t& rem, int y, int& x0, int& y0) {
-    const int lane = threadIdx.x & 63, gbase = lane & 48;
-    const unsigned long long bal = __ballot(rem != 0u);
-    const uint32_t gmask = (uint32_t)(bal >> gbase) & 0xFFFFu;
-    const bool active = gmask != 0u;
-    y0 = active ? __ffs((int)gmask) - 1 : 0;
-    const uint32_t rem_y0 = (uint32_t)__shfl((int)rem, gbase + y0);
-    x0 = active ? __ffs((int)rem_y0) - 1 : 0;
-    uint32_t fill = (active && y == y0) ? (1u << x0) : 0u;
-    for (int it = 0; it < 256; ++it) {
-        const uint32_t h = fill | (fill << 1) | (fill >> 1);
-        uint32_t up = (uint32_t)__shfl_up((int)h, 1, 16);
-        uint32_t dn = (uint32_t)__shfl_down((int)h, 1, 16);
-        if (y == 0) up = 0u;
-        if (y == 15) dn = 0u;
-        const uint32_t nf = (h | up | dn) & rem;
-        const bool changed = nf != fill;
-        fill = nf;
-        if (!__any(changed)) break;
-    }
-    rem &= ~fill;
-    return active;
+// Candidate start pixels of row `row` given the row above it (`up`, 0 for the first row).
+__device__ __forceinline__ uint32_t start_candidates(uint32_t row, uint32_t up) {
+    return row & ~(row << 1) & ~up & ~(up << 1) & ~(up >> 1) & 0xFFFFu;
 }
 
 // Straight runs.  After a step in an axis direction d the walk keeps going straight exactly
@@ -97,7 +78,9 @@ __device__ __forceinline__ int run_backward(uint32_t line, uint32_t side, int p)
 // icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border starting at (x0,y0).  The
 // 3-row window around the current pixel stays in registers; axis-aligned runs are jumped in one
 // go.  img = 16 row words, imgT = 16 column words (bit y of word x).  Returns the number of
-// points produced (stored only while they fit in cap), or -1 if the iteration guard tripped.
+// points produced (stored only while they fit in cap); 0 if the walk met a pixel that precedes
+// (x0,y0) in raster order, i.e. (x0,y0) is not the first pixel of its component and the border
+// belongs to another start (or is a hole border); -1 if the iteration guard tripped.
 __device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
     uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
     uint32_t nb = nb_mask(ra, rb, rc, x0);
@@ -145,6 +128,8 @@ __device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, in
         }
         // a run that ends on the start pixel, moving opposite to the first step, closes the border
         if (x4 == x0 && y4 == y0 && s2 == (s ^ 4)) return n;
+        // run interiors lie between their end points in raster order, so testing end points suffices
+        if (y4 * 16 + x4 < y0 * 16 + x0) return 0;
         const uint32_t a = img[(y4 - 1) & 15], b = img[y4], c = img[(y4 + 1) & 15];
         ra = y4 > 0 ? a : 0u;
         rb = b;
@@ -294,6 +279,7 @@ __device__ inline int contour_vertices(const uint32_t* img, const uint32_t* imgT
                                        uint32_t* vrows) {
     const int n = trace_border(img, imgT, x0, y0, m.pts, m.cap);
     if (n < 0) return 2;
+    if (n == 0) return 0;
     if (n > m.cap) return 1;
     return approx_and_convex(m.pts, n, m.dst, m.stk, m.cap_stk, vrows) ? 0 : 1;
 }

@@ -61,9 +61,9 @@ inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 // dynamic-LDS carve-up of the transition kernel
 void layout_lds(Params& P, int want_slots) {
-    P.nslot = want_slots > 0 ? want_slots : 64;                       // outer borders traced per pass
+    P.nslot = want_slots > 0 ? want_slots : 64;                       // candidate starts traced per pass
     if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
-    if (P.nslot < 16) P.nslot = 16;                                   // one extraction round yields up to 16
+    if (P.nslot < 16) P.nslot = 16;
     P.slot_cap = 64;                                                  // <= 64: the cooperative path keeps a border in one register per lane
     P.slot_stk = 16;
     P.long_border = 8;
@@ -76,9 +76,9 @@ void layout_lds(Params& P, int want_slots) {
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
     P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
-    P.o_clist = off;     off += align16(P.nslot * 4);
+    P.o_clist = off;     off += 512;                                  // 256 candidate starts per (sub-)batch
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
-    P.o_red = off;       off += 256;
+    P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
     // and the candidate keys: the tile's float32 copy is written out before the slots reuse it
     int32_t scratch = P.nslot * P.slot_bytes;

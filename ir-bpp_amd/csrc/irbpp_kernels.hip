@@ -158,7 +158,8 @@ struct Lds {
     uint16_t* taskidx;      // [R][64] level code -> task index
     uint16_t* tasklist;     // [ntasks] rot<<8 | level code
     uint32_t* img;          // [16][16] level images of the current batch, one 16-bit row per word
-    uint32_t* clist;        // [nslot] outer borders to trace: image | x0<<8 | y0<<12
+    uint16_t* clist;        // [256] candidate starts of the image (sub-)batch: image | x0<<4 | y0<<8
+    uint16_t* cn;           // [nslot] point count of each traced border of the current pass
     uint32_t* vmask;
     unsigned char* scratch;
     double* redd;
@@ -174,7 +175,8 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.taskidx = (uint16_t*)(smem + P.o_taskidx);
     L.tasklist = (uint16_t*)(smem + P.o_tasklist);
     L.img = (uint32_t*)(smem + P.o_img);
-    L.clist = (uint32_t*)(smem + P.o_clist);
+    L.clist = (uint16_t*)(smem + P.o_clist);
+    L.cn = (uint16_t*)(smem + P.o_red + 256);
     L.vmask = (uint32_t*)(smem + P.o_vmask);
     L.scratch = smem + P.o_scratch;
     L.redd = (double*)(smem + P.o_red);
@@ -223,45 +225,50 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             }
         }
         __syncthreads();
-        uint32_t rem = base + g < ntasks ? (L.img[tid] & 0xFFFFu) : 0u;
-        // Alternate (a) component extraction -- every image gives up its raster-first remaining
-        // component per round, the start pixels go to the border list -- and (b) one lane per
-        // listed border: trace + approximate + convexity test, all lanes running the same code.
-        for (int guard = 0; guard < 4096; ++guard) {
-            const long long t_a = prof ? (long long)clock64() : 0;
-            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[10] = 0; L.redi[11] = 0; L.redi[12] = 0; }
-            __syncthreads();
-            for (int round = 0; round < 256; ++round) {
-                const int more = __syncthreads_or(rem != 0u);
-                if (!more || L.redi[10] + IMGS > P.nslot) break;
-                int x0, y0;
-                const bool got = component_start(rem, y, x0, y0);
-                if (got && y == y0) {
-                    const int idx = atomicAdd(&L.redi[10], 1);
-                    L.clist[idx] = (uint32_t)g | ((uint32_t)x0 << 8) | ((uint32_t)y0 << 12);
-                }
+        // (a) candidate starts: one thread per (image, row), pure bit operations.  The list holds
+        // CLIST entries; a batch with more candidates (pathological speckle) is walked one image at
+        // a time (an image has at most 64: every other pixel of every other row).
+        constexpr int CLIST = 256;
+        const uint32_t row_bits = base + g < ntasks ? (L.img[tid] & 0xFFFFu) : 0u;
+        const uint32_t up_bits = (base + g < ntasks && y > 0) ? (L.img[tid - 1] & 0xFFFFu) : 0u;
+        const uint32_t my_cand = start_candidates(row_bits, up_bits);
+        const int batch_total = block_sum_int(__popc(my_cand), L.redi);
+        const int nsub = batch_total <= CLIST ? 1 : IMGS;
+        for (int sub = 0; sub < nsub; ++sub) {
+        __syncthreads();
+        if (tid == 0) L.redi[10] = 0;
+        __syncthreads();
+        if (nsub == 1 || g == sub) {
+            uint32_t cand = my_cand;
+            while (cand) {
+                const int x = __ffs((int)cand) - 1;
+                cand &= cand - 1u;
+                L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(g | (x << 4) | (y << 8));
             }
-            __syncthreads();
-            const int count = L.redi[10];
+        }
+        __syncthreads();
+        const int total = L.redi[10];
+        // (b) one lane per candidate, nslot per pass, all lanes running the same code
+        for (int c0 = 0; c0 < total; c0 += P.nslot) {
+            const int count = total - c0 < P.nslot ? total - c0 : P.nslot;
             const long long t_b = prof ? (long long)clock64() : 0;
-            if (prof && tid == 0) { prof[5] += t_b - t_a; prof[7] += count; }
-            if (count == 0) break;
-            // (b1) trace: one lane per listed border, all in lockstep (packed into the first wave)
+            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[11] = 0; L.redi[12] = 0; }
+            __syncthreads();
+            // (b1) trace; a candidate that is not the first pixel of its component returns 0 points
             uint8_t* llist = (uint8_t*)(L.redi + 32);            // borders too long for the lockstep DP
             int my_n = 0, my_r = 0;
             const SlotMem mine = carve_slot(L.scratch + tid * P.slot_bytes, P.slot_cap, P.slot_stk);
             if (tid < count) {
-                const uint32_t e = L.clist[tid];
-                const int gi = e & 255u;
+                const uint32_t e = L.clist[c0 + tid];
+                const int gi = e & 15u;
                 my_r = L.tasklist[base + gi] >> 8;
-                const int n = trace_border(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 8) & 15u, (e >> 12) & 15u,
+                const int n = trace_border(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 4) & 15u, (e >> 8) & 15u,
                                            mine.pts, mine.cap);
+                L.cn[tid] = (uint16_t)(n < 0 ? 0 : (n > 0xFFFF ? 0xFFFF : n));
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                 else if (n > mine.cap) atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
-                else if (n > P.long_border) {
-                    llist[atomicAdd(&L.redi[11], 1)] = (uint8_t)tid;
-                    L.clist[tid] = e | ((uint32_t)n << 16);
-                } else my_n = n;
+                else if (n > P.long_border) llist[atomicAdd(&L.redi[11], 1)] = (uint8_t)tid;
+                else my_n = n;
             }
             __syncthreads();
             // (b2) short borders: Douglas-Peucker + convexity per lane, still in lockstep
@@ -276,10 +283,9 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                     li = __shfl(li, 0);
                     if (li >= nlong) break;
                     const int c = llist[li];
-                    const uint32_t e = L.clist[c];
-                    const int r = L.tasklist[base + (e & 255u)] >> 8;
+                    const int r = L.tasklist[base + (L.clist[c0 + c] & 15u)] >> 8;
                     const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
-                    if (!approx_and_convex_wave(m.pts, (int)(e >> 16), L.vmask + r * 16) && (tid & 63) == 0)
+                    if (!approx_and_convex_wave(m.pts, (int)L.cn[c], L.vmask + r * 16) && (tid & 63) == 0)
                         atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
                 }
             }
@@ -294,18 +300,19 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                         const SlotMem m = carve_slot(L.scratch, cap, cap);
                         for (int c = 0; c < count; ++c) {
                             if (!((redo >> c) & 1ull)) continue;
-                            const uint32_t e = L.clist[c];
-                            const int gi = e & 255u;
+                            const uint32_t e = L.clist[c0 + c];
+                            const int gi = e & 15u;
                             const int r = L.tasklist[base + gi] >> 8;
-                            if (contour_vertices(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 8) & 15u, (e >> 12) & 15u, m,
-                                                 L.vmask + r * 16) != 0)
+                            if (contour_vertices(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 4) & 15u, (e >> 8) & 15u, m,
+                                                 L.vmask + r * 16) == 2)
                                 atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                         }
                     }
                     __syncthreads();
                 }
             }
-            if (prof && tid == 0) prof[6] += (long long)clock64() - t_b;
+            if (prof && tid == 0) { prof[6] += (long long)clock64() - t_b; prof[7] += count; }
+        }
         }
     }
 }
