@@ -137,6 +137,18 @@ int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev,
  * order of np.round(score, 6) with invalid cells at 1e6.  RANDOM is not provided. */
 int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int32_t* out_dev, void* stream);
 
+/* replaces: tools.shot_item (tools.py:98-135), the per-(shape, rotation) footprint precompute that
+ * shotInfoPre caches on disk (tools.py:248-279) -- trimesh ray casting in the reference, a
+ * z-ray/triangle rasteriser here.  Stateless.  verts_dev: float64[n_verts][3] of the mesh already
+ * rotated and translated to its bounding-box minimum; faces_dev: int32[n_faces][3]; ray (i, j)
+ * passes through (i*resolution_h + shift, j*resolution_h + shift) (shift = 0.001, tools.py:81-95).
+ * Outputs float64[fx][fy] each: heightMapT (highest hit), heightMapB (lowest hit), maskH, maskB;
+ * if no ray hits at all: T = extent_z, B = 0, masks 1 (tools.py:112-117,126-131).
+ * scratch_dev: one int32 of device memory. */
+int irbpp_shot_item(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, int32_t fx, int32_t fy,
+                    double resolution_h, double shift, double extent_z, double* top_dev, double* bottom_dev,
+                    double* mask_top_dev, double* mask_bottom_dev, int32_t* scratch_dev, void* stream);
+
 /* getConvexHullActions (cvTools.py:61-102) on caller-supplied grids, independent of the
  * environment state: posz_valid_dev float64[n_grids][n_rot][Ax][Ay], mask_dev
  * uint8[n_grids][n_rot][Ax][Ay].  vertex_rows_dev: uint32[n_grids][n_rot][16]; word `row` has

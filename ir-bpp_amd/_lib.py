@@ -42,6 +42,8 @@ SIGNATURES = {
     "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_possible_position": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_heuristic_action": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "irbpp_shot_item": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                  C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_convex_hull_actions": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_get_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -359,6 +359,22 @@ int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int3
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
+int irbpp_shot_item(const double* verts_dev, const int32_t* faces_dev, int32_t n_faces, int32_t fx, int32_t fy,
+                    double resolution_h, double shift, double extent_z, double* top_dev, double* bottom_dev,
+                    double* mask_top_dev, double* mask_bottom_dev, int32_t* scratch_dev, void* stream) {
+    if (!verts_dev || !faces_dev || n_faces < 1 || fx < 1 || fy < 1 || !top_dev || !bottom_dev || !mask_top_dev ||
+        !mask_bottom_dev || !scratch_dev)
+        return IRBPP_ERR_ARG;
+    HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(int32_t), (hipStream_t)stream));
+    const int n = fx * fy, grid = (n + 255) / 256;
+    hipLaunchKernelGGL(irbpp_shot_item_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, verts_dev, faces_dev,
+                       n_faces, fx, fy, resolution_h, shift, top_dev, bottom_dev, mask_top_dev, mask_bottom_dev,
+                       scratch_dev);
+    hipLaunchKernelGGL(irbpp_shot_item_fallback_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, n, extent_z,
+                       top_dev, bottom_dev, mask_top_dev, mask_bottom_dev, scratch_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
 int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev, const uint8_t* mask_dev,
                               uint32_t* vertex_rows_dev, void* stream) {
     if (!env || n_grids < 1 || !posz_valid_dev || !mask_dev || !vertex_rows_dev) return IRBPP_ERR_ARG;

@@ -825,6 +825,53 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     }
 }
 
+// shot_item (tools.py:98-135): footprint tables of one mesh by vertical ray casting.  The mesh is
+// already rotated and translated so that its bounding-box minimum sits at the origin; ray (i, j)
+// passes through (i*res + shift, j*res + shift).  One thread per ray, all triangles per thread:
+// the bottom table is the lowest intersection, the top table the highest, masks flag a hit.
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_shot_item_kernel(const double* verts, const int32_t* faces, int n_faces, int fx, int fy, double res, double shift,
+                       double* top, double* bottom, double* mtop, double* mbot, int32_t* any_hit) {
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= fx * fy) return;
+    const double px = (double)(c / fy) * res + shift, py = (double)(c % fy) * res + shift;
+    double zmin = 1e300, zmax = -1e300;
+    bool hit = false;
+    for (int f = 0; f < n_faces; ++f) {
+        const double* a = verts + 3 * faces[3 * f + 0];
+        const double* b = verts + 3 * faces[3 * f + 1];
+        const double* d = verts + 3 * faces[3 * f + 2];
+        const double area = (b[0] - a[0]) * (d[1] - a[1]) - (b[1] - a[1]) * (d[0] - a[0]);
+        if (area == 0.0) continue;                              // edge-on triangle: a vertical ray cannot cross it
+        const double w0 = (b[0] - px) * (d[1] - py) - (b[1] - py) * (d[0] - px);
+        const double w1 = (d[0] - px) * (a[1] - py) - (d[1] - py) * (a[0] - px);
+        const double w2 = (a[0] - px) * (b[1] - py) - (a[1] - py) * (b[0] - px);
+        const bool inside = area > 0.0 ? (w0 >= 0.0 && w1 >= 0.0 && w2 >= 0.0) : (w0 <= 0.0 && w1 <= 0.0 && w2 <= 0.0);
+        if (!inside) continue;
+        const double z = (a[2] == b[2] && b[2] == d[2]) ? a[2] : (w0 * a[2] + w1 * b[2] + w2 * d[2]) / area;
+        zmin = fmin(zmin, z);
+        zmax = fmax(zmax, z);
+        hit = true;
+    }
+    top[c] = hit ? zmax : 0.0;
+    bottom[c] = hit ? zmin : 0.0;
+    mtop[c] = hit ? 1.0 : 0.0;
+    mbot[c] = hit ? 1.0 : 0.0;
+    if (hit) atomicOr(any_hit, 1);
+}
+
+// the no-hit-at-all fallback of shot_item (tools.py:112-117,126-131)
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_shot_item_fallback_kernel(int n, double extent_z, double* top, double* bottom, double* mtop, double* mbot,
+                                const int32_t* any_hit) {
+    const int c = blockIdx.x * BLOCK + threadIdx.x;
+    if (c >= n || *any_hit) return;
+    top[c] = extent_z;
+    bottom[c] = 0.0;
+    mtop[c] = 1.0;
+    mbot[c] = 1.0;
+}
+
 // getConvexHullActions on caller-supplied grids (parity tests of the contour stage).
 extern "C" __global__ void __launch_bounds__(BLOCK)
 irbpp_hull_kernel(const Params P, const State S, const double* posz_valid, const uint8_t* mask,

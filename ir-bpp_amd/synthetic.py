@@ -134,13 +134,17 @@ def _all_rotations(ext0, tab0: Table, n_rot: int, res_h: float):
     return exts, tabs
 
 
+def blockout_voxels(n_shapes: int = 64, seed: int = 0) -> List[np.ndarray]:
+    """The voxel occupancies behind ``blockout_shapes`` (same seed -> same polycubes)."""
+    rng = np.random.RandomState(seed)
+    return [_grow_polycube(rng, int(rng.randint(2, 6))) for _ in range(n_shapes)]
+
+
 def blockout_shapes(n_shapes: int = 64, res_h: float = 0.01, n_rot: int = 4,
                     cube: float = 0.04, seed: int = 0) -> ShapeSet:
     """Polycubes of 2-5 face-connected 4 cm cubes ('BlockOut'-like, README.md:33)."""
-    rng = np.random.RandomState(seed)
     extents, volumes, tables = [], [], []
-    for _ in range(n_shapes):
-        occ = _grow_polycube(rng, int(rng.randint(2, 6)))
+    for occ in blockout_voxels(n_shapes, seed):
         ext0, tab0 = _voxel_tables(occ, cube, res_h)
         e, t = _all_rotations(ext0, tab0, n_rot, res_h)
         extents.append(e)

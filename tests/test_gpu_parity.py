@@ -352,3 +352,43 @@ def test_batched_evaluation_matches_sequential_reference_protocol():
             np.testing.assert_allclose(got[2], [lx * 0.02, ly * 0.02, height], rtol=0, atol=1e-12)
             np.testing.assert_array_equal(got[3], rotation_quaternion_xyzw(rot))
     assert abs(out["mean_ratio"] - np.mean(out["ratio"])) < 1e-15
+
+
+def test_shot_item_rasteriser_matches_oracle_and_analytic_tables():
+    """tools.shot_item (tools.py:98-135) on the GPU: boxes and polycube meshes reproduce the
+    analytic tables of the synthetic generators exactly; a slanted solid matches the numpy oracle."""
+    from irbpp_amd import meshes
+    from oracle.shot import shot_item
+    # boxes (Cube dataset)
+    cube = synthetic.cube_shapes()
+    for k in (0, 37, 124):
+        ex, ey, ez = cube.extents[k, 0]
+        ss = meshes.shape_set_from_meshes([meshes.box_mesh(ex, ey, ez)], 2, 0.01, DEV)
+        for r in range(2):
+            np.testing.assert_array_equal(ss.extents[0, r], cube.extents[k, r])
+            for got, ref in zip(ss.tables[0][r], cube.tables[k][r]):
+                np.testing.assert_array_equal(got, ref)
+        assert abs(ss.volumes[0] - cube.volumes[k]) < 1e-15
+    # polycubes (BlockOut dataset), all four lattice rotations
+    blk = synthetic.blockout_shapes(n_shapes=10, n_rot=4, seed=0)
+    ms = [meshes.voxel_mesh(o, 0.04) for o in synthetic.blockout_voxels(10, 0)]
+    ss = meshes.shape_set_from_meshes(ms, 4, 0.01, DEV)
+    np.testing.assert_allclose(ss.extents, blk.extents, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(ss.volumes, blk.volumes, rtol=0, atol=1e-15)
+    for k in range(10):
+        for r in range(4):
+            for got, ref in zip(ss.tables[k][r], blk.tables[k][r]):
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-15)
+    # a slanted solid: skewed pyramid frustum, 45-degree pose included
+    rng = np.random.RandomState(2)
+    base = np.array([[0, 0, 0], [0.11, 0, 0.01], [0.12, 0.09, 0], [0.01, 0.1, 0.02]])
+    apex = np.array([0.05, 0.04, 0.13])
+    v = np.vstack([base, apex])
+    f = np.array([[0, 2, 1], [0, 3, 2], [0, 1, 4], [1, 2, 4], [2, 3, 4], [3, 0, 4]], dtype=np.int32)
+    for deg in (0.0, 45.0):
+        vr = meshes.rotate_z(v, deg)
+        ext, tab = meshes.shot_item_gpu(vr, f, 0.01, DEV)
+        ref = shot_item(vr - vr.min(0), f, 0.01)
+        for got, want in zip(tab, ref):
+            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
+        assert tab[2].sum() > 20 and (tab[0] >= tab[1]).all()
