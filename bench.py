@@ -92,13 +92,16 @@ def usable_cores():
 
 def _cpu_worker(args):
     """One OS process = one bin, like wrapper/shmem_vec_env.py:120-157.  Runs for a fixed wall time."""
-    name, rank, seconds = args
+    name, rank, seconds, impl = args
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
         os.environ[var] = "1"
     sys.path.insert(0, ROOT)
-    from oracle.packing import OracleVecEnv
     shapes, seqs, kw = make_workload(name)
-    env = OracleVecEnv(1, shapes, seqs, global_offset=rank, global_num=1 << 20, **kw)
+    if impl == "c":
+        from oracle.c_oracle import COracleVecEnv as Env
+    else:
+        from oracle.packing import OracleVecEnv as Env
+    env = Env(1, shapes, seqs, global_offset=rank, global_num=1 << 20, **kw)
     obs = env.reset()
 
     def minz(o):
@@ -115,15 +118,22 @@ def _cpu_worker(args):
 
 
 def cpu_baseline(name, budget_s=15.0):
+    """The oracle on the host cores, one process per bin: the plain-C restatement (the fair CPU
+    number) and, for reference, the numpy/python one (what the reference's own Python costs)."""
     cores = usable_cores()
     ctx = mp.get_context("fork")
-    with ctx.Pool(cores) as pool:
-        res = pool.map(_cpu_worker, [(name, r, budget_s) for r in range(cores)])
-    rate = sum(n / t for n, t in res)
+    out = {}
+    for impl, secs in (("c", budget_s * 0.6), ("python", budget_s * 0.4)):
+        with ctx.Pool(cores) as pool:
+            res = pool.map(_cpu_worker, [(name, r, secs, impl) for r in range(cores)])
+        out[impl] = (sum(n / t for n, t in res), sum(n for n, _ in res), secs)
+    rate, steps, secs = out["c"]
     return {"value": rate, "unit": "placement-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x 1 bin x {budget_s:.0f} s of the python/numpy oracle, "
-                      f"{sum(n for n, _ in res)} steps in total (process-per-bin like shmem_vec_env; "
-                      f"no physics, which flatters the CPU side)"}
+            "sample": f"{cores} processes x 1 bin x {secs:.0f} s of the plain-C oracle (oracle/c/), {steps} steps in "
+                      f"total, scripted MINZ policy in numpy (process-per-bin like shmem_vec_env; no physics, "
+                      f"which flatters the CPU side)",
+            "python_port": {"value": out["python"][0], "sample": f"same, numpy/python oracle, {out['python'][2]:.0f} s, "
+                                                                 f"{out['python'][1]} steps"}}
 
 
 def main():

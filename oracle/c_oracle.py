@@ -1,0 +1,149 @@
+"""ORACLE (test infrastructure) -- ctypes front end of the plain-C restatement (oracle/c/).
+
+``COracleVecEnv`` has the interface of ``oracle.packing.OracleVecEnv`` and must agree with it
+bit for bit (tests/test_c_oracle.py); it is ~100x faster, which makes large parity runs and a
+fair CPU baseline possible.  Build with ``make -C oracle`` (done by __graft_entry__.build()).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "_ref", "libirbpp_oracle.so")
+_lib = None
+_f64 = C.POINTER(C.c_double)
+_i32 = C.POINTER(C.c_int)
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(HERE, "c", "irbpp_oracle.c")):
+            subprocess.run(["make", "-C", HERE, "-s"], check=True)
+        lib = C.CDLL(LIB)
+        lib.orc_create.restype = C.c_void_p
+        lib.orc_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, _f64, C.c_double,
+                                   C.c_int, _f64, _f64, _i32, C.POINTER(C.c_int64), C.c_int64, _f64, _f64, _f64, _f64,
+                                   _i32, C.c_int, C.c_int, C.c_int, C.c_int]
+        lib.orc_destroy.argtypes = [C.c_void_p]
+        lib.orc_obs_len.argtypes = [C.c_void_p, C.c_int]
+        lib.orc_reset.argtypes = [C.c_void_p, _f64]
+        lib.orc_get_action_candidates.argtypes = [C.c_void_p, C.c_int, _f64]
+        lib.orc_step.argtypes = [C.c_void_p, C.c_int, _f64, _f64, _i32, _f64]
+        lib.orc_step.restype = C.c_int
+        lib.orc_get_grids.argtypes = [C.c_void_p, _f64, _f64]
+        lib.orc_get_heightmap.argtypes = [C.c_void_p, _f64]
+        lib.orc_set_heightmap.argtypes = [C.c_void_p, _f64]
+        _lib = lib
+    return _lib
+
+
+def _pack(shapes):
+    n, R = shapes.n_shapes, shapes.n_rot
+    dims = np.zeros((n, R, 2), dtype=np.int32)
+    offs = np.zeros((n, R), dtype=np.int64)
+    pools = [[], [], [], []]
+    pos = 0
+    for k in range(n):
+        for r in range(R):
+            dims[k, r] = shapes.tables[k][r][0].shape
+            offs[k, r] = pos
+            pos += shapes.tables[k][r][0].size
+            for pool, arr in zip(pools, shapes.tables[k][r]):
+                pool.append(np.ascontiguousarray(arr, dtype=np.float64).reshape(-1))
+    return dims, offs, pos, [np.concatenate(p) for p in pools]
+
+
+class CPackingGame(object):
+    def __init__(self, shapes, sequences, resolutionA=0.02, resolutionH=0.01, resolutionZ=0.01,
+                 bin_dimension=(0.32, 0.32, 0.30), selectedAction=500, bufferSize=1, scale_z=100.0,
+                 first_traj=1, traj_stride=1):
+        self.lib = load()
+        dims, offs, plen, (T, B, mH, mB) = _pack(shapes)
+        binr = np.round(np.asarray(bin_dimension, dtype=np.float64), 6)
+        ext = np.ascontiguousarray(shapes.extents, dtype=np.float64)
+        vol = np.ascontiguousarray(shapes.volumes, dtype=np.float64)
+        seq = np.ascontiguousarray(sequences, dtype=np.int32)
+        p = lambda a: a.ctypes.data_as(_f64)   # noqa: E731
+        self.h = C.c_void_p(self.lib.orc_create(
+            shapes.n_rot, selectedAction, bufferSize, resolutionA, resolutionH, resolutionZ, p(binr), scale_z,
+            shapes.n_shapes, p(ext), p(vol), dims.ctypes.data_as(_i32), offs.ctypes.data_as(C.POINTER(C.c_int64)),
+            plen, p(T), p(B), p(mH), p(mB), seq.ctypes.data_as(_i32), seq.shape[0], seq.shape[1], first_traj, traj_stride))
+        self.obs_len = self.lib.orc_obs_len(self.h, 0)
+        self.loc_obs_len = self.lib.orc_obs_len(self.h, 1)
+        self.n_rot = shapes.n_rot
+        self.Hx = int(np.ceil(binr[0] / resolutionH)); self.Hy = int(np.ceil(binr[1] / resolutionH))
+        self.Ax = int(np.ceil(binr[0] / resolutionA)); self.Ay = int(np.ceil(binr[1] / resolutionA))
+
+    def reset(self):
+        obs = np.empty(self.obs_len)
+        self.lib.orc_reset(self.h, obs.ctypes.data_as(_f64))
+        return obs
+
+    def get_action_candidates(self, order_action):
+        obs = np.empty(self.loc_obs_len)
+        self.lib.orc_get_action_candidates(self.h, int(order_action), obs.ctypes.data_as(_f64))
+        return obs
+
+    def step(self, action):
+        obs = np.empty(self.obs_len)
+        rew, ratio, counter = C.c_double(), C.c_double(), C.c_int()
+        done = self.lib.orc_step(self.h, int(action), obs.ctypes.data_as(_f64), C.byref(rew), C.byref(counter), C.byref(ratio))
+        info = {"Valid": True}
+        if done:
+            info = {"counter": counter.value, "ratio": ratio.value, "Valid": True}
+        return obs, rew.value, bool(done), info
+
+    def grids(self):
+        n = self.n_rot * self.Ax * self.Ay
+        pz, mk = np.empty(n), np.empty(n)
+        self.lib.orc_get_grids(self.h, pz.ctypes.data_as(_f64), mk.ctypes.data_as(_f64))
+        return pz.reshape(self.n_rot, self.Ax, self.Ay), mk.reshape(self.n_rot, self.Ax, self.Ay)
+
+    def heightmap(self):
+        hm = np.empty(self.Hx * self.Hy)
+        self.lib.orc_get_heightmap(self.h, hm.ctypes.data_as(_f64))
+        return hm.reshape(self.Hx, self.Hy)
+
+    def set_heightmap(self, hm):
+        hm = np.ascontiguousarray(hm, dtype=np.float64)
+        self.lib.orc_set_heightmap(self.h, hm.ctypes.data_as(_f64))
+
+    def __del__(self):
+        try:
+            self.lib.orc_destroy(self.h)
+        except Exception:
+            pass
+
+
+class COracleVecEnv(object):
+    """Same protocol as oracle.packing.OracleVecEnv (auto-reset + Monitor episode info)."""
+
+    def __init__(self, num_envs, shapes, sequences, traj_start=1, global_offset=0, global_num=None, **kw):
+        global_num = num_envs if global_num is None else global_num
+        self.envs = [CPackingGame(shapes, sequences, first_traj=traj_start + global_offset + g,
+                                  traj_stride=global_num, **kw) for g in range(num_envs)]
+        self.num_envs = num_envs
+        self.obs_len = self.envs[0].obs_len
+        self.rewards = [[] for _ in range(num_envs)]
+
+    def reset(self):
+        self.rewards = [[] for _ in range(self.num_envs)]
+        return np.array([e.reset() for e in self.envs])
+
+    def get_action_candidates(self, order_actions):
+        return np.array([e.get_action_candidates(int(a)) for e, a in zip(self.envs, order_actions)])
+
+    def step(self, actions):
+        obs, rews, dones, infos = [], [], [], []
+        for i, (e, a) in enumerate(zip(self.envs, actions)):
+            o, r, d, info = e.step(int(a))
+            self.rewards[i].append(r)
+            if d:
+                info["episode"] = {"r": round(sum(self.rewards[i]), 6), "l": len(self.rewards[i])}
+                self.rewards[i] = []
+                o = e.reset()
+            obs.append(o); rews.append(r); dones.append(d); infos.append(info)
+        return np.array(obs), np.array(rews), np.array(dones), infos

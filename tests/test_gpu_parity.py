@@ -392,3 +392,53 @@ def test_shot_item_rasteriser_matches_oracle_and_analytic_tables():
         for got, want in zip(tab, ref):
             np.testing.assert_allclose(got, want, rtol=0, atol=1e-12)
         assert tab[2].sum() > 20 and (tab[0] >= tab[1]).all()
+
+
+def test_make_vec_envs_with_reference_style_args():
+    """envs.make_vec_envs (envs.py:67-99): same call shape, same return triple, reference containers."""
+    import types
+    from irbpp_amd.vec_env import make_vec_envs
+    sh = synthetic.cube_shapes()
+    args = types.SimpleNamespace(
+        num_processes=5, device=0, shotInfo=sh.shot_info(), infoDict=sh.info_dict(), resolutionA=0.02,
+        resolutionH=0.01, resolutionZ=0.01, bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=500,
+        bufferSize=1, scale=[100, 100, 100], sequences=synthetic.make_sequences(sh.n_shapes, 32, 60, seed=123))
+    envs, spaces, obs_len = make_vec_envs(args, "./logs/runinfo", True)
+    assert obs_len == 5 * 500 + 9 + 1024 and envs.num_envs == 5
+    assert spaces[0].shape == (obs_len,) and spaces[1].n == 500
+    oenv = OracleVecEnv(5, sh, args.sequences)
+    obs = envs.reset()
+    assert obs.dtype == torch.float32 and obs.is_cuda and tuple(obs.shape) == (5, obs_len)
+    np.testing.assert_array_equal(obs.cpu().numpy(), _f32(oenv.reset()))
+    act = envs.env.policy_minz(obs).cpu().numpy()
+    envs.step_async(act)
+    with pytest.raises(RuntimeError):
+        envs.step_async(act)                      # one outstanding step (shmem_vec_env.py:58-74)
+    obs, rew, done, infos = envs.step_wait()
+    o2, r2, d2, i2 = oenv.step(act)
+    np.testing.assert_array_equal(obs.cpu().numpy(), _f32(o2))
+    assert rew.dtype == torch.float32 and tuple(rew.shape) == (5, 1) and not rew.is_cuda
+    assert done.dtype == bool and len(infos) == 5 and all(infos[i]["Valid"] for i in range(5))
+    envs.close()
+
+
+def test_abi_rejects_calls_out_of_order():
+    """Error behaviour of the boundary: status codes instead of crashes."""
+    import ctypes as C
+    from irbpp_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.IrbppConfig(num_bins=2, n_rot=2, selected=500, buffer_size=1, resolution_a=0.02, resolution_h=0.01,
+                           resolution_z=0.01, bin=(C.c_double * 3)(0.32, 0.32, 0.3), scale_z=100.0, traj_start=1,
+                           global_offset=0, global_bins=2, device=0, contour_slots=0)
+    h = C.c_void_p()
+    assert lib.irbpp_create(C.byref(cfg), C.byref(h)) == 0
+    obs = torch.zeros((2, 3533), dtype=torch.float32, device=DEV)
+    act = torch.zeros((2,), dtype=torch.int32, device=DEV)
+    p = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+    assert lib.irbpp_reset(h, p(obs), None) == -3                 # IRBPP_ERR_STATE: nothing loaded yet
+    assert lib.irbpp_step(h, p(act), p(obs), None, None) == -3    # step before reset
+    assert lib.irbpp_get_action_candidates(h, p(act), p(obs), None) == -3
+    assert lib.irbpp_reset(h, None, None) == -1                   # IRBPP_ERR_ARG
+    bad = np.zeros(4, dtype=np.int32)
+    assert lib.irbpp_load_sequences(h, bad.ctypes.data_as(_lib.c_i32_p), 0, 4) == -1
+    assert lib.irbpp_destroy(h) == 0

@@ -1,0 +1,29 @@
+#!/usr/bin/env python
+"""Tooling: placement-steps/s through the reference-compatible VecEnv surface, i.e. the way
+trainer.py drives it (trainer.py:161-186): device policy -> action.cpu().numpy() -> envs.step() ->
+(obs on device, reward CPU tensor, done numpy, infos) with every info dict touched.  This is the
+PCIe/host-inclusive rate; bench.py's `value` keeps everything on the device."""
+import json, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import irbpp_amd  # noqa
+from bench import make_workload
+from irbpp_amd.vec_env import GpuVecEnv
+
+bins = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+shapes, seqs, kw = make_workload("blockout")
+envs = GpuVecEnv(shapes, seqs, bins, device="cuda:0", **kw)
+state = envs.reset()
+for _ in range(50):
+    action = envs.env.policy_minz(state)
+    state, reward, done, infos = envs.step(action.cpu().numpy())
+torch.cuda.synchronize(); t = time.perf_counter(); K = 100; finished = 0
+for _ in range(K):
+    mask = state[:, :2500].reshape(-1, 500, 5)[:, :, -1]              # get_mask_from_state (tools.py:298-299)
+    action = envs.env.policy_minz(state)
+    state, reward, done, infos = envs.step(action.cpu().numpy())
+    for i in range(len(infos)):                                       # the trainer's per-env loop (trainer.py:167-178)
+        if done[i] and infos[i]["Valid"]:
+            finished += 1
+torch.cuda.synchronize(); dt = time.perf_counter() - t
+print(json.dumps({"bins": bins, "vecenv_steps_per_s": bins * K / dt, "ms_per_step": dt / K * 1e3, "episodes": finished}))
