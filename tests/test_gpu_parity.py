@@ -442,3 +442,33 @@ def test_abi_rejects_calls_out_of_order():
     bad = np.zeros(4, dtype=np.int32)
     assert lib.irbpp_load_sequences(h, bad.ctypes.data_as(_lib.c_i32_p), 0, 4) == -1
     assert lib.irbpp_destroy(h) == 0
+
+
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60)])
+def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
+    """Scale check made possible by the C oracle: the bench workloads themselves, hundreds of bins,
+    whole episodes including auto-resets; every observation, reward, done and episode info equal."""
+    from bench import make_workload
+    from oracle.c_oracle import COracleVecEnv
+    shapes, seqs, kw = make_workload(workload)
+    seqs = seqs[:2000]
+    genv = GpuVecEnv(shapes, seqs, n, device=DEV, **kw)
+    cenv = COracleVecEnv(n, shapes, seqs, **kw)
+    gobs = genv.reset()
+    np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cenv.reset()))
+    ndone = 0
+    for t in range(steps):
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        gobs, grew, gdone, ginfo = genv.step(act)
+        cobs, crew, cdone, cinfo = cenv.step(act)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cobs), err_msg=f"step {t}")
+        np.testing.assert_array_equal(gdone, cdone)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], crew.astype(np.float32))
+        for i in np.nonzero(cdone)[0]:
+            gi, ci = ginfo[int(i)], cinfo[int(i)]
+            assert gi["counter"] == ci["counter"] and gi["ratio"] == ci["ratio"]
+            assert gi["episode"]["r"] == ci["episode"]["r"] and gi["episode"]["l"] == ci["episode"]["l"]
+            ndone += 1
+    genv.env.check_device_error()
+    genv.close()
+    assert ndone >= n // 2
