@@ -32,22 +32,37 @@ def shard(rank: int, world: int, bins_per_rank: int):
     return {"global_offset": rank * bins_per_rank, "global_bins": world * bins_per_rank}
 
 
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
+    """all_reduce that also works for device tensors under the gloo backend (CPU tests, dry runs)."""
+    if dist.get_backend() == "gloo" and t.is_cuda:
+        c = t.cpu()
+        dist.all_reduce(c, op=op)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op)
+    return t
+
+
 def reduce_totals(totals: torch.Tensor) -> torch.Tensor:
     """Sum [episodes, sum ratio, sum counter, sum reward] over ranks (in place)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(totals, op=dist.ReduceOp.SUM)
+    if _active():
+        _all_reduce(totals, dist.ReduceOp.SUM)
     return totals
 
 
 def max_over_ranks(value: float, device) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if _active():
+        _all_reduce(t, dist.ReduceOp.MAX)
     return float(t.item())
 
 
 def barrier(device=None):
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
     if device is not None and torch.device(device).type == "cuda":
         torch.cuda.synchronize(device)
