@@ -65,10 +65,10 @@ void layout_lds(Params& P, int want_slots) {
     if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
     if (P.nslot < 16) P.nslot = 16;
     P.slot_cap = 64;                                                  // <= 64: the cooperative path keeps a border in one register per lane
-    P.slot_stk = 16;
+    P.slot_stk = 12;
     P.long_border = 8;
     if (const char* lb = getenv("IRBPP_LONG_BORDER")) P.long_border = atoi(lb);   // tuning knob
-    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 196 B = 49 dwords: odd stride, lanes hit distinct LDS banks
+    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 180 B = 45 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
     P.o_lev = off;       off += align16(P.R * P.AC);
@@ -77,6 +77,7 @@ void layout_lds(Params& P, int want_slots) {
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
     P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
     P.o_clist = off;     off += 512;                                  // 256 candidate starts per (sub-)batch
+    P.o_mb = off;        off += align16(P.mb_w * P.mb_h * 8);            // block-max grid (0 bytes on the generic path)
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
@@ -131,6 +132,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.res_a = cfg->resolution_a;
     P.res_h = cfg->resolution_h;
     P.res_z = cfg->resolution_z;
+    P.inv_res_z = 1.0 / cfg->resolution_z;
+    for (int k = 0; k < 16; ++k) P.txs[k] = round6_host((double)k * cfg->resolution_a);
     P.bin_x = cfg->bin[0];
     P.bin_y = cfg->bin[1];
     P.bin_z = cfg->bin[2];
@@ -153,7 +156,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
     P.obs_len1 = 5 * P.S + 9 + P.Hc;
     P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
-    layout_lds(P, cfg->contour_slots);
+    layout_lds(P, cfg->contour_slots);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
@@ -204,7 +207,33 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     HIP_TRY(hipSetDevice(env->cfg.device));
     const int R = P.R;
     std::vector<ShapeRot> sr((size_t)n_shapes * R);
-    std::vector<Cell> bcell, tcell;
+    std::vector<Cell> bcell, tcell, blkcell;
+    // Block path: the largest b (multiple of step, <= 8) such that every footprint of the dataset is a
+    // union of b x b tiles that are fully masked out or fully masked in with one bottom height.
+    int block_b = 0;
+    if (!getenv("IRBPP_NO_BLOCKS")) {
+        for (int b = 8; b >= 2 && block_b == 0; --b) {
+            if (b % P.step != 0 || (P.Hx - b) % P.step != 0 || (P.Hy - b) % P.step != 0) continue;
+            bool ok = true;
+            for (int64_t i = 0; i < (int64_t)n_shapes * R && ok; ++i) {
+                const int fx = dims[i * 2], fy = dims[i * 2 + 1];
+                if (fx % b != 0 || fy % b != 0) { ok = false; break; }
+                for (int ti = 0; ti < fx / b && ok; ++ti)
+                    for (int tj = 0; tj < fy / b && ok; ++tj) {
+                        const int64_t e0 = offsets[i] + (int64_t)(ti * b) * fy + tj * b;
+                        for (int u = 0; u < b && ok; ++u)
+                            for (int v = 0; v < b && ok; ++v) {
+                                const int64_t e = offsets[i] + (int64_t)(ti * b + u) * fy + tj * b + v;
+                                if (mask_bottom[e] != mask_bottom[e0] ||
+                                    (mask_bottom[e0] != 0.0 && height_bottom[e] != height_bottom[e0]))
+                                    ok = false;
+                            }
+                    }
+            }
+            if (ok) block_b = b;
+        }
+    }
+    const int mb_h = block_b ? (P.Hx - block_b) / P.step + 1 : 0, mb_w = block_b ? (P.Hy - block_b) / P.step + 1 : 0;
     for (int k = 0; k < n_shapes; ++k) {
         for (int r = 0; r < R; ++r) {
             const size_t i = (size_t)k * R + r;
@@ -240,18 +269,40 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             }
             s.nb = (int32_t)bcell.size() - s.ob;
             s.nt = (int32_t)tcell.size() - s.ot;
+            s.oblk = (int32_t)blkcell.size();
+            if (block_b)
+                for (int ti = 0; ti < s.fx / block_b; ++ti)
+                    for (int tj = 0; tj < s.fy / block_b; ++tj) {
+                        const int64_t e0 = off + (int64_t)(ti * block_b) * s.fy + tj * block_b;
+                        if (mask_bottom[e0] != 0.0)
+                            blkcell.push_back(Cell{height_bottom[e0], (ti * block_b / P.step) * mb_w + tj * block_b / P.step, 0});
+                    }
+            s.nblk = (int32_t)blkcell.size() - s.oblk;
             if (s.nb == 0 && !s.has_out) return IRBPP_ERR_ARG;
         }
     }
     if (bcell.empty()) bcell.push_back(Cell{0.0, 0, 0});
     if (tcell.empty()) tcell.push_back(Cell{0.0, 0, 0});
+    if (blkcell.empty()) blkcell.push_back(Cell{0.0, 0, 0});
     Tables& T = env->T;
     int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.bcell, (const Cell*)bcell.data(), bcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.tcell, (const Cell*)tcell.data(), tcell.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.blkcell, (const Cell*)blkcell.data(), blkcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
     T.n_shapes = n_shapes;
+    if (block_b) {                               // switch the overlap test to the block path
+        env->P.block_b = block_b;
+        env->P.mb_h = mb_h;
+        env->P.mb_w = mb_w;
+        layout_lds(env->P, env->cfg.contour_slots);
+        if (env->P.lds_bytes > 160 * 1024) return IRBPP_ERR_ARG;
+        if (hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess)
+            return IRBPP_ERR_HIP;
+    }
     env->shapes_loaded = true;
     return IRBPP_OK;
 }

@@ -21,6 +21,7 @@ struct ShapeRot {
     int32_t ob, ot;        // offsets of this (shape, rot) in the bottom / top cell lists
     int32_t has_out;       // 1 iff some maskB==0 cell exists: the window max then includes (H-B)*0 = 0
     int32_t pad;
+    int32_t nblk, oblk;    // block list (Params.block_b > 0): uniform-bottom b x b tiles of the footprint
     double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
     double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
 };
@@ -40,6 +41,7 @@ struct Tables {
     const ShapeRot* sr;    // [n_shapes][R]
     const Cell* bcell;     // bottom cells (maskB == 1)
     const Cell* tcell;     // top cells    (maskH == 1)
+    const Cell* blkcell;   // bottom tiles (block path): v = the tile's heightMapB, off = offset into the block-max grid
     const double* volume;  // [n_shapes]
     const int32_t* seq;    // [n_traj][seq_len]
     int32_t n_shapes, n_traj, seq_len;
@@ -76,7 +78,8 @@ struct State {
 
 struct Params {
     int32_t N, Hx, Hy, Hc, Ax, Ay, AC, step, R, S, K;
-    double res_a, res_h, res_z;
+    double res_a, res_h, res_z, inv_res_z;
+    double txs[16];                // np.round(k * resolutionA, 6) for k = 0..15 (binPhy.py:236)
     double bin_x, bin_y, bin_z, bin_vol;
     double scale_z, ibin_z;        // Interface scale and round(bin_z*scale, 6)
     int32_t traj_start, goff, gbins;
@@ -85,6 +88,11 @@ struct Params {
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red;
     int32_t nslot, slot_cap, slot_stk, slot_bytes, scratch_bytes, lds_bytes;
     int32_t long_border;   // borders with more points than this use the wave-cooperative Douglas-Peucker
+    // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
+    // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid
+    // mb[pi][pj] = max of the b x b heightmap block at (pi*step, pj*step) replaces the cell list:
+    // max over the tile of (H - B) == (max over the tile of H) - B exactly (rounding is monotone).
+    int32_t block_b, mb_w, mb_h, o_mb;
 };
 
 enum Mode : int32_t {

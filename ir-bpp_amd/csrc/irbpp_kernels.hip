@@ -36,34 +36,24 @@ constexpr int WAVES = BLOCK / 64;
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
 
-// Exact C fmod(a, b) for b > 0 and |a/b| < 2^52 without ocml's generic loop: the true remainder
-// is always representable, so fma(-q, b, a) is exact once q is the truncated quotient; a/b is
-// correctly rounded, hence trunc(a/b) is off by at most one, which the sign/range test repairs.
-__device__ __forceinline__ double fmod_exact(double a, double b) {
+// Sign of np.round(x, 6) without the divide: rint(x*1e6)/1e6 has the sign (and zero-ness) of
+// rint(x*1e6), and float64 division is a quarter-rate multi-instruction sequence on CDNA.
+__device__ __forceinline__ double round6_scaled(double x) { return rint(x * 1e6); }
+
+// (int) np.floor_divide(a, b) for b > 0 (numpy npy_divmod on float64; decides which cells share a
+// height level, cvTools.py:78 -- e.g. 0.06 // 0.01 == 5) WITHOUT any division.  numpy computes
+// mod = fmod(a,b), div = (a-mod)/b [-1 if mod has the other sign], and rounds div to the nearest
+// integer: that integer is the exact quotient floor(a/b).  The exact quotient comes from a
+// reciprocal-multiply guess (off by at most one) corrected with the exact FMA remainder
+// (fmod's result is always representable, so fma(-q, b, |a|) is exact for the right q).
+__device__ __forceinline__ int np_floor_divide_int(double a, double b, double inv_b) {
     const double x = fabs(a);
-    double q = trunc(x / b);
+    double q = trunc(x * inv_b);
     double r = fma(-q, b, x);
     if (r < 0.0) { q -= 1.0; r = fma(-q, b, x); }
     else if (r >= b) { q += 1.0; r = fma(-q, b, x); }
-    return copysign(r, a);
-}
-
-// numpy floor_divide on float64 (npy_divmod): decides which cells share a height level
-// (cvTools.py:78), e.g. 0.06 // 0.01 == 5.
-__device__ inline double np_floor_divide(double a, double b) {
-    double mod = fmod_exact(a, b);
-    double div = (a - mod) / b;
-    if (mod != 0.0) {
-        if ((b < 0) != (mod < 0)) { mod += b; div -= 1.0; }
-    }
-    double fd;
-    if (div != 0.0) {
-        fd = floor(div);
-        if (div - fd > 0.5) fd += 1.0;
-    } else {
-        fd = copysign(0.0, a / b);
-    }
-    return fd;
+    if (!(a < 0.0)) return (int)q;
+    return r == 0.0 ? -(int)q : -(int)q - 1;
 }
 
 __device__ inline double block_max_f64(double v, double* red) {
@@ -152,6 +142,7 @@ __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) 
 
 struct Lds {
     double* hm;
+    double* mb;             // block-max grid of the tile (block path of the overlap test)
     double* posz;
     uint8_t* lev;
     unsigned long long* present;
@@ -169,6 +160,7 @@ struct Lds {
 __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     Lds L;
     L.hm = (double*)(smem + P.o_hm);
+    L.mb = (double*)(smem + P.o_mb);
     L.posz = (double*)(smem + P.o_posz);
     L.lev = smem + P.o_lev;
     L.present = (unsigned long long*)(smem + P.o_present);
@@ -210,19 +202,36 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's image g
     constexpr int IMGS = BLOCK / 16;                 // 16 level images per batch
     for (int base = 0; base < ntasks; base += IMGS) {
-        for (int i = tid; i < 2 * IMGS * 16; i += BLOCK) L.img[i] = 0u;       // rows, then transposed columns
+        for (int i = tid; i < IMGS * 16; i += BLOCK) L.img[i] = 0u;           // rows (the column copy is derived below)
         __syncthreads();
-        if (tid < AC) {
-            for (int r = 0; r < R; ++r) {
-                const int code = L.lev[r * AC + tid];
-                if (code != 255) {
-                    const int ti = (int)L.taskidx[r * 64 + code] - base;
-                    if (ti >= 0 && ti < IMGS) {
-                        atomicOr(&L.img[ti * 16 + X], 1u << Y);                    // row X, bit Y
-                        atomicOr(&L.img[(IMGS + ti) * 16 + Y], 1u << X);           // column Y, bit X
-                    }
+        // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
+        // lanes of a lane group are the 16 columns of row X, and the ballot of "my cell belongs to
+        // image ti" IS that row of the image.  Only this lane group ever writes word (ti, X).
+        for (int r = 0; r < R; ++r) {
+            const int code = tid < AC ? (int)L.lev[r * AC + tid] : 255;
+            int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
+            if (ti >= IMGS) ti = -1;
+            if (P.Ay != 16) {                    // lane groups are not image rows: plain LDS atomics
+                if (ti >= 0) atomicOr(&L.img[ti * 16 + X], 1u << Y);
+                continue;
+            }
+            unsigned long long todo = __ballot(ti >= 0);
+            while (todo) {
+                const int t0 = __builtin_amdgcn_readlane(ti, __ffsll((long long)todo) - 1);
+                const unsigned long long bal = __ballot(ti == t0);
+                todo &= ~bal;
+                if ((tid & 15) == 0) {
+                    const uint32_t rowbits = (uint32_t)(bal >> (tid & 48)) & 0xFFFFu;
+                    if (rowbits) L.img[t0 * 16 + X] = rowbits;
                 }
             }
+        }
+        __syncthreads();
+        // transposed copy (column words) for the vertical run jumps: thread (g, y) gathers column y
+        {
+            uint32_t col = 0u;
+            for (int k = 0; k < 16; ++k) col |= ((L.img[g * 16 + k] >> y) & 1u) << k;
+            L.img[(IMGS + g) * 16 + y] = col;
         }
         __syncthreads();
         // (a) candidate starts: one thread per (image, row), pure bit operations.  The list holds
@@ -390,62 +399,123 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = tid / Ay, Y = tid % Ay;
+    constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
+    // All R ShapeRots of the item in ONE coalesced load into LDS (the scratch region is free while the
+    // tile is in use only if it does not alias it -- it does, so they go to the front of L.posz's
+    // last rotation slab, which is written only at the very end of this function for r = R-1).
+    int* srw = (int*)(L.lev);                                // R*AC bytes >= R*72: lev is written after the loops read sr
+    if (item >= 0)
+        for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
     for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
+    if (P.block_b > 0) {                         // block-max grid of the current tile, plane offsets built incrementally
+        for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
+            const int pi = t / P.mb_w, pj = t - pi * P.mb_w;
+            const double* base = L.hm + pi * Ay + pj;
+            double m = -1e300;
+            int ri = 0, xi = 0;
+            for (int i = 0; i < P.block_b; ++i) {
+                int rj = 0, yj = 0;
+                for (int j = 0; j < P.block_b; ++j) {
+                    m = fmax(m, base[(ri * P.step + rj) * AC + xi * Ay + yj]);
+                    if (++rj == P.step) { rj = 0; ++yj; }
+                }
+                if (++ri == P.step) { ri = 0; ++xi; }
+            }
+            L.mb[t] = m;
+        }
+    }
     __syncthreads();
 
     // ---- Space.get_possible_position (space.py:98-129): one action cell per lane -------
+    const bool blocks = P.block_b > 0;
+    const int lane = tid & 63;
     int my_valid = 0;
-    for (int r = 0; r < R; ++r) {
-        double z = 1e3;
-        bool valid = false;
-        if (item >= 0) {
-            const ShapeRot sr = T.sr[item * R + r];
-            const bool in_range = tid < AC && X <= Ax - sr.ax && Y <= Ay - sr.ay;
-            const double* h0 = L.hm + X * Ay + Y;
-            double m = sr.has_out ? 0.0 : -1e300;
-            // The footprint list is fetched 64 cells at a time, one 16-byte cell per lane (a
-            // coalesced vector load), and broadcast cell by cell with v_readlane: the loop then has
-            // only LDS reads in flight, which the hardware returns in order and the compiler can
-            // pipeline (scalar loads would share lgkmcnt with the LDS reads and force full drains).
-            const Cell* cells = T.bcell + sr.ob;
-            const int lane = tid & 63;
-            for (int base = 0; base < sr.nb; base += 64) {
-                const int idx = base + lane < sr.nb ? base + lane : sr.nb - 1;
-                const Cell c = cells[idx];
-                const int cnt = sr.nb - base < 64 ? sr.nb - base : 64;
-                int c_off = c.off;
-                int c_lo = (int)__double2loint(c.v), c_hi = (int)__double2hiint(c.v);
-                // every lane must really hold its cell (v_readlane reads lanes that are masked off
-                // below): keep the compiler from sinking the load into the in_range branch
-                asm volatile("" : "+v"(c_off), "+v"(c_lo), "+v"(c_hi));
-                if (in_range) {
-                    int u = 0;
-                    for (; u + 8 <= cnt; u += 8) {                  // 8 LDS reads in flight per trip
-                        double hv[8], vv[8];
+    // per-rotation results are kept in registers until all rotations have read their ShapeRot from
+    // the LDS staging area (which shares memory with L.lev)
+    double zs[8];
+    bool vs[8];
+    int level_code[8];
+    int ncell_next = 0, off_next = 0;
+    Cell pre = {};                                           // first cell chunk of the next rotation, in flight
+    if (item >= 0) {
+        const ShapeRot* s0 = (const ShapeRot*)srw;
+        ncell_next = __builtin_amdgcn_readfirstlane(blocks ? s0->nblk : s0->nb);
+        off_next = __builtin_amdgcn_readfirstlane(blocks ? s0->oblk : s0->ob);
+        const Cell* c0 = (blocks ? T.blkcell : T.bcell) + off_next;
+        if (ncell_next > 0) pre = c0[lane < ncell_next ? lane : ncell_next - 1];
+    }
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) {
-                            const int off = __builtin_amdgcn_readlane(c_off, u + k);
-                            vv[k] = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u + k),
-                                                     __builtin_amdgcn_readlane(c_lo, u + k));
-                            hv[k] = h0[off];
-                        }
+    for (int r = 0; r < 8; ++r) {
+        zs[r] = 1e3;
+        vs[r] = false;
+        level_code[r] = 255;
+        if (r >= R || item < 0) continue;
+        const ShapeRot* sp = (const ShapeRot*)srw + r;
+        const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
+        const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
+        const double ext_z_r = sp->ext_z_r;
+        const int ncell = ncell_next, off0 = off_next;
+        Cell c = pre;
+        if (r + 1 < R) {                                     // issue the next rotation's first chunk now
+            const ShapeRot* sn = sp + 1;
+            ncell_next = __builtin_amdgcn_readfirstlane(blocks ? sn->nblk : sn->nb);
+            off_next = __builtin_amdgcn_readfirstlane(blocks ? sn->oblk : sn->ob);
+            const Cell* cn = (blocks ? T.blkcell : T.bcell) + off_next;
+            if (ncell_next > 0) pre = cn[lane < ncell_next ? lane : ncell_next - 1];
+        }
+        const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+        const double* h0 = blocks ? L.mb + X * P.mb_w + Y : L.hm + X * Ay + Y;
+        double m = has_out ? 0.0 : -1e300;
+        // The footprint list is fetched 64 cells at a time, one 16-byte cell per lane (a coalesced
+        // vector load), and broadcast cell by cell with v_readlane: the loop then has only LDS reads
+        // in flight, which the hardware returns in order and the compiler can pipeline (scalar
+        // loads would share lgkmcnt with the LDS reads and force full drains).
+        const Cell* cells = (blocks ? T.blkcell : T.bcell) + off0;
+        for (int base = 0; base < ncell; base += 64) {
+            if (base > 0) {
+                const int idx = base + lane < ncell ? base + lane : ncell - 1;
+                c = cells[idx];
+            }
+            const int cnt = ncell - base < 64 ? ncell - base : 64;
+            int c_off = c.off;
+            int c_lo = (int)__double2loint(c.v), c_hi = (int)__double2hiint(c.v);
+            // every lane must really hold its cell (v_readlane reads lanes that are masked off
+            // below): keep the compiler from sinking the load into the in_range branch
+            asm volatile("" : "+v"(c_off), "+v"(c_lo), "+v"(c_hi));
+            if (in_range) {
+                int u = 0;
+                for (; u + 8 <= cnt; u += 8) {                  // 8 LDS reads in flight per trip
+                    double hv[8], vv[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) m = fmax(m, hv[k] - vv[k]);
+                    for (int k = 0; k < 8; ++k) {
+                        const int off = __builtin_amdgcn_readlane(c_off, u + k);
+                        vv[k] = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u + k),
+                                                 __builtin_amdgcn_readlane(c_lo, u + k));
+                        hv[k] = h0[off];
                     }
-                    for (; u < cnt; ++u) {
-                        const int off = __builtin_amdgcn_readlane(c_off, u);
-                        const double v = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u),
-                                                          __builtin_amdgcn_readlane(c_lo, u));
-                        m = fmax(m, h0[off] - v);
-                    }
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) m = fmax(m, hv[k] - vv[k]);
+                }
+                for (; u < cnt; ++u) {
+                    const int off = __builtin_amdgcn_readlane(c_off, u);
+                    const double v = __hiloint2double(__builtin_amdgcn_readlane(c_hi, u),
+                                                      __builtin_amdgcn_readlane(c_lo, u));
+                    m = fmax(m, h0[off] - v);
                 }
             }
-            if (in_range) {
-                z = m;
-                valid = round6(z + sr.ext_z_r - P.bin_z) <= 0.0;
-            }
         }
+        if (in_range) {
+            zs[r] = m;
+            vs[r] = round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+        }
+    }
+    __syncthreads();                                         // every ShapeRot has been read: L.lev may be written
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r >= R) continue;
+        const double z = zs[r];
+        const bool valid = vs[r];
         if (tid < AC) {
             if (debug_out) {
                 io.posz_out[((size_t)b * R + r) * AC + tid] = z;
@@ -454,7 +524,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             L.posz[r * AC + tid] = valid ? z : 1e3;
             int code = 255;
             if (valid) {
-                const int li = (int)np_floor_divide(z, P.res_z);      // cvTools.py:78
+                const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
                 if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                     const int idx = li + 32;
                     if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
@@ -463,8 +533,22 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 ++my_valid;
             }
             L.lev[r * AC + tid] = (uint8_t)code;
-            if (code != 255) atomicOr(&L.present[r], 1ull << code);
+            level_code[r] = code;
         }
+    }
+    // presence masks: one LDS atomic per distinct level per wave (64 lanes ORing into one word would
+    // be serialised by the LDS lane by lane)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        if (r >= R) continue;
+        const int code = level_code[r];
+        unsigned long long todo = __ballot(code != 255), bits = 0ull;
+        while (todo) {
+            const int c = __builtin_amdgcn_readlane(code, __ffsll((long long)todo) - 1);
+            bits |= 1ull << c;
+            todo &= ~__ballot(code == c);
+        }
+        if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
     }
     return block_sum_int(my_valid, L.redi);                  // np.sum(naiveMask) for prejudge
 }
@@ -654,8 +738,8 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
         ShapeRot sr = {};
         if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
         if (ok) {
-            const double tx = round6((double)lx * P.res_a), ty = round6((double)ly * P.res_a);
-            if (round6(tx + sr.ext_x - P.bin_x) > 0.0 || round6(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
+            const double tx = P.txs[lx & 15], ty = P.txs[ly & 15];       // np.round(lx*resA, 6), precomputed
+            if (round6_scaled(tx + sr.ext_x - P.bin_x) > 0.0 || round6_scaled(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
         }
         double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)
         if (ok) {
@@ -668,7 +752,7 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
             }
             // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
             const double top = z * P.scale_z + sr.ext_z * P.scale_z;
-            if (round6(top - P.ibin_z) > 0.0) ok = false;
+            if (round6_scaled(top - P.ibin_z) > 0.0) ok = false;
         }
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
@@ -891,7 +975,7 @@ irbpp_hull_kernel(const Params P, const State S, const double* posz_valid, const
             L.posz[r * AC + tid] = z;
             int code = 255;
             if (valid) {
-                const int li = (int)np_floor_divide(z, P.res_z);
+                const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);
                 if (li != -1) {
                     const int idx = li + 32;
                     if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
