@@ -240,7 +240,15 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         constexpr int CLIST = 256;
         const uint32_t row_bits = base + g < ntasks ? (L.img[tid] & 0xFFFFu) : 0u;
         const uint32_t up_bits = (base + g < ntasks && y > 0) ? (L.img[tid - 1] & 0xFFFFu) : 0u;
-        const uint32_t my_cand = start_candidates(row_bits, up_bits);
+        const uint32_t down_bits = (base + g < ntasks && y < 15) ? (L.img[tid + 1] & 0xFFFFu) : 0u;
+        uint32_t my_cand = start_candidates(row_bits, up_bits);
+        {   // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
+            // returns the point and find_convex_vetex keeps every vertex of a polygon with <= 3 of
+            // them (cvTools.py:42-43).  Mark it directly; it never needs a trace lane.
+            const uint32_t iso = my_cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
+            if (iso) atomicOr(&L.vmask[(L.tasklist[base + g] >> 8) * 16 + y], iso);
+            my_cand &= ~iso;
+        }
         const int batch_total = block_sum_int(__popc(my_cand), L.redi);
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
