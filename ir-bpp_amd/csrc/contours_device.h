@@ -325,18 +325,19 @@ __device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uin
     int pos = 0, right_start = 0;
     bool le_eps = false;
     int start_pt = 0;
+    // Lane j holds point j, so a pass / slice needs no memory access: each lane works out its own
+    // position t along the traversal (t = (j - start) mod count) and whether that lies inside.
+    const int px = IRBPP_PX(pv), py = IRBPP_PY(pv);
     for (int it = 0; it < 3; ++it) {
         pos += right_start;
         if (pos >= count) pos -= count;
         start_pt = __builtin_amdgcn_readlane(pv, pos);
         const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
+        int j = lane - pos;
+        if (j < 0) j += count;
         uint32_t best = 0u;
-        const int j = 1 + lane;
-        if (j < count) {
-            int idx = pos + j;
-            if (idx >= count) idx -= count;
-            const int pt = pts[idx];
-            const int dx = IRBPP_PX(pt) - sx, dy = IRBPP_PY(pt) - sy;
+        if (lane < count && j >= 1) {
+            const int dx = px - sx, dy = py - sy;
             best = ((uint32_t)(dx * dx + dy * dy) << 12) | (uint32_t)(4095 - j);
         }
         best = wave_max_u32(best);
@@ -369,13 +370,11 @@ __device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uin
             const int end_pt = __builtin_amdgcn_readlane(pv, s_end);
             const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
             const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
+            int t = lane - s_start;
+            if (t < 0) t += count;
             uint32_t best = 0u;
-            const int t = 1 + lane;
-            if (t < len) {
-                int idx = s_start + t;
-                if (idx >= count) idx -= count;
-                const int pt = pts[idx];
-                int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
+            if (lane < count && t >= 1 && t < len) {
+                int dist = (py - sy) * dx - (px - sx) * dy;
                 dist = dist < 0 ? -dist : dist;
                 best = ((uint32_t)dist << 12) | (uint32_t)(4095 - t);
             }

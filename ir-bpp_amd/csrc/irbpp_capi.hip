@@ -66,7 +66,7 @@ void layout_lds(Params& P, int want_slots) {
     if (P.nslot < 16) P.nslot = 16;
     P.slot_cap = 64;                                                  // <= 64: the cooperative path keeps a border in one register per lane
     P.slot_stk = 12;
-    P.long_border = 8;
+    P.long_border = 12;
     if (const char* lb = getenv("IRBPP_LONG_BORDER")) P.long_border = atoi(lb);   // tuning knob
     P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 180 B = 45 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
