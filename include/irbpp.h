@@ -175,9 +175,11 @@ int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream);
  * switches the log off. */
 int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, int32_t capacity);
 
-/* Tooling: when cycles_dev != NULL every later transition launch stores, per bin, eight
- * shader-clock stamps int64[num_bins][8]: 0 start, 1 action applied, 2 overlap test done,
- * 3 contour stage done, 4 observation written (5..7 unused).  NULL switches it off. */
+/* Tooling: when cycles_dev != NULL every later transition launch stores, per bin, one row
+ * int64[num_bins][16]: shader-clock stamps 0 start, 1 action applied, 2 overlap test done,
+ * 3 contour stage done, 4 observation written; 5..7 contour-stage detail; 8/9 the 100 MHz wall
+ * clock at entry/exit; 10 = HW_ID | XCC_ID<<32 of the CU that ran the bin; 11..15 unused.
+ * NULL switches it off. */
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
 
 /* Device-side error word raised by kernels (0 = none).  Synchronises the stream. */

@@ -77,7 +77,12 @@ void layout_lds(Params& P, int want_slots) {
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
     P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
     P.o_clist = off;     off += 512;                                  // 256 candidate starts per (sub-)batch
-    P.o_mb = off;        off += align16(P.mb_w * P.mb_h * 8);            // block-max grid (0 bytes on the generic path)
+    // block-max grid of the overlap test (0 bytes on the generic path): dead before the contour
+    // stage builds its images, so it shares their bytes when it fits (25 KB per workgroup is the
+    // most that still lets six of them share a CU)
+    const int32_t mb_bytes = align16(P.mb_w * P.mb_h * 8);
+    if (mb_bytes <= align16(2 * 16 * 16 * 4) + 512) P.o_mb = P.o_img;
+    else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
@@ -290,6 +295,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.tcell, (const Cell*)tcell.data(), tcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.blkcell, (const Cell*)blkcell.data(), blkcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
+    if (rc == IRBPP_OK) rc = dev_alloc(env, &env->S.item_cost, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
     T.n_shapes = n_shapes;
     if (block_b) {                               // switch the overlap test to the block path

@@ -71,7 +71,8 @@ struct State {
     uint32_t* log_meta;    // optional [N][log_cap]: item | rot<<16 | lx<<20 | ly<<24 of the episode's placements
     double* log_z;         // optional [N][log_cap]: drop height of each placement
     int32_t log_cap;
-    int32_t* cost;         // [N] shader cycles the bin's last transition took (scheduling hint)
+    int32_t* cost;         // [N] predicted shader cycles of the bin's next transition (scheduling hint)
+    int32_t* item_cost;    // [n_shapes] running mean of the cycles a transition observing that item took
     int32_t* order;        // [N] launch order of the bins: most expensive first
     int32_t* err;          // [1] device error word
 };

@@ -125,9 +125,22 @@ __device__ __forceinline__ int linear_of_tile(const Params& P, int t) {
 typedef const __attribute__((address_space(4))) Cell* ConstCellPtr;
 __device__ __forceinline__ ConstCellPtr as_const(const Cell* p) { return (ConstCellPtr)(unsigned long long)p; }
 
-// optional per-phase shader-clock stamps (s_memtime), one row of 8 per bin
+// optional per-phase shader-clock stamps (s_memtime), one row of PHASE_ROW per bin:
+// [0..4] phase boundaries, [5..7] contour-stage detail, [8]/[9] 100 MHz wall clock at entry/exit,
+// [10] HW_ID | XCC_ID << 32 (which CU the bin ran on)
+constexpr int PHASE_ROW = 16;
 __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
-    if (io.phase_cycles && threadIdx.x == 0) io.phase_cycles[(size_t)b * 8 + k] = (long long)clock64();
+    if (io.phase_cycles && threadIdx.x == 0) {
+        long long* row = io.phase_cycles + (size_t)b * PHASE_ROW;
+        row[k] = (long long)clock64();
+        if (k == 0) {
+            row[8] = (long long)wall_clock64();
+            const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);      // HW_REG_HW_ID
+            const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);    // HW_REG_XCC_ID
+            row[10] = (long long)hw | ((long long)xcc << 32);
+        }
+        if (k == 4) row[9] = (long long)wall_clock64();
+    }
 }
 
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
@@ -579,8 +592,8 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     __syncthreads();
     stamp(io, b, 2);
 
-    if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * 8 + 5] = 0; io.phase_cycles[(size_t)b * 8 + 6] = 0; io.phase_cycles[(size_t)b * 8 + 7] = 0; }
-    contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * 8 : nullptr);
+    if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * PHASE_ROW + 5] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 6] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 7] = 0; }
+    contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * PHASE_ROW : nullptr);
     stamp(io, b, 3);
 
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
@@ -843,36 +856,59 @@ irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io,
     }
     if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out);
     if (tid == 0 && mode != MODE_POSSIBLE) {
+        // Scheduling hint for the next launch.  A bin's cycle count is nearly uncorrelated with its
+        // own previous step (r = -0.1 on the blockout workload) but a third of its variance is
+        // explained by WHICH item gets observed, and the pre-drawn trajectory tells that one
+        // step ahead: keep a running mean per item and predict with it.
         const long long dt = (long long)clock64() - t_begin;
-        S.cost[b] = dt > 0x7fffffffLL ? 0x7fffffff : (int)dt;
+        const int c = dt > 0x7fffffffLL ? 0x7fffffff : (int)dt;
+        int hint = c;
+        if (P.K == 1 && (mode == MODE_STEP || mode == MODE_RESET)) {
+            if (do_observe && obs_item >= 0) {
+                const int old = S.item_cost[obs_item];               // racy read-modify-write: a hint only
+                S.item_cost[obs_item] = old ? old + ((c - old) >> 3) : c;
+            }
+            const int nxt = fetch_item(P, T, S, b, S.bs[b].episode, S.bs[b].cursor);
+            const int m = nxt >= 0 ? S.item_cost[nxt] : 0;
+            if (m) hint = m;
+        }
+        S.cost[b] = hint;
     }
 }
 
-// Counting sort of the bins by descending cost bucket (64 buckets of 8192 cycles) -> S.order.
-// One workgroup; runs before every transition launch (a few microseconds).
+// Counting sort of the bins by descending cost (256 buckets between the smallest and the largest
+// hint) -> S.order.  One workgroup; runs before every transition launch (a few microseconds).
 extern "C" __global__ void __launch_bounds__(1024)
 irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
-    __shared__ int hist[64];
-    __shared__ int start[64];
+    __shared__ int hist[256];
+    __shared__ int start[256];
+    __shared__ int lo_hi[2];
     const int tid = threadIdx.x;
-    if (tid < 64) hist[tid] = 0;
+    if (tid < 256) hist[tid] = 0;
+    if (tid == 0) { lo_hi[0] = 0x7fffffff; lo_hi[1] = 0; }
     __syncthreads();
-    for (int b = tid; b < N; b += 1024) {
-        int k = 63 - (cost[b] >> 13);
-        k = k < 0 ? 0 : k;                      // bucket 0 = most expensive
-        atomicAdd(&hist[k], 1);
+    int lo = 0x7fffffff, hi = 0;
+    for (int b = tid; b < N; b += 1024) { const int c = cost[b]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
+    for (int o = 32; o > 0; o >>= 1) {
+        const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
+        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
+    }
+    if ((tid & 63) == 0) { atomicMin(&lo_hi[0], lo); atomicMax(&lo_hi[1], hi); }
+    __syncthreads();
+    lo = lo_hi[0];
+    const float scale = 255.0f / (float)(lo_hi[1] - lo + 1);
+    for (int b = tid; b < N; b += 1024) atomicAdd(&hist[255 - (int)((float)(cost[b] - lo) * scale)], 1);   // bucket 0 = most expensive
+    __syncthreads();
+    if (tid < 64) {                                  // exclusive scan of the 256 counts by one wave
+        int v[4], sum = 0;
+        for (int i = 0; i < 4; ++i) { v[i] = hist[tid * 4 + i]; sum += v[i]; }
+        int inc = sum;
+        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+        int acc = inc - sum;
+        for (int i = 0; i < 4; ++i) { start[tid * 4 + i] = acc; acc += v[i]; }
     }
     __syncthreads();
-    if (tid == 0) {
-        int acc = 0;
-        for (int k = 0; k < 64; ++k) { start[k] = acc; acc += hist[k]; }
-    }
-    __syncthreads();
-    for (int b = tid; b < N; b += 1024) {
-        int k = 63 - (cost[b] >> 13);
-        k = k < 0 ? 0 : k;
-        order[atomicAdd(&start[k], 1)] = b;
-    }
+    for (int b = tid; b < N; b += 1024) order[atomicAdd(&start[255 - (int)((float)(cost[b] - lo) * scale)], 1)] = b;
 }
 
 // Space.get_heuristic_action (space.py:162-218) for the item of the last observation: its own

@@ -203,8 +203,8 @@ class GpuPackingEnv(object):
         return self._log_meta, self._log_z
 
     def enable_phase_cycles(self, on: bool = True) -> Optional[torch.Tensor]:
-        """Tooling: int64[N,8] shader-clock stamps written by every later transition launch."""
-        self._cycles = torch.zeros((self.num_bins, 8), dtype=torch.int64, device=self.device) if on else None
+        """Tooling: int64[N,16] shader-clock stamps written by every later transition launch."""
+        self._cycles = torch.zeros((self.num_bins, 16), dtype=torch.int64, device=self.device) if on else None
         _lib.check(self.lib.irbpp_debug_phase_cycles(self._h, _ptr(self._cycles)), "irbpp_debug_phase_cycles")
         return self._cycles
 
