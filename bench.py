@@ -172,19 +172,15 @@ def main():
     obs_b = torch.empty_like(obs_a)
     act = torch.empty((a.bins,), dtype=torch.int32, device=dev)
 
-    def one_step(src, dst, ev=None):
+    def one_step(src, dst):
         env.policy_minz(src, actions_out=act)
-        if ev is not None:
-            ev[0].record()
         env.step(act, obs_out=dst)
-        if ev is not None:
-            ev[1].record()
 
     cur, nxt = obs_a, obs_b
     for _ in range(a.warmup):
         one_step(cur, nxt)
         cur, nxt = nxt, cur
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
+    env.enable_kernel_timing(a.steps)          # HIP events right around irbpp_env_kernel, on its stream
 
     def barrier():
         D.barrier(dev)
@@ -192,13 +188,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
-        one_step(cur, nxt, events[i])
+        one_step(cur, nxt)
         cur, nxt = nxt, cur
     barrier()
     elapsed = time.perf_counter() - t0
     env.check_device_error()
 
-    kernel_ms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in events]))     # transition kernel only
+    kernel_ms = float(env.kernel_times_ms().mean())                              # irbpp_env_kernel alone
+    env.enable_kernel_timing(0)
     elapsed = D.max_over_ranks(elapsed, dev)
     tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
 

@@ -182,6 +182,16 @@ int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, i
  * NULL switches it off. */
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
 
+/* Tooling: time the transition kernel alone.  capacity > 0 creates a ring of that many HIP event
+ * pairs; every later transition launch (reset / step / get_action_candidates) records the next
+ * pair on its stream right around irbpp_env_kernel (the few-microsecond ordering kernel in front
+ * of it stays outside the bracket).  capacity 0 frees the ring.
+ * irbpp_debug_kernel_times waits for the recorded launches and writes the durations of the latest
+ * min(max_count, recorded) of them in ms to ms_host, oldest first; *count says how many; the ring
+ * is then empty again. */
+int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);
+int irbpp_debug_kernel_times(irbpp_env* env, float* ms_host, int32_t max_count, int32_t* count);
+
 /* Device-side error word raised by kernels (0 = none).  Synchronises the stream. */
 int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
 

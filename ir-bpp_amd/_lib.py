@@ -50,6 +50,8 @@ SIGNATURES = {
     "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_placement_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "irbpp_debug_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
+    "irbpp_debug_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "irbpp_device_error": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p]),
 }
 

@@ -25,6 +25,8 @@ struct irbpp_env {
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
     long long* phase_cycles = nullptr;
+    std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
+    size_t timing_next = 0, timing_used = 0;
     std::vector<void*> allocs;
 };
 
@@ -76,24 +78,28 @@ void layout_lds(Params& P, int want_slots) {
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
     P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
-    P.o_clist = off;     off += 512;                                  // 256 candidate starts per (sub-)batch
     // block-max grid of the overlap test (0 bytes on the generic path): dead before the contour
-    // stage builds its images, so it shares their bytes when it fits (25 KB per workgroup is the
-    // most that still lets six of them share a CU)
+    // stage builds its images, so it shares their bytes when it fits
     const int32_t mb_bytes = align16(P.mb_w * P.mb_h * 8);
-    if (mb_bytes <= align16(2 * 16 * 16 * 4) + 512) P.o_mb = P.o_img;
+    if (mb_bytes <= align16(2 * 16 * 16 * 4)) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
     // and the candidate keys: the tile's float32 copy is written out before the slots reuse it
-    int32_t scratch = P.nslot * P.slot_bytes;
+    const int32_t slots = align16(P.nslot * P.slot_bytes);
+    int32_t scratch = slots;
     const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
     if (scratch < P.Hc * 8) scratch = P.Hc * 8;
+    P.scratch_bytes = align16(scratch);
+    // the 256 candidate starts of an image (sub-)batch live behind the slots when the tile left room
+    const bool clist_in_scratch = slots + 512 <= P.scratch_bytes;
+    if (!clist_in_scratch) { P.o_clist = off; off += 512; }
     P.o_hm = off;
     P.o_scratch = off;
-    P.scratch_bytes = align16(scratch);
+    if (clist_in_scratch) P.o_clist = off + slots;
+    P.big_slot_bytes = clist_in_scratch ? slots : P.scratch_bytes;
     off += P.scratch_bytes;
     if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tuning: caps workgroups per CU
     P.lds_bytes = off;
@@ -196,6 +202,7 @@ int irbpp_destroy(irbpp_env* env) {
     if (!env) return IRBPP_OK;
     hipSetDevice(env->cfg.device);
     for (void* p : env->allocs) hipFree(p);
+    for (hipEvent_t e : env->timing) hipEventDestroy(e);
     delete env;
     return IRBPP_OK;
 }
@@ -335,8 +342,15 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream) {
     if (mode == MODE_STEP || mode == MODE_CANDS)      // most expensive bins first (see irbpp_env_kernel)
         hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, env->S.cost, env->S.order,
                            env->P.N);
+    const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
+    if (pairs) hipEventRecord(env->timing[2 * slot], (hipStream_t)stream);
     hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                        env->P, env->T, env->S, io, mode);
+    if (pairs) {
+        hipEventRecord(env->timing[2 * slot + 1], (hipStream_t)stream);
+        env->timing_next = (slot + 1) % pairs;
+        if (env->timing_used < pairs) env->timing_used++;
+    }
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
@@ -471,6 +485,34 @@ int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, i
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
     env->phase_cycles = (long long*)cycles_dev;
+    return IRBPP_OK;
+}
+
+int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity) {
+    if (!env || capacity < 0) return IRBPP_ERR_ARG;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    for (hipEvent_t e : env->timing) hipEventDestroy(e);
+    env->timing.clear();
+    env->timing_next = env->timing_used = 0;
+    for (int i = 0; i < 2 * capacity; ++i) {
+        hipEvent_t e;
+        HIP_TRY(hipEventCreate(&e));
+        env->timing.push_back(e);
+    }
+    return IRBPP_OK;
+}
+
+int irbpp_debug_kernel_times(irbpp_env* env, float* ms_host, int32_t max_count, int32_t* count) {
+    if (!env || !ms_host || !count || max_count < 0) return IRBPP_ERR_ARG;
+    const size_t pairs = env->timing.size() / 2;
+    size_t n = env->timing_used < (size_t)max_count ? env->timing_used : (size_t)max_count;
+    for (size_t i = 0; i < n; ++i) {                   // the n latest launches, oldest first
+        const size_t slot = (env->timing_next + pairs - n + i) % pairs;
+        HIP_TRY(hipEventSynchronize(env->timing[2 * slot + 1]));
+        HIP_TRY(hipEventElapsedTime(&ms_host[i], env->timing[2 * slot], env->timing[2 * slot + 1]));
+    }
+    *count = (int32_t)n;
+    env->timing_next = env->timing_used = 0;
     return IRBPP_OK;
 }
 

@@ -326,7 +326,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                 const unsigned long long redo = ((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8];
                 if (redo != 0ull) {
                     if (tid == 0) {
-                        const int cap = (P.scratch_bytes / 6) & ~3;
+                        const int cap = (P.big_slot_bytes / 6) & ~3;
                         const SlotMem m = carve_slot(L.scratch, cap, cap);
                         for (int c = 0; c < count; ++c) {
                             if (!((redo >> c) & 1ull)) continue;

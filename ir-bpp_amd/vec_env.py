@@ -208,6 +208,20 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_debug_phase_cycles(self._h, _ptr(self._cycles)), "irbpp_debug_phase_cycles")
         return self._cycles
 
+    def enable_kernel_timing(self, capacity: int) -> None:
+        """Tooling: bracket the transition kernel of the next ``capacity`` launches with HIP events
+        on their stream (``capacity`` 0 switches it off)."""
+        _lib.check(self.lib.irbpp_debug_kernel_timing(self._h, int(capacity)), "irbpp_debug_kernel_timing")
+        self._timing_cap = int(capacity)
+
+    def kernel_times_ms(self) -> np.ndarray:
+        """Durations (ms) of the transition kernels recorded since the last call, oldest first."""
+        cap = getattr(self, "_timing_cap", 0)
+        buf = (C.c_float * max(cap, 1))()
+        n = C.c_int32(0)
+        _lib.check(self.lib.irbpp_debug_kernel_times(self._h, buf, cap, C.byref(n)), "irbpp_debug_kernel_times")
+        return np.array(buf[:n.value], dtype=np.float64)
+
     def check_device_error(self) -> None:
         flags = C.c_int32(0)
         _lib.check(self.lib.irbpp_device_error(self._h, self._stream(), C.byref(flags)),

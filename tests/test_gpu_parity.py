@@ -444,6 +444,30 @@ def test_abi_rejects_calls_out_of_order():
     assert lib.irbpp_destroy(h) == 0
 
 
+def test_tooling_hooks_time_and_locate_every_bin():
+    """irbpp_debug_kernel_timing / irbpp_debug_phase_cycles: the numbers bench.py and tools/ report."""
+    shapes = synthetic.blockout_shapes(16, seed=3)
+    seqs = synthetic.make_sequences(16, n_traj=40, length=60, seed=4)
+    env = GpuPackingEnv(shapes, seqs, 64, device=DEV)
+    obs = env.reset()
+    env.enable_kernel_timing(4)
+    cyc = env.enable_phase_cycles(True)
+    for _ in range(3):
+        obs, _, _ = env.step(env.policy_minz(obs))
+    ms = env.kernel_times_ms()
+    assert ms.shape == (3,) and (ms > 0).all() and (ms < 100).all()
+    assert env.kernel_times_ms().shape == (0,)                   # the ring was drained
+    for _ in range(6):                                            # more launches than pairs: the latest four
+        obs, _, _ = env.step(env.policy_minz(obs))
+    assert env.kernel_times_ms().shape == (4,)
+    env.enable_kernel_timing(0)
+    c = cyc.cpu().numpy()
+    assert (np.diff(c[:, :5], axis=1) > 0).all()                  # stamps of every bin are ordered
+    assert (c[:, 9] > c[:, 8]).all()                              # wall clock exit after entry
+    env.enable_phase_cycles(False)
+    env.check_device_error()
+
+
 @pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60)])
 def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
     """Scale check made possible by the C oracle: the bench workloads themselves, hundreds of bins,
