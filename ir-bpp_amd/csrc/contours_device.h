@@ -81,7 +81,7 @@ __device__ __forceinline__ int run_backward(uint32_t line, uint32_t side, int p)
 // points produced (stored only while they fit in cap); 0 if the walk met a pixel that precedes
 // (x0,y0) in raster order, i.e. (x0,y0) is not the first pixel of its component and the border
 // belongs to another start (or is a hole border); -1 if the iteration guard tripped.
-__device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
+__device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
     uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
     uint32_t nb = nb_mask(ra, rb, rc, x0);
     // clockwise search 3,2,1,0,7,6,5 (s_end = 4: the west pixel is background) for the first neighbour
@@ -113,7 +113,7 @@ __device__ inline int trace_border(const uint32_t* img, const uint32_t* imgT, in
         {
             const bool horiz = (s2 & 3) == 0;                     // E or W: walk a row, else a column
             const bool fwd = s2 == 0 || s2 == 6;                  // E or S: towards higher bits
-            const uint32_t* base = horiz ? img : imgT;
+            const uint16_t* base = horiz ? img : imgT;
             const int li = horiz ? y4 : x4;
             const int si = (horiz == fwd) ? li + 1 : li - 1;      // E: row below, W: row above, S: column left, N: column right
             int p = horiz ? x4 : y4;
@@ -275,7 +275,7 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
 
 // One outer border, serially: trace, approximate, mark convex vertices.  Returns 0 ok,
 // 1 capacity overflow (caller retries with a bigger slot), 2 iteration guard.
-__device__ inline int contour_vertices(const uint32_t* img, const uint32_t* imgT, int x0, int y0, const SlotMem& m,
+__device__ inline int contour_vertices(const uint16_t* img, const uint16_t* imgT, int x0, int y0, const SlotMem& m,
                                        uint32_t* vrows) {
     const int n = trace_border(img, imgT, x0, y0, m.pts, m.cap);
     if (n < 0) return 2;

@@ -77,11 +77,12 @@ void layout_lds(Params& P, int want_slots) {
     P.o_present = off;   off += align16(P.R * 8);
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
     P.o_tasklist = off;  off += align16(P.R * 64 * 2);
-    P.o_img = off;       off += align16(2 * 16 * 16 * 4);                 // 16 level images: row words + column words
+    const int32_t img_bytes = align16(2 * CONTOUR_IPT * 16 * 16 * 2);  // level images of a batch: 16-bit row words + column words
+    P.o_img = off;       off += img_bytes;
     // block-max grid of the overlap test (0 bytes on the generic path): dead before the contour
     // stage builds its images, so it shares their bytes when it fits
     const int32_t mb_bytes = align16(P.mb_w * P.mb_h * 8);
-    if (mb_bytes <= align16(2 * 16 * 16 * 4)) P.o_mb = P.o_img;
+    if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
@@ -171,7 +172,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
-    if (hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)irbpp_env_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
@@ -311,7 +314,9 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         env->P.mb_w = mb_w;
         layout_lds(env->P, env->cfg.contour_slots);
         if (env->P.lds_bytes > 160 * 1024) return IRBPP_ERR_ARG;
-        if (hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
+        if (hipFuncSetAttribute((const void*)irbpp_env_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess)
             return IRBPP_ERR_HIP;
@@ -344,8 +349,13 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream) {
                            env->P.N);
     const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
     if (pairs) hipEventRecord(env->timing[2 * slot], (hipStream_t)stream);
-    hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
-                       env->P, env->T, env->S, io, mode);
+    // six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
+    if (6 * env->P.lds_bytes <= 150 * 1024)
+        hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+                           env->P, env->T, env->S, io, mode);
+    else
+        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+                           env->P, env->T, env->S, io, mode);
     if (pairs) {
         hipEventRecord(env->timing[2 * slot + 1], (hipStream_t)stream);
         env->timing_next = (slot + 1) % pairs;

@@ -14,6 +14,10 @@
 
 namespace irbpp {
 
+// Contour stage: every thread of the 256-thread workgroup owns CONTOUR_IPT (image, row) pairs, i.e. a
+// batch holds CONTOUR_IPT * 16 level images of 16x16 pixels (row words + column words, 16 bit each).
+constexpr int CONTOUR_IPT = 2;
+
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
     int32_t ax, ay;        // footprint in action cells:    ceil(round(extents,6)/resA)  (space.py:106)

@@ -161,8 +161,8 @@ struct Lds {
     unsigned long long* present;
     uint16_t* taskidx;      // [R][64] level code -> task index
     uint16_t* tasklist;     // [ntasks] rot<<8 | level code
-    uint32_t* img;          // [16][16] level images of the current batch, one 16-bit row per word
-    uint16_t* clist;        // [256] candidate starts of the image (sub-)batch: image | x0<<4 | y0<<8
+    uint16_t* img;          // [2][IMGS][16] level images of the current batch: 16-bit row words, then column words
+    uint16_t* clist;        // [256] candidate starts of the image (sub-)batch: image | x0<<6 | y0<<10
     uint16_t* cn;           // [nslot] point count of each traced border of the current pass
     uint32_t* vmask;
     unsigned char* scratch;
@@ -179,7 +179,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.present = (unsigned long long*)(smem + P.o_present);
     L.taskidx = (uint16_t*)(smem + P.o_taskidx);
     L.tasklist = (uint16_t*)(smem + P.o_tasklist);
-    L.img = (uint32_t*)(smem + P.o_img);
+    L.img = (uint16_t*)(smem + P.o_img);
     L.clist = (uint16_t*)(smem + P.o_clist);
     L.cn = (uint16_t*)(smem + P.o_red + 256);
     L.vmask = (uint32_t*)(smem + P.o_vmask);
@@ -212,10 +212,13 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         }
     }
     const int X = tid / P.Ay, Y = tid % P.Ay;
-    const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's image g
-    constexpr int IMGS = BLOCK / 16;                 // 16 level images per batch
+    const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
+    constexpr int IPT = CONTOUR_IPT;                 // (image, row) pairs per thread
+    constexpr int IMGS = IPT * (BLOCK / 16);         // level images per batch
+    uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
+    uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
-        for (int i = tid; i < IMGS * 16; i += BLOCK) L.img[i] = 0u;           // rows (the column copy is derived below)
+        for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
         __syncthreads();
         // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
         // lanes of a lane group are the 16 columns of row X, and the ballot of "my cell belongs to
@@ -225,7 +228,10 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
             if (ti >= IMGS) ti = -1;
             if (P.Ay != 16) {                    // lane groups are not image rows: plain LDS atomics
-                if (ti >= 0) atomicOr(&L.img[ti * 16 + X], 1u << Y);
+                if (ti >= 0) {
+                    const int w = ti * 16 + X;
+                    atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
+                }
                 continue;
             }
             unsigned long long todo = __ballot(ti >= 0);
@@ -235,45 +241,56 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                 todo &= ~bal;
                 if ((tid & 15) == 0) {
                     const uint32_t rowbits = (uint32_t)(bal >> (tid & 48)) & 0xFFFFu;
-                    if (rowbits) L.img[t0 * 16 + X] = rowbits;
+                    if (rowbits) rows[t0 * 16 + X] = (uint16_t)rowbits;
                 }
             }
         }
         __syncthreads();
         // transposed copy (column words) for the vertical run jumps: thread (g, y) gathers column y
-        {
+        for (int h = 0; h < IPT; ++h) {
+            const int gg = g + h * (BLOCK / 16);
             uint32_t col = 0u;
-            for (int k = 0; k < 16; ++k) col |= ((L.img[g * 16 + k] >> y) & 1u) << k;
-            L.img[(IMGS + g) * 16 + y] = col;
+            for (int k = 0; k < 16; ++k) col |= (((uint32_t)rows[gg * 16 + k] >> y) & 1u) << k;
+            cols[gg * 16 + y] = (uint16_t)col;
         }
         __syncthreads();
         // (a) candidate starts: one thread per (image, row), pure bit operations.  The list holds
         // CLIST entries; a batch with more candidates (pathological speckle) is walked one image at
         // a time (an image has at most 64: every other pixel of every other row).
         constexpr int CLIST = 256;
-        const uint32_t row_bits = base + g < ntasks ? (L.img[tid] & 0xFFFFu) : 0u;
-        const uint32_t up_bits = (base + g < ntasks && y > 0) ? (L.img[tid - 1] & 0xFFFFu) : 0u;
-        const uint32_t down_bits = (base + g < ntasks && y < 15) ? (L.img[tid + 1] & 0xFFFFu) : 0u;
-        uint32_t my_cand = start_candidates(row_bits, up_bits);
-        {   // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
+        uint32_t my_cand[IPT];
+        int my_count = 0;
+        for (int h = 0; h < IPT; ++h) {
+            const int gg = g + h * (BLOCK / 16);
+            const bool live = base + gg < ntasks;
+            const uint32_t row_bits = live ? (uint32_t)rows[gg * 16 + y] : 0u;
+            const uint32_t up_bits = (live && y > 0) ? (uint32_t)rows[gg * 16 + y - 1] : 0u;
+            const uint32_t down_bits = (live && y < 15) ? (uint32_t)rows[gg * 16 + y + 1] : 0u;
+            uint32_t cand = start_candidates(row_bits, up_bits);
+            // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
             // returns the point and find_convex_vetex keeps every vertex of a polygon with <= 3 of
             // them (cvTools.py:42-43).  Mark it directly; it never needs a trace lane.
-            const uint32_t iso = my_cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
-            if (iso) atomicOr(&L.vmask[(L.tasklist[base + g] >> 8) * 16 + y], iso);
-            my_cand &= ~iso;
+            const uint32_t iso = cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
+            if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
+            cand &= ~iso;
+            my_cand[h] = cand;
+            my_count += __popc(cand);
         }
-        const int batch_total = block_sum_int(__popc(my_cand), L.redi);
+        const int batch_total = block_sum_int(my_count, L.redi);
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
         __syncthreads();
         if (tid == 0) L.redi[10] = 0;
         __syncthreads();
-        if (nsub == 1 || g == sub) {
-            uint32_t cand = my_cand;
-            while (cand) {
-                const int x = __ffs((int)cand) - 1;
-                cand &= cand - 1u;
-                L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(g | (x << 4) | (y << 8));
+        for (int h = 0; h < IPT; ++h) {
+            const int gg = g + h * (BLOCK / 16);
+            if (nsub == 1 || gg == sub) {
+                uint32_t cand = my_cand[h];
+                while (cand) {
+                    const int x = __ffs((int)cand) - 1;
+                    cand &= cand - 1u;
+                    L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(gg | (x << 6) | (y << 10));
+                }
             }
         }
         __syncthreads();
@@ -290,9 +307,9 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             const SlotMem mine = carve_slot(L.scratch + tid * P.slot_bytes, P.slot_cap, P.slot_stk);
             if (tid < count) {
                 const uint32_t e = L.clist[c0 + tid];
-                const int gi = e & 15u;
+                const int gi = e & 63u;
                 my_r = L.tasklist[base + gi] >> 8;
-                const int n = trace_border(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 4) & 15u, (e >> 8) & 15u,
+                const int n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u,
                                            mine.pts, mine.cap);
                 L.cn[tid] = (uint16_t)(n < 0 ? 0 : (n > 0xFFFF ? 0xFFFF : n));
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
@@ -313,7 +330,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                     li = __shfl(li, 0);
                     if (li >= nlong) break;
                     const int c = llist[li];
-                    const int r = L.tasklist[base + (L.clist[c0 + c] & 15u)] >> 8;
+                    const int r = L.tasklist[base + (L.clist[c0 + c] & 63u)] >> 8;
                     const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
                     if (!approx_and_convex_wave(m.pts, (int)L.cn[c], L.vmask + r * 16) && (tid & 63) == 0)
                         atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
@@ -331,9 +348,9 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                         for (int c = 0; c < count; ++c) {
                             if (!((redo >> c) & 1ull)) continue;
                             const uint32_t e = L.clist[c0 + c];
-                            const int gi = e & 15u;
+                            const int gi = e & 63u;
                             const int r = L.tasklist[base + gi] >> 8;
-                            if (contour_vertices(L.img + gi * 16, L.img + (IMGS + gi) * 16, (e >> 4) & 15u, (e >> 8) & 15u, m,
+                            if (contour_vertices(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u, m,
                                                  L.vmask + r * 16) == 2)
                                 atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                         }
@@ -694,9 +711,27 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
 // ---------------------------------------------------------------------------------------
 // The environment transition kernel: one workgroup per bin.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(BLOCK)
+// Two builds of one body.  irbpp_env_kernel is held to 80 VGPRs (six waves per SIMD): used when the
+// LDS layout lets six workgroups share a CU (R <= 4 on a 32x32 heightmap).  With larger layouts LDS
+// caps the CU at four or five workgroups anyway and irbpp_env_kernel_wide lets the register
+// allocator have what it wants (+8 % on the R=8 "general" workload).
+__device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
+                                               const int mode, unsigned char* smem);
+
+extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6)))
 irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    env_transition(P, T, S, io, mode, smem);
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_env_kernel_wide(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    env_transition(P, T, S, io, mode, smem);
+}
+
+__device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
+                                               const int mode, unsigned char* smem) {
     const Lds L = carve_lds(smem, P);
     // Bins are launched most-expensive-first (S.order, refreshed by irbpp_order_kernel from the
     // cycle counts of the previous transition): with ~2.7 bins per resident workgroup slot the
