@@ -40,6 +40,14 @@ def make_workload(name):
         shapes = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
         seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 160, seed=123)
         kw = dict(resolutionA=0.02, resolutionH=0.01)
+    elif name == "blockout_r8":         # cfg 2 with the README command's eight rotations (README.md:100)
+        shapes = synthetic.blockout_shapes(n_shapes=64, n_rot=8, seed=0)
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 160, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.01)
+    elif name == "blockout_k10":        # cfg 4: buffered packing, order action scripted = slot 0
+        shapes = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
+        seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 160, seed=123)
+        kw = dict(resolutionA=0.02, resolutionH=0.01, bufferSize=10)
     elif name == "general":
         shapes = synthetic.general_shapes(n_shapes=256, n_rot=8, seed=1)
         seqs = synthetic.make_sequences(shapes.n_shapes, 10000, 100, seed=123)
@@ -103,6 +111,7 @@ def _cpu_worker(args):
         from oracle.packing import OracleVecEnv as Env
     env = Env(1, shapes, seqs, global_offset=rank, global_num=1 << 20, **kw)
     obs = env.reset()
+    buffered = kw.get("bufferSize", 1) > 1
 
     def minz(o):
         c = o[:5 * S].reshape(S, 5)
@@ -112,6 +121,8 @@ def _cpu_worker(args):
     n = 0
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < seconds:
+        if buffered:                    # one hierarchical placement = get_action_candidates + step
+            obs = env.get_action_candidates([0])
         obs, _, _, _ = env.step([minz(o) for o in obs])
         n += 1
     return n, time.perf_counter() - t0
@@ -168,11 +179,19 @@ def main():
     env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, contour_slots=a.slots,
                         **D.shard(rank, world, a.bins), **kw)
     hc = env.Hx * env.Hy
+    k = int(kw.get("bufferSize", 1))
+    launches = 2 if k > 1 else 1               # transition-kernel launches per placement
     obs_a = env.reset()
     obs_b = torch.empty_like(obs_a)
     act = torch.empty((a.bins,), dtype=torch.int32, device=dev)
+    if k > 1:
+        slot0 = torch.zeros((a.bins,), dtype=torch.int32, device=dev)
+        loc = torch.empty((a.bins, env.loc_obs_len), dtype=torch.float32, device=dev)
 
     def one_step(src, dst):
+        if k > 1:                              # one hierarchical placement: candidates of the
+            env.get_action_candidates(slot0, obs_out=loc)     # chosen buffer slot, then the placement
+            src = loc
         env.policy_minz(src, actions_out=act)
         env.step(act, obs_out=dst)
 
@@ -180,7 +199,7 @@ def main():
     for _ in range(a.warmup):
         one_step(cur, nxt)
         cur, nxt = nxt, cur
-    env.enable_kernel_timing(a.steps)          # HIP events right around irbpp_env_kernel, on its stream
+    env.enable_kernel_timing(a.steps * launches)   # HIP events right around irbpp_env_kernel, on its stream
 
     def barrier():
         D.barrier(dev)
@@ -194,7 +213,8 @@ def main():
     elapsed = time.perf_counter() - t0
     env.check_device_error()
 
-    kernel_ms = float(env.kernel_times_ms().mean())                              # irbpp_env_kernel alone
+    lds_bytes, kernel_name = env.kernel_info()
+    kernel_ms = float(env.kernel_times_ms().mean()) * launches                   # irbpp_env_kernel alone, per placement
     env.enable_kernel_timing(0)
     elapsed = D.max_over_ranks(elapsed, dev)
     tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
@@ -202,7 +222,7 @@ def main():
     # Extra measurement (not `value`): the same bins as S sub-batches on S HIP streams, each
     # stepping on its own; one sub-batch's straggler workgroups overlap the next one's start.
     pipelined = None
-    if a.pipeline_streams > 1 and a.bins % a.pipeline_streams == 0:
+    if a.pipeline_streams > 1 and a.bins % a.pipeline_streams == 0 and k == 1:
         ns, per = a.pipeline_streams, a.bins // a.pipeline_streams
         env.close()
         sh = D.shard(rank, world, a.bins)
@@ -245,7 +265,7 @@ def main():
 
     if rank == 0:
         total_steps = a.bins * world * a.steps
-        bps = algorithmic_bytes_per_step(shapes, hc, 1)
+        bps = algorithmic_bytes_per_step(shapes, hc, k)
         achieved = bps * a.bins / (kernel_ms * 1e-3) / 1e9
         traffic = None
         prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
@@ -260,12 +280,12 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.workload} online (bufferSize=1), {a.bins} bins/GPU, resolutionA=0.02 "
+            "config": {"workload": f"{a.workload} {'online' if k == 1 else 'buffered'} (bufferSize={k}), {a.bins} bins/GPU, resolutionA=0.02 "
                                    f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy",
                        "bins_per_gpu": a.bins, "global_bins": a.bins * world, "parallelism": f"bins sharded x{world}"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "irbpp_env_kernel", "kernel_ms": kernel_ms,
+                         "kernel": kernel_name, "kernel_ms": kernel_ms, "lds_bytes_per_workgroup": lds_bytes,
                          "algorithmic_bytes_per_step": bps},
             "episodes": {"finished": float(tot[0]), "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
                          "mean_items": float(tot[2] / tot[0]) if tot[0] else None},

@@ -103,6 +103,14 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which);
  * obs_dev: float32[num_bins][obs_len(0)].  Restarts the trajectory counters. */
 int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream);
 
+/* replaces: ShmemVecEnv.reset_specific (shmem_vec_env.py:113-117): PackingGame.reset of the
+ * listed bins only.  bins_dev: int32[count] distinct local bin indices (device memory);
+ * obs_dev: float32[count][obs_len(0)], row i = the reset observation of bin bins_dev[i].
+ * Like the reference's per-env reset the bin moves on to its next trajectory and the episode it
+ * abandons enters no statistics.  An index outside [0, num_bins) is skipped and raises
+ * IRBPP_DEVERR_BAD_BIN. */
+int irbpp_reset_bins(irbpp_env* env, const int32_t* bins_dev, int32_t count, float* obs_dev, void* stream);
+
 /* replaces: ShmemVecEnv.step_async+step_wait (shmem_vec_env.py:70-81) -> PackingGame.step
  * (binPhy.py:248-337, no-physics branch) + the worker's auto-reset (shmem_vec_env.py:141-144).
  * actions_dev: int32[num_bins] indices into the candidate rows of the last location
@@ -189,6 +197,9 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
  * irbpp_debug_kernel_times waits for the recorded launches and writes the durations of the latest
  * min(max_count, recorded) of them in ms to ms_host, oldest first; *count says how many; the ring
  * is then empty again. */
+/* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and which build
+ * of it launches: 0 = irbpp_env_kernel (80 VGPRs, six workgroups per CU), 1 = irbpp_env_kernel_wide. */
+int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide);
 int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);
 int irbpp_debug_kernel_times(irbpp_env* env, float* ms_host, int32_t max_count, int32_t* count);
 
@@ -198,6 +209,7 @@ int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
 #define IRBPP_DEVERR_LEVEL_RANGE   1   /* a height level fell outside the 64 supported bins  */
 #define IRBPP_DEVERR_TRACE_GUARD   2   /* border following exceeded its iteration guard      */
 #define IRBPP_DEVERR_BAD_ITEM      4   /* item id outside the loaded shape table             */
+#define IRBPP_DEVERR_BAD_BIN       8   /* irbpp_reset_bins: bin index outside [0, num_bins)  */
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ SIGNATURES = {
     "irbpp_load_sequences": (C.c_int, [C.c_void_p, c_i32_p, C.c_int32, C.c_int32]),
     "irbpp_obs_len": (C.c_int, [C.c_void_p, C.c_int32]),
     "irbpp_reset": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_reset_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(IrbppStepOut), C.c_void_p]),
     "irbpp_get_action_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -50,6 +51,7 @@ SIGNATURES = {
     "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_placement_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "irbpp_debug_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "irbpp_debug_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "irbpp_debug_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),
     "irbpp_device_error": (C.c_int, [C.c_void_p, C.c_void_p, c_i32_p]),

@@ -342,19 +342,22 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
     return which == 0 ? env->P.obs_len0 : env->P.obs_len1;
 }
 
-static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream) {
+// six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
+static bool use_wide_kernel(const Params& P) { return 6 * P.lds_bytes > 150 * 1024; }
+
+static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int grid = 0) {
+    if (grid <= 0) grid = env->P.N;
     io.phase_cycles = env->phase_cycles;
     if (mode == MODE_STEP || mode == MODE_CANDS)      // most expensive bins first (see irbpp_env_kernel)
         hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, env->S.cost, env->S.order,
                            env->P.N);
     const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
     if (pairs) hipEventRecord(env->timing[2 * slot], (hipStream_t)stream);
-    // six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
-    if (6 * env->P.lds_bytes <= 150 * 1024)
-        hipLaunchKernelGGL(irbpp_env_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+    if (!use_wide_kernel(env->P))
+        hipLaunchKernelGGL(irbpp_env_kernel, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                            env->P, env->T, env->S, io, mode);
     else
-        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                            env->P, env->T, env->S, io, mode);
     if (pairs) {
         hipEventRecord(env->timing[2 * slot + 1], (hipStream_t)stream);
@@ -374,6 +377,18 @@ int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream) {
     const int rc = launch_env(env, io, MODE_RESET, stream);
     if (rc == IRBPP_OK) env->was_reset = true;
     return rc;
+}
+
+int irbpp_reset_bins(irbpp_env* env, const int32_t* bins_dev, int32_t count, float* obs_dev, void* stream) {
+    if (!env || count < 0 || count > env->P.N || (count > 0 && (!bins_dev || !obs_dev))) return IRBPP_ERR_ARG;
+    if (!env->was_reset) return IRBPP_ERR_STATE;
+    if (count == 0) return IRBPP_OK;
+    StepIO io;
+    memset(&io, 0, sizeof(io));
+    io.obs = obs_dev;
+    io.obs_stride = env->P.obs_len0;
+    io.bin_list = bins_dev;
+    return launch_env(env, io, MODE_RESET, stream, count);
 }
 
 int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const irbpp_step_out* out, void* stream) {
@@ -495,6 +510,13 @@ int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, i
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
     env->phase_cycles = (long long*)cycles_dev;
+    return IRBPP_OK;
+}
+
+int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide) {
+    if (!env || !lds_bytes || !wide) return IRBPP_ERR_ARG;
+    *lds_bytes = env->P.lds_bytes;
+    *wide = use_wide_kernel(env->P) ? 1 : 0;
     return IRBPP_OK;
 }
 

@@ -124,6 +124,7 @@ struct StepIO {
     int32_t* heur_out;          // MODE_HEURISTIC: [N][3] = rot, lx, ly
     int32_t heur_method;        // 1 MINZ, 2 DBLF, 3 FIRSTFIT, 4 HM (space.py:168-218)
     int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
+    const int32_t* bin_list;    // MODE_RESET on a subset (reset_specific): workgroup i resets bin bin_list[i]
 };
 
 }  // namespace irbpp

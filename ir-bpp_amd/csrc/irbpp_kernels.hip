@@ -736,12 +736,18 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     // Bins are launched most-expensive-first (S.order, refreshed by irbpp_order_kernel from the
     // cycle counts of the previous transition): with ~2.7 bins per resident workgroup slot the
     // stragglers would otherwise decide the kernel's duration.
-    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x] : (int)blockIdx.x;
+    const bool some = mode == MODE_RESET && io.bin_list != nullptr;          // reset_specific
+    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x]
+                  : some ? io.bin_list[blockIdx.x] : (int)blockIdx.x;
     const int tid = threadIdx.x;
+    if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
+        if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
+        return;
+    }
     const long long t_begin = (long long)clock64();
     double* ghm = S.hm + (size_t)b * P.Hc;
     int32_t* q = S.queue + (size_t)b * P.K;
-    float* obs = io.obs ? io.obs + (size_t)b * io.obs_stride : nullptr;
+    float* obs = io.obs ? io.obs + (size_t)(some ? (int)blockIdx.x : b) * io.obs_stride : nullptr;
 
     stamp(io, b, 0);
     // stage the heightmap tile
@@ -769,8 +775,12 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
         if (tid == 0) {
             BinState* ps = S.bs + b;
-            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, 0, i);
-            ps->episode = 0;
+            // reset(): start over at episode 0.  reset_specific(): the env's own reset, i.e. the
+            // item creator moves on to its next trajectory (IRcreator.py:86-92) and the running
+            // episode is dropped without statistics (monitor.py reset)
+            const int ep = some ? ps->episode + 1 : 0;
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
+            ps->episode = ep;
             ps->cursor = P.K;
             ps->cur_item = -1;
             ps->nvalid = 0;
@@ -779,7 +789,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             ps->ep_len = 0;
             ps->ratio_acc = 0.0;
             ps->ep_reward = 0.0;
-            for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
+            if (!some) for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
         __syncthreads();

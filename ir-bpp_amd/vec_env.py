@@ -127,6 +127,15 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_reset(self._h, _ptr(obs), self._stream()), "irbpp_reset")
         return obs
 
+    def reset_bins(self, bins: torch.Tensor) -> torch.Tensor:
+        """PackingGame.reset of the listed bins only (distinct int32 indices on the device):
+        float32[len(bins), obs_len], row i = reset observation of bin ``bins[i]``."""
+        assert bins.dtype == torch.int32 and bins.is_cuda and bins.dim() == 1
+        obs = torch.empty((bins.numel(), self.obs_len), dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.irbpp_reset_bins(self._h, _ptr(bins), int(bins.numel()), _ptr(obs), self._stream()),
+                   "irbpp_reset_bins")
+        return obs
+
     def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
         """actions: int32[N] on the device.  Returns (obs, reward f64[N], done u8[N]) device tensors;
         the reward/done tensors are views of buffers overwritten by the next step."""
@@ -208,6 +217,12 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_debug_phase_cycles(self._h, _ptr(self._cycles)), "irbpp_debug_phase_cycles")
         return self._cycles
 
+    def kernel_info(self):
+        """Tooling: (LDS bytes per workgroup, name of the transition-kernel build that launches)."""
+        lds, wide = C.c_int32(0), C.c_int32(0)
+        _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(wide)), "irbpp_debug_kernel_info")
+        return lds.value, "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
+
     def enable_kernel_timing(self, capacity: int) -> None:
         """Tooling: bracket the transition kernel of the next ``capacity`` launches with HIP events
         on their stream (``capacity`` 0 switches it off)."""
@@ -272,8 +287,10 @@ class GpuVecEnv(object):
 
     closed = False
 
-    def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0", **env_kw):
+    def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0",
+                 allow_early_resets: bool = True, **env_kw):
         self.env = GpuPackingEnv(shapes, sequences, num_envs, device=device, **env_kw)
+        self.allow_early_resets = allow_early_resets                       # Monitor's flag (monitor.py:44-48)
         self.num_envs = num_envs
         self.device = self.env.device
         self.obs_len = self.env.obs_len
@@ -326,6 +343,20 @@ class GpuVecEnv(object):
         ``np.array`` after ``.cpu()``, and callers that accept tensors can skip the round trip."""
         return self.env.get_action_candidates(self._actions_to_device(order_actions))
 
+    def reset_specific(self, indexs) -> torch.Tensor:
+        """shmem_vec_env.py:113-117: reset the listed envs only; their observations in list order."""
+        if not self.allow_early_resets:                                    # every env is mid-episode: auto-reset
+            raise RuntimeError("Tried to reset an environment before done. If you want to allow early "
+                               "resets, pass allow_early_resets=True")     # monitor.py:45-46
+        if self.waiting_step:
+            self.step_wait()
+        idx = np.asarray(list(indexs), dtype=np.int32).reshape(-1)
+        if len(np.unique(idx)) != len(idx) or (len(idx) and (idx.min() < 0 or idx.max() >= self.num_envs)):
+            raise ValueError("reset_specific needs distinct env indices in [0, num_envs)")
+        obs = self.env.reset_bins(torch.from_numpy(idx).to(self.device))
+        self.env.check_device_error()
+        return obs
+
     def close(self):
         if not self.closed:
             self.env.close()
@@ -343,7 +374,7 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
     if shapes is None:
         shapes = shape_set_from_reference(args.shotInfo, args.infoDict)
     dev = args.device if isinstance(args.device, (str, torch.device)) else f"cuda:{int(args.device)}"
-    envs = GpuVecEnv(shapes, args.sequences, args.num_processes, device=dev,
+    envs = GpuVecEnv(shapes, args.sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
                      resolutionA=args.resolutionA, resolutionH=args.resolutionH,
                      resolutionZ=getattr(args, "resolutionZ", 0.01),
                      bin_dimension=tuple(getattr(args, "bin_dimension", BIN_DIMENSION)),

@@ -264,6 +264,13 @@ class OracleVecEnv(object):
         self.rewards = [[] for _ in range(self.num_envs)]
         return np.array([e.reset() for e in self.envs])
 
+    def reset_specific(self, indexs):
+        """shmem_vec_env.py:113-117: ``env.reset()`` of the listed workers; Monitor.reset drops the
+        rewards of the abandoned episode (monitor.py:47-56)."""
+        for i in indexs:
+            self.rewards[i] = []
+        return np.array([self.envs[i].reset() for i in indexs])
+
     def get_action_candidates(self, order_actions):
         return np.array([e.get_action_candidates(int(a)) for e, a in zip(self.envs, order_actions)])
 

@@ -422,6 +422,65 @@ def test_make_vec_envs_with_reference_style_args():
     envs.close()
 
 
+@pytest.mark.parametrize("k", [1, 3])
+def test_reset_specific_matches_per_env_reset(k):
+    """ShmemVecEnv.reset_specific (shmem_vec_env.py:113-117): the listed envs start their next
+    trajectory with an empty bin, the others are untouched, no episode statistics are recorded."""
+    shapes = synthetic.blockout_shapes(24, seed=5)
+    seqs = synthetic.make_sequences(24, n_traj=64, length=50, seed=6)
+    n = 7
+    genv = GpuVecEnv(shapes, seqs, n, device=DEV, bufferSize=k)
+    oenv = OracleVecEnv(n, shapes, seqs, bufferSize=k)
+    gobs, oobs = genv.reset(), _f32(oenv.reset())
+    np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+
+    def advance(steps, gobs, oobs):
+        for _ in range(steps):
+            if k > 1:
+                order = np.arange(n) % k
+                gloc = genv.get_action_candidates(order)
+                oloc = _f32(oenv.get_action_candidates(order))
+                np.testing.assert_array_equal(gloc.cpu().numpy(), oloc)
+            else:
+                gloc, oloc = gobs, oobs
+            act = np.array([minz_action(o, S) for o in oloc])
+            gobs, grew, gdone, ginfo = genv.step(act)
+            oobs, orew, odone, oinfo = oenv.step(act)
+            oobs = _f32(oobs)
+            np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+            np.testing.assert_array_equal(gdone, odone)
+            for i in range(n):
+                if odone[i]:
+                    assert ginfo[i]["episode"]["l"] == oinfo[i]["episode"]["l"]
+                    assert abs(ginfo[i]["episode"]["r"] - oinfo[i]["episode"]["r"]) < 1e-5
+        return gobs, oobs
+
+    gobs, oobs = advance(9, gobs, oobs)
+    before = genv.env.episode_totals().cpu().numpy().copy()
+    for idxs in ([4, 1], [6], []):
+        sub = genv.reset_specific(idxs)
+        assert tuple(sub.shape) == (len(idxs), genv.obs_len)
+        if not idxs:
+            continue
+        ref = _f32(oenv.reset_specific(idxs))
+        np.testing.assert_array_equal(sub.cpu().numpy(), ref)
+        for j, i in enumerate(idxs):
+            gobs[i] = sub[j]
+            oobs[i] = ref[j]
+    np.testing.assert_array_equal(genv.env.episode_totals().cpu().numpy(), before)    # nothing recorded
+    hm = genv.env.get_heightmaps().cpu().numpy()
+    assert (hm[[1, 4, 6]] == 0).all() and (hm[[0, 2, 3, 5]] != 0).any()
+    advance(40, gobs, oobs)                                # incl. whole episodes after the partial reset
+    with pytest.raises(ValueError):
+        genv.reset_specific([2, 2])
+    with pytest.raises(ValueError):
+        genv.reset_specific([n])
+    strict = GpuVecEnv(shapes, seqs, 2, device=DEV, allow_early_resets=False)
+    strict.reset()
+    with pytest.raises(RuntimeError):
+        strict.reset_specific([0])
+
+
 def test_abi_rejects_calls_out_of_order():
     """Error behaviour of the boundary: status codes instead of crashes."""
     import ctypes as C
@@ -439,6 +498,8 @@ def test_abi_rejects_calls_out_of_order():
     assert lib.irbpp_step(h, p(act), p(obs), None, None) == -3    # step before reset
     assert lib.irbpp_get_action_candidates(h, p(act), p(obs), None) == -3
     assert lib.irbpp_reset(h, None, None) == -1                   # IRBPP_ERR_ARG
+    assert lib.irbpp_reset_bins(h, p(act), 2, p(obs), None) == -3  # before the first reset
+    assert lib.irbpp_reset_bins(h, p(act), 3, p(obs), None) == -1  # more bins than the env has
     bad = np.zeros(4, dtype=np.int32)
     assert lib.irbpp_load_sequences(h, bad.ctypes.data_as(_lib.c_i32_p), 0, 4) == -1
     assert lib.irbpp_destroy(h) == 0
