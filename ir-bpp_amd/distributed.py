@@ -62,7 +62,11 @@ def max_over_ranks(value: float, device) -> float:
 
 
 def barrier(device=None):
+    """Local device work done, every rank arrived, device idle again (the bracket bench.py times between)."""
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    if on_gpu:
+        torch.cuda.synchronize(device)
     if _active():
         dist.barrier()
-    if device is not None and torch.device(device).type == "cuda":
+    if on_gpu:
         torch.cuda.synchronize(device)

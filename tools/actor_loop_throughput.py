@@ -55,7 +55,27 @@ out = {"bins": a.bins, "capacity_per_env": a.capacity, "replay_bytes": int(mem.s
 env.close()
 
 if a.loop_bins:
-    from oracle.replay import ReplayMemory as PerEnvReplay
+    class PerEnvReplay(object):
+        """Stand-in with the reference's structure and cost profile (memory.py:55-70,117-121): numpy ring
+        + a sum tree walked leaf-to-root in Python, one object per env.  Not a checker, just a clock."""
+
+        def __init__(self, cap, obs_len):
+            self.cap, self.i, self.t, self.max = cap, 0, 0, 1.0
+            self.tree = np.zeros(2 * cap - 1, dtype=np.float32)
+            self.states = np.zeros((cap, obs_len), dtype=np.float32)
+            self.meta = np.zeros((cap, 4), dtype=np.float32)
+
+        def append(self, state, action, reward, terminal):
+            self.states[self.i] = state
+            self.meta[self.i] = (self.t, action, reward, not terminal)
+            k = self.i + self.cap - 1
+            self.tree[k] = self.max
+            while k:
+                k = (k - 1) // 2
+                self.tree[k] = self.tree[2 * k + 1] + self.tree[2 * k + 2]
+            self.i = (self.i + 1) % self.cap
+            self.t = 0 if terminal else self.t + 1
+
     n = a.loop_bins
     venv = GpuVecEnv(shapes, seqs, n, device="cuda:0", **kw)
     mems = [PerEnvReplay(a.capacity, venv.obs_len) for _ in range(n)]
