@@ -131,16 +131,22 @@ def test_approx_poly_dp_is_an_ordered_subset_within_epsilon(seed):
             src = [tuple(int(v) for v in p) for p in c.reshape(-1, 2)]
             out = [tuple(int(v) for v in p) for p in C.approx_poly_dp(c, eps, True).reshape(-1, 2)]
             assert 1 <= len(out) <= len(src)
-            # subset, in the cyclic order of the source
-            pos, j = [], 0
-            start = src.index(out[0])
-            rot = src[start:] + src[:start]
-            for p in out:
-                while rot[j] != p:
+            # subset, in the cyclic order of the source (thin parts are walked both ways, so points repeat:
+            # try every occurrence of the first output point as the rotation origin; greedy matching is exact
+            # for a fixed origin)
+            def embeds(start):
+                rot, j = src[start:] + src[:start], 0
+                for p in out:
+                    while j < len(rot) and rot[j] != p:
+                        j += 1
+                    if j == len(rot):
+                        return False
                     j += 1
-                    assert j < len(rot), "approximation is not an ordered subset of the contour"
-                pos.append(j)
-            # Douglas-Peucker guarantee: every source point within eps of the closed result polygon
+                return True
+            assert any(embeds(k) for k, p in enumerate(src) if p == out[0]), "not an ordered subset of the contour"
+            # Douglas-Peucker keeps every source point within eps of its slice's chord; the clean-up pass then
+            # drops vertices closer than eps/sqrt(2) to the chord of their neighbours (approx.cpp), so the
+            # closed result polygon stays within eps * (1 + 1/sqrt(2)) of every source point
             edges = list(zip(out, out[1:] + out[:1]))
             for p in src:
-                assert min(_dist_point_segment(p, a, b) for a, b in edges) <= eps + 1e-9
+                assert min(_dist_point_segment(p, a, b) for a, b in edges) <= eps * (1 + 0.5 ** 0.5) + 1e-9
