@@ -1,0 +1,52 @@
+"""bench.py's bookkeeping that does not need a GPU: the algorithmic-bytes formula of SURVEY.md 8(d)
+and the host-core count the CPU baseline is allowed to use."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+
+def test_algorithmic_bytes_follow_the_survey_formula():
+    shapes, _, kw = bench.make_workload("blockout")
+    hc, S = 32 * 32, 500
+    f = np.array([[t[0].size for t in per_rot] for per_rot in shapes.tables], dtype=np.float64)
+    reads = 8 * hc + 5 * f.sum(1).mean() + 5 * f.mean() + 4 + 4
+    writes = 8 * hc + 4 * (5 * S + 9 + hc) + 5
+    assert bench.algorithmic_bytes_per_step(shapes, hc, 1) == reads + writes
+    # SURVEY 8(d) works cfg 2 out at ~25.9 KB with a float32 heightmap and F ~ 12x12 per rotation; the
+    # synthetic polycubes average ~98 cells per rotation, and the float64 master tile adds 2*4*Hc
+    assert 23_000 < bench.algorithmic_bytes_per_step(shapes, hc, 1) - 8 * hc < 26_000
+    # buffered placements also write the order observation [k ids | heightmap]
+    k10 = bench.algorithmic_bytes_per_step(shapes, hc, 10)
+    assert k10 - bench.algorithmic_bytes_per_step(shapes, hc, 1) == 4 * 9 + 4 * (10 + hc)
+
+
+def test_every_workload_builds_and_names_its_config():
+    for name, n_rot, res_h in (("blockout", 4, 0.01), ("blockout_r8", 8, 0.01), ("blockout_k10", 4, 0.01),
+                               ("general", 8, 0.01), ("abc_fine", 8, 0.005), ("cube", 2, 0.01)):
+        shapes, seqs, kw = bench.make_workload(name)
+        assert shapes.n_rot == n_rot and kw["resolutionH"] == res_h
+        assert seqs.dtype == np.int32 and seqs.max() < shapes.n_shapes
+        shapes.validate(kw["resolutionH"], kw["resolutionA"])
+    assert bench.make_workload("blockout_k10")[2]["bufferSize"] == 10
+
+
+def test_usable_cores_is_bounded_by_affinity():
+    n = bench.usable_cores()
+    assert 1 <= n <= len(os.sched_getaffinity(0))
+
+
+def test_committed_bench_line_keeps_the_contract():
+    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "bench_default.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in line, key
+    r = line["roofline"]
+    assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
+    assert abs(line["value"] - 4096 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1.0
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
