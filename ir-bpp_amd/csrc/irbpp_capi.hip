@@ -61,8 +61,16 @@ int dev_upload(irbpp_env* env, const T** out, const T* host, size_t count) {
 inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np.round(x, 6)
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
-// dynamic-LDS carve-up of the transition kernel
+inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
+
+// dynamic-LDS carve-up of the transition kernel (and the division constants of its grid sizes)
 void layout_lds(Params& P, int want_slots) {
+    P.mg_hy = div_magic(P.Hy);
+    P.mg_step = div_magic(P.step);
+    P.mg_ay = div_magic(P.Ay);
+    P.mg_ax = div_magic(P.Ax);
+    P.mg_ac = div_magic(P.AC);
+    P.mg_mbw = div_magic(P.mb_w);
     P.nslot = want_slots > 0 ? want_slots : 64;                       // candidate starts traced per pass
     if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
     if (P.nslot < 16) P.nslot = 16;

@@ -60,7 +60,7 @@ struct alignas(64) BinState {
     int32_t order_action;  // buffer slot chosen by get_action_candidates (binPhy.py:168)
     int32_t item_idx;      // items packed in this episode (info['counter'])
     int32_t ep_len;        // steps in this episode (Monitor 'l')
-    int32_t pad0;
+    int32_t traj_row;      // row of the current episode's trajectory in seq: (traj_start + g + e*G) mod n_traj
     double ratio_acc;      // sequential sum of packed volumes (get_ratio, binPhy.py:149-153)
     double ep_reward;      // sequential sum of rewards (Monitor 'r')
     double pad1[2];
@@ -99,6 +99,9 @@ struct Params {
     // mb[pi][pj] = max of the b x b heightmap block at (pi*step, pj*step) replaces the cell list:
     // max over the tile of (H - B) == (max over the tile of H) - B exactly (rounding is monotone).
     int32_t block_b, mb_w, mb_h, o_mb;
+    // Division by the runtime grid sizes costs ~25 VALU instructions each; n / d == umulhi(n, mg_d) exactly
+    // for n, d < 2^16 with mg_d = floor(2^32 / d) + 1 (d >= 2), see fdiv() in irbpp_kernels.hip.
+    uint32_t mg_hy, mg_step, mg_ay, mg_ax, mg_ac, mg_mbw;
 };
 
 enum Mode : int32_t {

@@ -96,27 +96,52 @@ __device__ inline int block_scan_flag(bool flag, int* red, int& total) {
 
 // LoadItemCreator.generate_item (IRcreator.py:97-103) on the pre-drawn trajectories; the
 // trajectory of global bin g in its e-th episode is (traj_start + g + e*global_bins) % n_traj.
-__device__ inline int fetch_item(const Params& P, const Tables& T, const State& S, int b, int episode, int cursor) {
-    if (cursor >= T.seq_len) return -1;
+// The 64-bit modulo runs once per episode (trajectory_row, kept in BinState::traj_row), not per item.
+__device__ inline int trajectory_row(const Params& P, const Tables& T, int b, int episode) {
     long long row = (long long)P.traj_start + P.goff + b + (long long)episode * P.gbins;
     row %= T.n_traj;
     if (row < 0) row += T.n_traj;
-    const int id = T.seq[row * T.seq_len + cursor];
+    return (int)row;
+}
+__device__ inline int fetch_item(const Tables& T, const State& S, int row, int cursor) {
+    if (cursor >= T.seq_len) return -1;
+    const int id = T.seq[(long long)row * T.seq_len + cursor];
     if (id >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); return -1; }
     return id < 0 ? -1 : id;
 }
 
+// n / d for 0 <= n < 2^16 and the runtime grid sizes 1 <= d < 2^16, without the ~25-instruction integer
+// division sequence: with m = floor(2^32 / d) + 1, m*d = 2^32 + e, 0 < e <= d, so
+// floor(n*m / 2^32) = floor(n/d + n*e / (d * 2^32)) = floor(n/d) because n*e < 2^32.  (m would overflow for d = 1.)
+__device__ __forceinline__ int fdiv(int n, int d, uint32_t m) {
+    return d == 1 ? n : (int)__umulhi((uint32_t)n, m);
+}
+
+// Kernel arguments that are used once, by one thread, at the end of a phase (step outputs, episode totals,
+// placement log, scheduling hints).  Read normally they are loaded at kernel entry together with
+// everything else -- as 8- and 16-dword tuples that do not fit the SGPR file and get spilled to VGPR
+// lanes and restored, tuple-wise, eleven times along the way (176 v_readlane for the six output
+// pointers alone).  Read through this laundered pointer to the kernarg segment they are scalar loads
+// right where they are needed.  Both transition kernels take (Params, Tables, State, StepIO, int).
+struct KernArgs { Params P; Tables T; State S; StepIO io; int mode; };
+typedef const __attribute__((address_space(4))) KernArgs* KernArgsPtr;
+__device__ __forceinline__ KernArgsPtr cold_args() {
+    KernArgsPtr p = (KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+
 // linear heightmap index (row*Hy + col) <-> LDS tile index in the phase-plane layout
 __device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
-    const int row = g / P.Hy, col = g - row * P.Hy;
-    const int X = row / P.step, ri = row - X * P.step;
-    const int Y = col / P.step, rj = col - Y * P.step;
+    const int row = fdiv(g, P.Hy, P.mg_hy), col = g - row * P.Hy;
+    const int X = fdiv(row, P.step, P.mg_step), ri = row - X * P.step;
+    const int Y = fdiv(col, P.step, P.mg_step), rj = col - Y * P.step;
     return (ri * P.step + rj) * P.AC + X * P.Ay + Y;
 }
 __device__ __forceinline__ int linear_of_tile(const Params& P, int t) {
-    const int plane = t / P.AC, rem = t - plane * P.AC;
-    const int X = rem / P.Ay, Y = rem - X * P.Ay;
-    const int ri = plane / P.step, rj = plane - ri * P.step;
+    const int plane = fdiv(t, P.AC, P.mg_ac), rem = t - plane * P.AC;
+    const int X = fdiv(rem, P.Ay, P.mg_ay), Y = rem - X * P.Ay;
+    const int ri = fdiv(plane, P.step, P.mg_step), rj = plane - ri * P.step;
     return (X * P.step + ri) * P.Hy + Y * P.step + rj;
 }
 
@@ -211,7 +236,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             L.taskidx[t] = (uint16_t)idx;
         }
     }
-    const int X = tid / P.Ay, Y = tid % P.Ay;
+    const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
     constexpr int IPT = CONTOUR_IPT;                 // (image, row) pairs per thread
     constexpr int IMGS = IPT * (BLOCK / 16);         // level images per batch
@@ -436,7 +461,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                                    const Lds& L, int b, int item, bool debug_out) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
-    const int X = tid / Ay, Y = tid % Ay;
+    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
     // All R ShapeRots of the item in ONE coalesced load into LDS (the scratch region is free while the
     // tile is in use only if it does not alias it -- it does, so they go to the front of L.posz's
@@ -448,7 +473,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
     if (P.block_b > 0) {                         // block-max grid of the current tile, plane offsets built incrementally
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
-            const int pi = t / P.mb_w, pj = t - pi * P.mb_w;
+            const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
             const double* base = L.hm + pi * Ay + pj;
             double m = -1e300;
             int ri = 0, xi = 0;
@@ -556,8 +581,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const bool valid = vs[r];
         if (tid < AC) {
             if (debug_out) {
-                io.posz_out[((size_t)b * R + r) * AC + tid] = z;
-                io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
+                const KernArgsPtr ka = cold_args();
+                ka->io.posz_out[((size_t)b * R + r) * AC + tid] = z;
+                ka->io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
             }
             L.posz[r * AC + tid] = valid ? z : 1e3;
             int code = 255;
@@ -599,7 +625,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
-    const int X = tid / Ay, Y = tid % Ay;
+    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
@@ -618,7 +644,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     uint32_t* okey = keys + R * AC;                 // [S]
     int n = 0;
     {
-        const int cx = tid / Ax, cy = tid % Ax;     // col-major walk: x = column (ly), y = row (lx)
+        const int cx = fdiv(tid, Ax, P.mg_ax), cy = tid - cx * Ax;     // col-major walk: x = column (ly), y = row (lx)
         for (int r = 0; r < R; ++r) {
             const bool flag = tid < AC && ((L.vmask[r * 16 + cy] >> cx) & 1u);
             int total;
@@ -779,8 +805,10 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             // item creator moves on to its next trajectory (IRcreator.py:86-92) and the running
             // episode is dropped without statistics (monitor.py reset)
             const int ep = some ? ps->episode + 1 : 0;
-            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
+            const int trow = trajectory_row(P, T, b, ep);
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, i);
             ps->episode = ep;
+            ps->traj_row = trow;
             ps->cursor = P.K;
             ps->cur_item = -1;
             ps->nvalid = 0;
@@ -789,7 +817,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             ps->ep_len = 0;
             ps->ratio_acc = 0.0;
             ps->ep_reward = 0.0;
-            if (!some) for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
+            if (!some) for (int i = 0; i < 4; ++i) cold_args()->S.totals[(size_t)b * 4 + i] = 0.0;
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
         __syncthreads();
@@ -835,6 +863,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         }
         if (tid == 0) {
             BinState* ps = S.bs + b;                                 // field-wise: no struct copy (keeps scratch at 0)
+            const KernArgsPtr ka = cold_args();                      // outputs, totals, log: loaded here, not at entry
             if (ok) {
                 const double vol = T.volume[item0];
                 const double reward = (vol / P.bin_vol) * 10.0;      // binPhy.py:321-322
@@ -842,41 +871,43 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 const int epl = ps->ep_len + 1;
                 const int cursor = ps->cursor;
                 const int slot = ps->item_idx;                       // self.packed.append(...) (binPhy.py:296)
-                if (S.log_meta && slot < S.log_cap) {
-                    S.log_meta[(size_t)b * S.log_cap + slot] = (uint32_t)item0 | ((uint32_t)rot << 16) |
+                if (ka->S.log_meta && slot < ka->S.log_cap) {
+                    ka->S.log_meta[(size_t)b * ka->S.log_cap + slot] = (uint32_t)item0 | ((uint32_t)rot << 16) |
                                                                 ((uint32_t)lx << 20) | ((uint32_t)ly << 24);
-                    S.log_z[(size_t)b * S.log_cap + slot] = z;
+                    ka->S.log_z[(size_t)b * ka->S.log_cap + slot] = z;
                 }
                 ps->ep_reward = epr;
                 ps->ep_len = epl;
                 ps->item_idx += 1;
                 ps->ratio_acc += vol;
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
-                q[P.K - 1] = fetch_item(P, T, S, b, ps->episode, cursor);   // generate_item (:325)
+                q[P.K - 1] = fetch_item(T, S, ps->traj_row, cursor);        // generate_item (:325)
                 ps->cursor = cursor + 1;
-                if (io.reward) io.reward[b] = reward;
-                if (io.done) io.done[b] = 0;
-                if (io.counter) io.counter[b] = -1;
-                if (io.ratio) io.ratio[b] = -1.0;
-                if (io.ep_reward) io.ep_reward[b] = epr;
-                if (io.ep_len) io.ep_len[b] = epl;
+                if (ka->io.reward) ka->io.reward[b] = reward;
+                if (ka->io.done) ka->io.done[b] = 0;
+                if (ka->io.counter) ka->io.counter[b] = -1;
+                if (ka->io.ratio) ka->io.ratio[b] = -1.0;
+                if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
+                if (ka->io.ep_len) ka->io.ep_len[b] = epl;
             } else {
                 const int counter = ps->item_idx;                    // info (binPhy.py:306-309)
                 const double ratio = ps->ratio_acc / P.bin_vol;      // get_ratio (:149-153)
                 const double epr = ps->ep_reward + 0.0;
                 const int epl = ps->ep_len + 1;
-                if (io.reward) io.reward[b] = 0.0;
-                if (io.done) io.done[b] = 1;
-                if (io.counter) io.counter[b] = counter;
-                if (io.ratio) io.ratio[b] = ratio;
-                if (io.ep_reward) io.ep_reward[b] = epr;
-                if (io.ep_len) io.ep_len[b] = epl;
-                double* tot = S.totals + (size_t)b * 4;
+                if (ka->io.reward) ka->io.reward[b] = 0.0;
+                if (ka->io.done) ka->io.done[b] = 1;
+                if (ka->io.counter) ka->io.counter[b] = counter;
+                if (ka->io.ratio) ka->io.ratio[b] = ratio;
+                if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
+                if (ka->io.ep_len) ka->io.ep_len[b] = epl;
+                double* tot = ka->S.totals + (size_t)b * 4;
                 tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
                 // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset
                 const int ep = ps->episode + 1;
+                const int trow = trajectory_row(P, T, b, ep);
                 ps->episode = ep;
-                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(P, T, S, b, ep, i);
+                ps->traj_row = trow;
+                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, i);
                 ps->cursor = P.K;
                 ps->item_idx = 0;
                 ps->ratio_acc = 0.0;
@@ -908,16 +939,18 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         const long long dt = (long long)clock64() - t_begin;
         const int c = dt > 0x7fffffffLL ? 0x7fffffff : (int)dt;
         int hint = c;
+        const KernArgsPtr ka = cold_args();
         if (P.K == 1 && (mode == MODE_STEP || mode == MODE_RESET)) {
+            int32_t* item_cost = ka->S.item_cost;
             if (do_observe && obs_item >= 0) {
-                const int old = S.item_cost[obs_item];               // racy read-modify-write: a hint only
-                S.item_cost[obs_item] = old ? old + ((c - old) >> 3) : c;
+                const int old = item_cost[obs_item];                 // racy read-modify-write: a hint only
+                item_cost[obs_item] = old ? old + ((c - old) >> 3) : c;
             }
-            const int nxt = fetch_item(P, T, S, b, S.bs[b].episode, S.bs[b].cursor);
-            const int m = nxt >= 0 ? S.item_cost[nxt] : 0;
+            const int nxt = fetch_item(T, S, S.bs[b].traj_row, S.bs[b].cursor);
+            const int m = nxt >= 0 ? item_cost[nxt] : 0;
             if (m) hint = m;
         }
-        S.cost[b] = hint;
+        ka->S.cost[b] = hint;
     }
 }
 
@@ -964,7 +997,7 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     const Lds L = carve_lds(smem, P);
     const int b = blockIdx.x, tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ay = P.Ay;
-    const int X = tid / Ay, Y = tid % Ay;
+    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     const double* ghm = S.hm + (size_t)b * P.Hc;
     for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     __syncthreads();
@@ -992,9 +1025,11 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     if (tid == 0) {                      // np.argmin: the first minimum in C order (rot, X, Y)
         for (int w = 1; w < WAVES; ++w)
             if (L.redd[w] < best || (L.redd[w] == best && L.redi[4 + w] < best_i)) { best = L.redd[w]; best_i = L.redi[4 + w]; }
-        io.heur_out[b * 3 + 0] = best_i / AC;
-        io.heur_out[b * 3 + 1] = (best_i % AC) / Ay;
-        io.heur_out[b * 3 + 2] = best_i % Ay;
+        const int hr = fdiv(best_i, AC, P.mg_ac), hrem = best_i - hr * AC;
+        const int hx = fdiv(hrem, Ay, P.mg_ay);
+        io.heur_out[b * 3 + 0] = hr;
+        io.heur_out[b * 3 + 1] = hx;
+        io.heur_out[b * 3 + 2] = hrem - hx * Ay;
     }
 }
 
