@@ -271,7 +271,11 @@ def main():
         prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
         if os.path.exists(prof):
             try:
+                # PMC passes (profiles/r01_pmc_hbm.json) were taken at 4096 bins per launch; bins are
+                # independent, so the traffic of a launch scales with their number
                 traffic = json.load(open(prof)).get(a.workload, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:
+                    traffic = traffic * a.bins / 4096.0
             except Exception:
                 traffic = None
         out = {
