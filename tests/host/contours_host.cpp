@@ -1,0 +1,66 @@
+// Host harness (test infrastructure): compiles the lane-serial device routines of
+// ir-bpp_amd/csrc/contours_device.h -- candidate starts, border tracing, Douglas-Peucker + convexity --
+// with g++ so that the CPU test-suite can run the very code the GPU executes against the oracle on
+// thousands of images.  The wave-cooperative variant needs real lanes and stays a GPU test.
+#include <stdint.h>
+#include <string.h>
+
+// the device header includes <hip/hip_runtime.h>: tests/host/stub/ holds an empty one, the few names used follow
+#define __device__
+#define __forceinline__ inline
+static inline int __ffs(int v) { return __builtin_ffs(v); }
+static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline unsigned atomicOr(uint32_t* p, uint32_t v) { const unsigned o = *p; *p |= v; return o; }
+// cross-lane builtins appear only in the cooperative routine, which is compiled but never called here
+struct { unsigned x; } threadIdx = {0};
+#define __builtin_amdgcn_readlane(v, l) (v)
+#define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) (v)
+#define __shfl(v, l) (v)
+
+#include "../../ir-bpp_amd/csrc/contours_device.h"
+
+using namespace irbpp;
+
+static void transpose(const uint16_t* rows, uint16_t* cols) {
+    for (int x = 0; x < 16; ++x) {
+        uint16_t c = 0;
+        for (int y = 0; y < 16; ++y) c |= (uint16_t)(((rows[y] >> x) & 1u) << y);
+        cols[x] = c;
+    }
+}
+
+extern "C" {
+
+// rows[16]: bit x of word y = pixel (x, y).  out[16] = candidate start bits per row.
+void host_start_candidates(const uint16_t* rows, uint32_t* out) {
+    for (int y = 0; y < 16; ++y) out[y] = start_candidates(rows[y], y ? rows[y - 1] : 0u);
+}
+
+// Returns trace_border's value; pts receives min(n, cap) points as x | y<<4.
+int host_trace_border(const uint16_t* rows, int x0, int y0, uint8_t* pts, int cap) {
+    uint16_t cols[16];
+    transpose(rows, cols);
+    return trace_border(rows, cols, x0, y0, pts, cap);
+}
+
+// approx_and_convex on a point list: vrows[16] gets the vertex bits; returns 1 ok, 0 stack overflow.
+int host_approx_and_convex(const uint8_t* pts, int count, int cap_stk, uint32_t* vrows) {
+    static uint8_t dst[4096];
+    static uint32_t stk[4096];
+    memset(vrows, 0, 16 * sizeof(uint32_t));
+    return approx_and_convex(pts, count, dst, stk, cap_stk, vrows) ? 1 : 0;
+}
+
+// contour_vertices with a slot of the given capacities: 0 ok, 1 overflow, 2 guard.
+int host_contour_vertices(const uint16_t* rows, int x0, int y0, int cap, int cap_stk, uint32_t* vrows) {
+    static uint8_t pts[4096], dst[4096];
+    static uint32_t stk[4096];
+    uint16_t cols[16];
+    transpose(rows, cols);
+    SlotMem m;
+    m.pts = pts; m.dst = dst; m.stk = stk; m.cap = cap; m.cap_stk = cap_stk;
+    return contour_vertices(rows, cols, x0, y0, m, vrows);
+}
+
+}  // extern "C"
