@@ -2,7 +2,8 @@
 tracing with run jumps, flattened Douglas-Peucker + convexity) compiled for the HOST by
 tests/host/contours_host.cpp and run against the oracle on thousands of 16x16 images: the code the
 GPU executes, checked without a GPU.  (The wave-cooperative Douglas-Peucker needs real lanes and is
-covered by the -m gpu tests.)"""
+covered by the -m gpu tests and, here, by tests/host/wave_host.cpp: 64 host threads in lockstep with
+every cross-lane operation emulated as a barrier-bracketed exchange.)"""
 import ctypes as C
 import os
 import shutil
@@ -19,6 +20,23 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "host", "contours_host.cpp")
 OUT = os.path.join(HERE, "host", "_build", "libcontours_host.so")
 u16p, u32p, u8p = C.POINTER(C.c_uint16), C.POINTER(C.c_uint32), C.POINTER(C.c_uint8)
+
+
+WAVE_SRC = os.path.join(HERE, "host", "wave_host.cpp")
+WAVE_OUT = os.path.join(HERE, "host", "_build", "libwave_host.so")
+
+
+@pytest.fixture(scope="module")
+def wave():
+    if shutil.which("g++") is None:
+        pytest.skip("no host compiler")
+    os.makedirs(os.path.dirname(WAVE_OUT), exist_ok=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-value",
+                    "-I", os.path.join(HERE, "host", "stub"), WAVE_SRC, "-o", WAVE_OUT], check=True)
+    lib = C.CDLL(WAVE_OUT)
+    lib.host_approx_and_convex_wave.argtypes = [u8p, C.c_int, u32p]
+    lib.host_approx_and_convex_wave.restype = C.c_int
+    return lib
 
 
 @pytest.fixture(scope="module")
@@ -146,3 +164,35 @@ def test_flattened_douglas_peucker_on_synthetic_polygons(host):
         assert host.host_approx_and_convex(arr, len(poly), 1360, vrows) == 1
         got = {(xx, yy) for yy in range(16) for xx in range(16) if (vrows[yy] >> xx) & 1}
         assert got == _oracle_vertices(poly)
+
+
+def test_wave_cooperative_douglas_peucker_in_lockstep_emulation(wave):
+    """approx_and_convex_wave: the routine the kernel uses for borders of more than 12 points."""
+    vrows = (C.c_uint32 * 16)()
+    done = 0
+    for img in _images(300, 60):
+        outer, _, _ = _oracle_outer(img)
+        for c in outer:
+            if not 1 <= len(c) <= 64 or (len(c) <= 12 and done % 4):      # mostly the long ones
+                continue
+            arr = (C.c_uint8 * len(c))(*[x | (y << 4) for x, y in c])
+            assert wave.host_approx_and_convex_wave(arr, len(c), vrows) == 1
+            got = {(x, y) for y in range(16) for x in range(16) if (vrows[y] >> x) & 1}
+            assert got == _oracle_vertices(c), c
+            done += 1
+    rng = np.random.RandomState(11)
+    for _ in range(40):                                               # arbitrary closed walks, up to the 64-point limit
+        n = rng.randint(1, 65)
+        x, y = rng.randint(0, 16), rng.randint(0, 16)
+        poly = [(x, y)]
+        while len(poly) < n:
+            x = int(np.clip(x + rng.randint(-1, 2), 0, 15))
+            y = int(np.clip(y + rng.randint(-1, 2), 0, 15))
+            if (x, y) != poly[-1]:
+                poly.append((x, y))
+        arr = (C.c_uint8 * len(poly))(*[px | (py << 4) for px, py in poly])
+        assert wave.host_approx_and_convex_wave(arr, len(poly), vrows) == 1
+        got = {(xx, yy) for yy in range(16) for xx in range(16) if (vrows[yy] >> xx) & 1}
+        assert got == _oracle_vertices(poly), poly
+        done += 1
+    assert done > 60                                                  # (each call is 64 threads and ~10^3 barriers)
