@@ -128,23 +128,90 @@ def _cpu_worker(args):
     return n, time.perf_counter() - t0
 
 
+def _shmem_worker(conn, name, rank, buf):
+    """Worker of the lockstep runner below: the command loop of wrapper/shmem_vec_env.py:120-157 --
+    receive an action over the pipe, step, auto-reset on done, write the observation into the shared
+    buffer, send (reward, done) back."""
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):
+        os.environ[var] = "1"
+    sys.path.insert(0, ROOT)
+    from oracle.c_oracle import COracleVecEnv
+    shapes, seqs, kw = make_workload(name)
+    env = COracleVecEnv(1, shapes, seqs, global_offset=rank, global_num=1 << 20, **kw)
+    dst = np.frombuffer(buf, dtype=np.float32)
+    dst[:] = env.reset()[0]
+    conn.send(None)
+    while True:
+        act = conn.recv()
+        if act is None:
+            break
+        obs, rew, done, _ = env.step([act])
+        dst[:] = obs[0]
+        conn.send((float(rew[0]), bool(done[0])))
+    conn.close()
+
+
+def cpu_lockstep_runner(name, cores, seconds):
+    """The reference's own process structure (envs.py:67-99 -> ShmemVecEnv): one worker process per
+    env, actions out and (reward, done) back over pipes, observations through shared memory, and ONE
+    parent that waits for every env before it chooses the next actions.  Online workloads only."""
+    ctx = mp.get_context("fork")
+    shapes, _, kw = make_workload(name)
+    hx = int(round(0.32 / kw["resolutionH"]))
+    obs_len = 5 * S + 9 + hx * hx
+    bufs = [ctx.RawArray("f", obs_len) for _ in range(cores)]
+    pipes, procs = [], []
+    for r in range(cores):
+        parent, child = ctx.Pipe()
+        p = ctx.Process(target=_shmem_worker, args=(child, name, r, bufs[r]), daemon=True)
+        p.start()
+        child.close()
+        pipes.append(parent)
+        procs.append(p)
+    for c in pipes:
+        c.recv()
+    views = [np.frombuffer(b, dtype=np.float32) for b in bufs]
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        for c, o in zip(pipes, views):                    # step_async (shmem_vec_env.py:70-74)
+            cand = o[:5 * S].reshape(S, 5)
+            v = cand[:, 4] == 1
+            c.send(int(np.argmin(np.where(v, cand[:, 3], np.inf))) if v.any() else 0)
+        for c in pipes:                                   # step_wait (:76-81)
+            c.recv()
+        n += cores
+    dt = time.perf_counter() - t0
+    for c in pipes:
+        c.send(None)
+    for p in procs:
+        p.join(timeout=5)
+    return n / dt, n
+
+
 def cpu_baseline(name, budget_s=15.0):
     """The oracle on the host cores, one process per bin: the plain-C restatement (the fair CPU
-    number) and, for reference, the numpy/python one (what the reference's own Python costs)."""
+    number) and, for reference, the numpy/python one (what the reference's own Python costs) and the
+    C one again under the reference's lockstep parent/worker structure."""
     cores = usable_cores()
     ctx = mp.get_context("fork")
     out = {}
-    for impl, secs in (("c", budget_s * 0.6), ("python", budget_s * 0.4)):
+    for impl, secs in (("c", budget_s * 0.5), ("python", budget_s * 0.3)):
         with ctx.Pool(cores) as pool:
             res = pool.map(_cpu_worker, [(name, r, secs, impl) for r in range(cores)])
         out[impl] = (sum(n / t for n, t in res), sum(n for n, _ in res), secs)
     rate, steps, secs = out["c"]
-    return {"value": rate, "unit": "placement-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{cores} processes x 1 bin x {secs:.0f} s of the plain-C oracle (oracle/c/), {steps} steps in "
-                      f"total, scripted MINZ policy in numpy (process-per-bin like shmem_vec_env; no physics, "
-                      f"which flatters the CPU side)",
-            "python_port": {"value": out["python"][0], "sample": f"same, numpy/python oracle, {out['python'][2]:.0f} s, "
-                                                                 f"{out['python'][1]} steps"}}
+    result = {"value": rate, "unit": "placement-steps/s", "cores": cores, "kind": "port",
+              "sample": f"{cores} processes x 1 bin x {secs:.0f} s of the plain-C oracle (oracle/c/), {steps} steps in "
+                        f"total, scripted MINZ policy in numpy (process-per-bin like shmem_vec_env; no physics, "
+                        f"which flatters the CPU side)",
+              "python_port": {"value": out["python"][0], "sample": f"same, numpy/python oracle, {out['python'][2]:.0f} s, "
+                                                                   f"{out['python'][1]} steps"}}
+    if make_workload(name)[2].get("bufferSize", 1) == 1:
+        lock_rate, lock_steps = cpu_lockstep_runner(name, cores, budget_s * 0.2)
+        result["lockstep_runner"] = {"value": lock_rate, "sample": f"plain-C oracle, {cores} worker processes + one parent "
+                                                                   f"choosing all actions per step over pipes/shared memory "
+                                                                   f"(the ShmemVecEnv structure), {lock_steps} steps"}
+    return result
 
 
 def main():
