@@ -55,3 +55,22 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_loader_fails_loudly_without_the_library(tmp_path, monkeypatch):
+    """No CPU fallback: a missing libirbpp_hip.so is an error, not a silent slow path."""
+    monkeypatch.setattr(_lib, "_lib", None)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        _lib.load(str(tmp_path / "libirbpp_hip.so"))
+
+
+def test_env_construction_without_a_gpu_raises(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    from irbpp_amd import synthetic
+    from irbpp_amd.vec_env import GpuVecEnv
+    shapes = synthetic.cube_shapes()
+    seqs = synthetic.make_sequences(shapes.n_shapes, 8, 10)
+    with pytest.raises(Exception):
+        GpuVecEnv(shapes, seqs, 2, device="cuda:0")
