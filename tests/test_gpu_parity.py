@@ -33,7 +33,7 @@ def _run_online(shapes, seqs, n, steps, **kw):
     ndone = 0
     for t in range(steps):
         act = genv.env.policy_minz(gobs).cpu().numpy()
-        ref_act = np.array([minz_action(o, S) for o in oobs])
+        ref_act = np.array([minz_action(o, kw.get("selectedAction", S)) for o in oobs])
         np.testing.assert_array_equal(act, ref_act)
         gobs, grew, gdone, ginfo = genv.step(act)
         oobs, orew, odone, oinfo = oenv.step(act)
@@ -72,6 +72,20 @@ def test_online_blockout_matches_oracle():
 def test_online_general_r8_matches_oracle():
     sh = synthetic.general_shapes(n_shapes=24, n_rot=8, seed=1)
     assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 64, 60, seed=9), 5, 30) >= 3
+
+
+def test_online_coarse_action_grid_matches_oracle():
+    """resolutionA = 0.04: an 8x8 action grid (stepSize 4), i.e. lane groups are not image rows."""
+    sh = synthetic.cube_shapes()
+    assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 64, 60, seed=21), 5, 30, resolutionA=0.04) >= 1
+
+
+def test_online_odd_geometry_matches_oracle():
+    """A 0.32 x 0.24 m bin (32x24 heightmap, 16x12 action grid: no power of two for the reciprocal-multiply
+    index arithmetic to hide behind), S = 120 candidates, 2 cm height levels."""
+    sh = synthetic.cube_shapes()
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 60, seed=33)
+    assert _run_online(sh, seqs, 6, 40, bin_dimension=(0.32, 0.24, 0.30), selectedAction=120, resolutionZ=0.02) >= 2
 
 
 def test_online_fine_heightmap_matches_oracle():
