@@ -3,7 +3,7 @@
 TEST INFRASTRUCTURE ONLY.  Nothing under ``oracle/`` is product code: it may be
 imported by ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg
 of ``bench.py`` -- as the checker, never as the thing measured or shipped.  The
-product (``ir-bpp_amd/``) never imports it and fails loudly without its HIP
+product (``irbpp_amd/``) never imports it and fails loudly without its HIP
 library.
 
 It restates, line by line, the reference's no-physics branch of

@@ -1,5 +1,5 @@
 // Host harness (test infrastructure): compiles the lane-serial device routines of
-// ir-bpp_amd/csrc/contours_device.h -- candidate starts, border tracing, Douglas-Peucker + convexity --
+// irbpp_amd/csrc/contours_device.h -- candidate starts, border tracing, Douglas-Peucker + convexity --
 // with g++ so that the CPU test-suite can run the very code the GPU executes against the oracle on
 // thousands of images.  The wave-cooperative variant needs real lanes and stays a GPU test.
 #include <stdint.h>
@@ -18,7 +18,7 @@ struct { unsigned x; } threadIdx = {0};
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) (v)
 #define __shfl(v, l) (v)
 
-#include "../../ir-bpp_amd/csrc/contours_device.h"
+#include "../../irbpp_amd/csrc/contours_device.h"
 
 using namespace irbpp;
 

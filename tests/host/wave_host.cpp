@@ -1,5 +1,5 @@
 // Host harness (test infrastructure): the wave-cooperative Douglas-Peucker of
-// ir-bpp_amd/csrc/contours_device.h run on the CPU by 64 threads in lockstep.  Every cross-lane
+// irbpp_amd/csrc/contours_device.h run on the CPU by 64 threads in lockstep.  Every cross-lane
 // operation the routine uses (v_readlane, v_readfirstlane, ds_bpermute via __shfl, and the DPP
 // controls of its max-reduction) is an exchange through a shared array between two barriers, so the
 // routine's wave-uniform control flow is executed exactly as a wave64 would.
@@ -46,7 +46,7 @@ static inline int emu_dpp(int old, int v, int ctrl, int row_mask) {
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) emu_dpp((old), (v), (ctrl), (rm))
 #define __shfl(v, l) xchg((v), (l))
 
-#include "../../ir-bpp_amd/csrc/contours_device.h"
+#include "../../irbpp_amd/csrc/contours_device.h"
 
 extern "C" int host_approx_and_convex_wave(const uint8_t* pts, int count, uint32_t* vrows) {
     memset(vrows, 0, 16 * sizeof(uint32_t));

@@ -49,7 +49,7 @@ def test_create_rejects_bad_config(lib):
 
 
 def test_product_never_imports_oracle():
-    pkg = os.path.join(ROOT, "ir-bpp_amd")
+    pkg = os.path.join(ROOT, "irbpp_amd")
     for dirpath, _, files in os.walk(pkg):
         for f in files:
             if f.endswith((".py", ".hip", ".h")):

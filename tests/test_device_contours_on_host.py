@@ -1,4 +1,4 @@
-"""The lane-serial device routines of ir-bpp_amd/csrc/contours_device.h (candidate starts, border
+"""The lane-serial device routines of irbpp_amd/csrc/contours_device.h (candidate starts, border
 tracing with run jumps, flattened Douglas-Peucker + convexity) compiled for the HOST by
 tests/host/contours_host.cpp and run against the oracle on thousands of 16x16 images: the code the
 GPU executes, checked without a GPU.  (The wave-cooperative Douglas-Peucker needs real lanes and is
