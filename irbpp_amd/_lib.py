@@ -60,11 +60,13 @@ SIGNATURES = {
 _lib = None
 
 
-def load(path: str = LIB_PATH) -> C.CDLL:
-    """dlopen the HIP library and bind every declared symbol (raises if anything is missing)."""
+def load(path: str = "") -> C.CDLL:
+    """dlopen the HIP library and bind every declared symbol (raises if anything is missing).
+    IRBPP_LIBRARY selects another build of the same sources (the tooling variant of build.py)."""
     global _lib
     if _lib is not None:
         return _lib
+    path = path or os.environ.get("IRBPP_LIBRARY", "") or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -23,21 +23,28 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built on this machine")
 
 
-def needs_build() -> bool:
-    if not os.path.exists(LIB_PATH):
+def needs_build(path: str = LIB_PATH) -> bool:
+    if not os.path.exists(path):
         return True
-    t = os.path.getmtime(LIB_PATH)
+    t = os.path.getmtime(path)
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/irbpp_capi.hip (which includes the kernels) into libirbpp_hip.so."""
-    if not force and not needs_build():
-        return LIB_PATH
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", LIB_PATH]
+ABLATE_LIB_PATH = os.path.join(PKG_DIR, "libirbpp_hip_ablate.so")
+
+
+def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
+    """Compile csrc/irbpp_capi.hip (which includes the kernels) into libirbpp_hip.so.
+
+    ``ablate=True`` builds the tooling variant libirbpp_hip_ablate.so (-DIRBPP_ABLATE: phases can be
+    run twice, see tools/ablate.py); it is selected with IRBPP_LIBRARY and never loaded by default."""
+    out = ABLATE_LIB_PATH if ablate else LIB_PATH
+    if not force and not needs_build(out):
+        return out
+    cmd = [_hipcc()] + HIPCC_FLAGS + (["-DIRBPP_ABLATE"] if ablate else []) + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", out]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
-    return LIB_PATH
+    return out

@@ -176,6 +176,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
     P.obs_len1 = 5 * P.S + 9 + P.Hc;
     P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
+    if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
     layout_lds(P, cfg->contour_slots);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 

@@ -102,6 +102,10 @@ struct Params {
     // Division by the runtime grid sizes costs ~25 VALU instructions each; n / d == umulhi(n, mg_d) exactly
     // for n, d < 2^16 with mg_d = floor(2^32 / d) + 1 (d >= 2), see fdiv() in irbpp_kernels.hip.
     uint32_t mg_hy, mg_step, mg_ay, mg_ax, mg_ac, mg_mbw;
+    // Tooling (IRBPP_DEBUG_REPEAT): bit k set = run phase k twice (idempotent), so that the slow-down of a
+    // launch prices that phase at full chip load.  1 trace, 2 Douglas-Peucker, 4 overlap loops, 8 emit,
+    // 16 whole contour stage.
+    int32_t dbg_repeat;
 };
 
 enum Mode : int32_t {

@@ -33,6 +33,15 @@ namespace irbpp {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
+// Tooling build only (-DIRBPP_ABLATE, tools/ablate.py): phase `bit` runs twice when Params.dbg_repeat has the
+// bit set.  Every repeated phase is idempotent, so results do not change and the slow-down of a launch
+// prices the phase at full chip load.  In the product build the trip count is the constant 1.
+#ifdef IRBPP_ABLATE
+#define IRBPP_REPS(bit) (1 + ((P.dbg_repeat >> (bit)) & 1))
+#else
+#define IRBPP_REPS(bit) 1
+#endif
+
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
 
@@ -334,8 +343,9 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                 const uint32_t e = L.clist[c0 + tid];
                 const int gi = e & 63u;
                 my_r = L.tasklist[base + gi] >> 8;
-                const int n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u,
-                                           mine.pts, mine.cap);
+                int n = 0;
+                for (int rep = 0; rep < IRBPP_REPS(0); ++rep)
+                    n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u, mine.pts, mine.cap);
                 L.cn[tid] = (uint16_t)(n < 0 ? 0 : (n > 0xFFFF ? 0xFFFF : n));
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                 else if (n > mine.cap) atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
@@ -344,6 +354,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             }
             __syncthreads();
             // (b2) short borders: Douglas-Peucker + convexity per lane, still in lockstep
+            for (int rep = 0; rep < IRBPP_REPS(1); ++rep)
             if (my_n > 0 && !approx_and_convex(mine.pts, my_n, mine.dst, mine.stk, mine.cap_stk, L.vmask + my_r * 16))
                 atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
             // (b3) long borders: each wave pulls one at a time and works on it with all 64 lanes
@@ -357,6 +368,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                     const int c = llist[li];
                     const int r = L.tasklist[base + (L.clist[c0 + c] & 63u)] >> 8;
                     const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
+                    for (int rep = 0; rep < IRBPP_REPS(1); ++rep)
                     if (!approx_and_convex_wave(m.pts, (int)L.cn[c], L.vmask + r * 16) && (tid & 63) == 0)
                         atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
                 }
@@ -501,6 +513,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     int level_code[8];
     int ncell_next = 0, off_next = 0;
     Cell pre = {};                                           // first cell chunk of the next rotation, in flight
+    for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
     if (item >= 0) {
         const ShapeRot* s0 = (const ShapeRot*)srw;
         ncell_next = __builtin_amdgcn_readfirstlane(blocks ? s0->nblk : s0->nb);
@@ -573,6 +586,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             vs[r] = round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
         }
     }
+    }
     __syncthreads();                                         // every ShapeRot has been read: L.lev may be written
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -636,6 +650,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     stamp(io, b, 2);
 
     if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * PHASE_ROW + 5] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 6] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 7] = 0; }
+    for (int rep = 0; rep < IRBPP_REPS(4); ++rep)
     contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * PHASE_ROW : nullptr);
     stamp(io, b, 3);
 
@@ -709,6 +724,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     }
 
     // ---- emit: candidate block [S][5], item vector [9], heightmap [Hc]; float32 cast last
+    for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
     for (int e = tid; e < 5 * P.S; e += BLOCK) {
         const int row = e / 5, col = e - row * 5;
         float v = 0.0f;

@@ -1,0 +1,165 @@
+"""Known-answer tests with HAND-WRITTEN expected values, run through
+the C ABI on the GPU.  Unlike the parity tests nothing here is computed by the oracle: the expected
+numbers follow from reading the reference (space.py:98-129, cvTools.py:61-102, binPhy.py:183-337,
+IRcreator.py:17-24) on cases small enough to do by hand."""
+import numpy as np
+import pytest
+import torch
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd.shapes import ShapeSet
+from irbpp_amd.vec_env import GpuVecEnv
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S = 500
+BIN_VOL = 0.32 * 0.32 * 0.30
+
+
+def _boxes(edges, n_rot=2):
+    """Solid boxes written out by hand in shotInfo format (tools.py:98-135): bottom 0, top e_z, full masks;
+    rotation 1 (90 degrees) swaps x and y."""
+    ext, vol, tab = [], [], []
+    for ex, ey, ez in edges:
+        per_e, per_t = [], []
+        for r in range(n_rot):
+            e = (ex, ey, ez) if r % 2 == 0 else (ey, ex, ez)
+            fx, fy = int(round(e[0] * 100)), int(round(e[1] * 100))
+            per_e.append(e)
+            per_t.append((np.full((fx, fy), ez), np.zeros((fx, fy)), np.ones((fx, fy)), np.ones((fx, fy))))
+        ext.append(per_e)
+        tab.append(per_t)
+        vol.append(ex * ey * ez)
+    return ShapeSet(np.array(ext), np.array(vol), tab, name="kat")
+
+
+def _rows(obs_row):
+    return obs_row[:5 * S].reshape(S, 5)
+
+
+def _find(rows, rot, lx, ly):
+    hit = np.nonzero((rows[:, 0] == rot) & (rows[:, 1] == lx) & (rows[:, 2] == ly) & (rows[:, 4] == 1))[0]
+    assert len(hit) == 1, f"candidate ({rot},{lx},{ly}) not offered exactly once"
+    return int(hit[0])
+
+
+KAT1_ROWS = [[r, lx, ly, 0.0, 1.0] for r in (0, 1) for (lx, ly) in ((0, 0), (13, 0), (0, 13), (13, 13))]
+
+
+def test_kat1_empty_bin_single_box():
+    """Box 0.06^3 in an empty bin: a 14x14 block of valid cells at height 0 per rotation -> its four corners,
+    ordered by (column, row) (np.unique, cvTools.py:100-101); 492 zero rows; item vector; empty heightmap."""
+    env = GpuVecEnv(_boxes([(0.06, 0.06, 0.06)]), np.zeros((4, 50), dtype=np.int32), 2, device=DEV)
+    obs = env.reset().cpu().numpy()
+    assert obs.shape == (2, 5 * S + 9 + 1024)
+    for b in range(2):
+        rows = _rows(obs[b])
+        np.testing.assert_array_equal(rows[:8], np.array(KAT1_ROWS, dtype=np.float32))
+        assert not rows[8:].any()
+        np.testing.assert_array_equal(obs[b, 5 * S:5 * S + 9], np.zeros(9, dtype=np.float32))   # [id=0, 0 x 8]
+        assert not obs[b, 5 * S + 9:].any()
+    posz, mask = env.env.possible_position(torch.zeros(2, dtype=torch.int32, device=DEV))
+    posz, mask = posz.cpu().numpy(), mask.cpu().numpy()
+    assert (mask[:, :, :14, :14] == 1).all() and mask.sum() == 2 * 2 * 196
+    assert (posz[:, :, :14, :14] == 0.0).all() and (posz[mask == 0] == 1e3).all()
+    env.close()
+
+
+def test_kat2_place_and_stack():
+    """Action 0 = (rot 0, lx 0, ly 0): heightmap[0:6,0:6] = 0.06, reward 0.06^3/0.03072*10 = 0.0703125; the next
+    identical item rests at 0.06 exactly where its window meets the first one (X<=2 and Y<=2), 0 elsewhere."""
+    env = GpuVecEnv(_boxes([(0.06, 0.06, 0.06)]), np.zeros((4, 50), dtype=np.int32), 1, device=DEV)
+    env.reset()
+    obs, rew, done, info = env.step(np.array([0]))
+    assert not done[0] and info[0] == {"Valid": True}
+    assert abs(float(rew[0, 0]) - 0.0703125) < 1e-5
+    hm = obs.cpu().numpy()[0, 5 * S + 9:].reshape(32, 32)
+    want = np.zeros((32, 32), dtype=np.float32)
+    want[0:6, 0:6] = np.float32(0.06)
+    np.testing.assert_array_equal(hm, want)
+    posz, mask = env.env.possible_position(torch.zeros(1, dtype=torch.int32, device=DEV))
+    posz = posz.cpu().numpy()[0]
+    for r in (0, 1):
+        assert (posz[r, :3, :3] == 0.06).all()
+        z = posz[r, :14, :14].copy()
+        z[:3, :3] = 0.0
+        assert (z == 0.0).all() and (posz[r, 14:, :] == 1e3).all() and (posz[r, :, 14:] == 1e3).all()
+    rows = _rows(obs.cpu().numpy()[0])
+    n = int((rows[:, 4] == 1).sum())
+    for r in (0, 1):
+        for lx, ly in ((0, 0), (2, 0), (0, 2), (2, 2)):           # the 3x3 block at level 0.06 // 0.01 == 5
+            assert rows[_find(rows, r, lx, ly), 3] == np.float32(0.06)
+        for lx, ly in ((13, 0), (0, 13), (13, 13)):               # outer convex corners of the L-shaped level-0 region
+            assert rows[_find(rows, r, lx, ly), 3] == 0.0
+    assert not rows[n:].any() and (rows[:n, 4] == 1).all()
+    env.close()
+
+
+def test_kat3_overflow_and_termination():
+    """Five boxes stacked at (0,0) reach 0.30; the sixth does not fit there (round(0.30+0.06-0.30, 6) > 0) but does
+    elsewhere; the episode ends when nothing is valid: reward 0, counter = placements, ratio = sum(vol)/0.03072,
+    and the observation returned is the reset observation (shmem_vec_env.py:142-144)."""
+    env = GpuVecEnv(_boxes([(0.06, 0.06, 0.06)]), np.zeros((4, 200), dtype=np.int32), 1, device=DEV)
+    first = env.reset().cpu().numpy()[0]
+    obs = first
+    for k in range(5):
+        o, rew, done, _ = env.step(np.array([_find(_rows(obs), 0, 0, 0)]))
+        obs = o.cpu().numpy()[0]
+        assert not done[0]
+        hm = obs[5 * S + 9:].reshape(32, 32)
+        assert (hm[0:6, 0:6] == np.float32((0.06, 0.12, 0.18, 0.24, 0.30)[k])).all() and np.count_nonzero(hm) == 36
+    rows = _rows(obs)
+    valid = rows[rows[:, 4] == 1]
+    assert len(valid) > 0 and not ((valid[:, 1] <= 2) & (valid[:, 2] <= 2)).any()     # nothing offered on the full column
+    placed, vol_sum = 5, 5 * (0.06 * 0.06 * 0.06)
+    for _ in range(200):
+        rows = _rows(obs)
+        v = rows[:, 4] == 1
+        a = int(np.argmin(np.where(v, rows[:, 3], np.inf))) if v.any() else 0
+        o, rew, done, info = env.step(np.array([a]))
+        obs = o.cpu().numpy()[0]
+        if done[0]:
+            break
+        placed += 1
+        vol_sum += 0.06 * 0.06 * 0.06
+    assert done[0] and float(rew[0, 0]) == 0.0
+    assert info[0]["counter"] == placed and 5 < placed <= 125                         # 5 x 5 x 5 boxes at most
+    assert abs(info[0]["ratio"] - vol_sum / BIN_VOL) < 1e-12 and info[0]["Valid"] is True
+    assert info[0]["episode"]["l"] == placed + 1 and abs(info[0]["episode"]["r"] - placed * 0.0703125) < 1e-5
+    np.testing.assert_array_equal(obs, first)
+    env.close()
+
+
+def test_kat4_fallback_candidates():
+    """An item wider than the bin (0.34 m: ax = 17 > 16): no cell of any rotation is valid, getConvexHullActions
+    returns None (cvTools.py:71-75) and the observation carries the first S cells of the flattened posZValid with
+    H = 0.30, V = 0 (binPhy.py:217-225); any action ends the episode with counter 0, ratio 0."""
+    env = GpuVecEnv(_boxes([(0.34, 0.34, 0.06)]), np.zeros((4, 50), dtype=np.int32), 1, device=DEV)
+    rows = _rows(env.reset().cpu().numpy()[0])
+    want = np.array([[c // 256, (c % 256) // 16, c % 16, 0.30, 0.0] for c in range(S)]).astype(np.float32)
+    np.testing.assert_array_equal(rows, want)
+    _, rew, done, info = env.step(np.array([7]))
+    assert done[0] and float(rew[0, 0]) == 0.0 and info[0]["counter"] == 0 and info[0]["ratio"] == 0.0
+    env.close()
+
+
+def test_kat5_buffer_pop_order():
+    """k = 3 queue [a, b, c]; order action 1 -> the location observation is built for b; after the placement the
+    queue is [a, c, new] (IRcreator.py:22-24, binPhy.py:324-325) and the order observation is [a, c, new | heightmap]."""
+    shapes = _boxes([(0.03, 0.03, 0.03), (0.06, 0.06, 0.06), (0.09, 0.09, 0.09), (0.12, 0.12, 0.12)])
+    seq = np.tile(np.array([[2, 1, 3, 0, 1, 2, 3, 0]], dtype=np.int32), (4, 1))
+    env = GpuVecEnv(shapes, seq, 1, device=DEV, bufferSize=3)
+    order = env.reset().cpu().numpy()[0]
+    assert order.shape == (3 + 1024,)
+    np.testing.assert_array_equal(order[:3], [2, 1, 3])
+    loc = env.get_action_candidates(np.array([1])).cpu().numpy()[0]
+    assert loc.shape == (5 * S + 9 + 1024,) and loc[5 * S] == 1.0                     # built for item b = 1
+    rows = _rows(loc)
+    np.testing.assert_array_equal(rows[:8], np.array(KAT1_ROWS, dtype=np.float32))    # the 0.06 box of KAT-1
+    order, rew, done, _ = env.step(np.array([0]))
+    order = order.cpu().numpy()[0]
+    np.testing.assert_array_equal(order[:3], [2, 3, 0])                               # b popped, next id appended
+    assert abs(float(rew[0, 0]) - 0.0703125) < 1e-5 and not done[0]
+    hm = order[3:].reshape(32, 32)
+    assert (hm[0:6, 0:6] == np.float32(0.06)).all() and np.count_nonzero(hm) == 36
+    env.close()

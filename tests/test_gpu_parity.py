@@ -217,22 +217,36 @@ def test_convex_hull_actions_golden_and_random(golden_dir):
         env.close()
 
 
-def test_full_size_properties_and_sharding_invariance():
-    """BASELINE config 2 at full width: size-independent properties instead of an oracle run."""
+@pytest.mark.parametrize("n,parts", [(4096, 2), (8192, 4)])
+def test_full_size_properties_and_sharding_invariance(n, parts):
+    """BASELINE config 2 at full width (4096 bins) and at north_star's 8192 bins on one GPU:
+    size-independent properties instead of an oracle run, and the same bins as `parts` shards."""
     sh = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
     seqs = synthetic.make_sequences(sh.n_shapes, 10000, 160, seed=123)
-    n = 4096
     env = GpuPackingEnv(sh, seqs, n, device=DEV)
-    half = [GpuPackingEnv(sh, seqs, n // 2, device=DEV, global_offset=o, global_bins=n) for o in (0, n // 2)]
+    half = [GpuPackingEnv(sh, seqs, n // parts, device=DEV, global_offset=o, global_bins=n)
+            for o in range(0, n, n // parts)]
     obs = env.reset()
     hobs = [h.reset() for h in half]
     vol = torch.from_numpy(sh.volumes).to(DEV)
     prev_hm = env.get_heightmaps().clone()
     placed_vol = torch.zeros(n, dtype=torch.float64, device=DEV)
-    for t in range(40):
+    # ... and the C oracle on a sample of the bins: groups of 16 global bins spread over the whole range
+    from oracle.c_oracle import COracleVecEnv
+    starts = [0, n // 3, n // 2 - 8, n - 16]
+    sample = np.concatenate([np.arange(o, o + 16) for o in starts])
+    cenvs = [COracleVecEnv(16, sh, seqs, global_offset=o, global_num=n) for o in starts]
+    np.testing.assert_array_equal(obs[sample].cpu().numpy(), _f32(np.concatenate([c.reset() for c in cenvs])))
+    ndone = 0
+    for t in range(110):
         act = env.policy_minz(obs)
         item = obs[:, 5 * S].to(torch.int64)
         obs, rew, done = env.step(act)
+        sact = act[sample].cpu().numpy()
+        cres = [c.step(sact[16 * j:16 * j + 16]) for j, c in enumerate(cenvs)]
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), _f32(np.concatenate([r[0] for r in cres])),
+                                      err_msg=f"sampled bins differ from the C oracle at step {t}")
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), np.concatenate([r[2] for r in cres]))
         hacts = [h.policy_minz(o) for h, o in zip(half, hobs)]
         hobs = [h.step(a)[0] for h, a in zip(half, hacts)]
         assert torch.equal(torch.cat(hobs), obs), "result depends on how bins are sharded"
@@ -247,7 +261,9 @@ def test_full_size_properties_and_sharding_invariance():
         placed_vol = torch.where(d, torch.zeros_like(placed_vol), placed_vol + vol[item.clamp(min=0)])
         assert bool((placed_vol <= 0.03072 + 1e-12).all())                # never more volume than the bin holds
         prev_hm = hm.clone()
+        ndone += int(d.sum())
     tot = env.episode_totals().cpu().numpy()
+    assert ndone > n // 4 and tot[0] == ndone                             # terminal steps and auto-resets were covered
     assert tot[0] >= 0 and tot[1] <= tot[0]                               # ratios are in [0,1]
     env.check_device_error()
     for e in [env] + half:
@@ -543,21 +559,33 @@ def test_tooling_hooks_time_and_locate_every_bin():
     env.check_device_error()
 
 
-@pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60)])
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60),
+                                              ("blockout_k10", 128, 120), ("abc_fine", 48, 40),
+                                              ("blockout_r8", 96, 80)])
 def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
-    """Scale check made possible by the C oracle: the bench workloads themselves, hundreds of bins,
-    whole episodes including auto-resets; every observation, reward, done and episode info equal."""
+    """Scale check made possible by the C oracle: the bench workloads themselves (every BASELINE config:
+    cfg 2 blockout / blockout_r8, cfg 3 general, cfg 4 blockout_k10 through get_action_candidates + step,
+    cfg 5 abc_fine on the 64x64 heightmap), hundreds of bins, whole episodes including auto-resets;
+    every observation, reward, done and episode info equal."""
     from bench import make_workload
     from oracle.c_oracle import COracleVecEnv
     shapes, seqs, kw = make_workload(workload)
     seqs = seqs[:2000]
+    k = int(kw.get("bufferSize", 1))
     genv = GpuVecEnv(shapes, seqs, n, device=DEV, **kw)
     cenv = COracleVecEnv(n, shapes, seqs, **kw)
     gobs = genv.reset()
     np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cenv.reset()))
     ndone = 0
     for t in range(steps):
-        act = genv.env.policy_minz(gobs).cpu().numpy()
+        if k > 1:                                     # hierarchical placement (binPhy.py:161-169, trainer.py:266-281)
+            order = (np.arange(n) * 3 + t) % k if t % 2 else np.zeros(n, dtype=np.int64)
+            gloc = genv.get_action_candidates(order)
+            np.testing.assert_array_equal(gloc.cpu().numpy(), _f32(cenv.get_action_candidates(order)),
+                                          err_msg=f"location obs step {t}")
+            act = genv.env.policy_minz(gloc).cpu().numpy()
+        else:
+            act = genv.env.policy_minz(gobs).cpu().numpy()
         gobs, grew, gdone, ginfo = genv.step(act)
         cobs, crew, cdone, cinfo = cenv.step(act)
         np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cobs), err_msg=f"step {t}")
