@@ -214,46 +214,52 @@ def cpu_baseline(name, budget_s=15.0):
     return result
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU")
-    ap.add_argument("--workload", default="blockout")
-    ap.add_argument("--slots", type=int, default=0)
-    ap.add_argument("--pipeline-streams", type=int, default=4,
-                    help="also measure the bins split into this many independently stepping sub-batches (0 = skip)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl is RCCL on ROCm "
-                    "(gloo + several ranks on one device is only for dry runs of the multi-rank path)")
-    ap.add_argument("--cpu-budget", type=float, default=15.0)
-    a = ap.parse_args()
+def respawn_under_torchrun(a):
+    """`python bench.py --gpus N` with no torchrun environment: become N ranks.  Re-executes this
+    command under `python -m torch.distributed.run` (one process per GPU, rendezvous on 127.0.0.1)
+    so that a plain launch can never silently measure one GPU and call it N."""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
 
-    from irbpp_amd import distributed as D
-    cpu = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.workload, a.cpu_budget)       # before HIP is initialised: the pool forks
-    rank, world, local_rank = D.init_from_env(a.backend)    # nccl == RCCL on ROCm
-    if a.backend != "nccl":
-        local_rank %= max(1, torch.cuda.device_count())     # dry run: ranks may share a device
-    assert world == a.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node == --gpus"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
 
-    from irbpp_amd.vec_env import GpuPackingEnv
-    shapes, seqs, kw = make_workload(a.workload)
-    env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, contour_slots=a.slots,
-                        **D.shard(rank, world, a.bins), **kw)
-    hc = env.Hx * env.Hy
-    k = int(kw.get("bufferSize", 1))
+def pmc_profile(workload):
+    """Counter passes committed under profiles/ (tools/collect_pmc.py) -- only if they were taken on the
+    kernel sources this run uses (stamp == irbpp_amd.build.source_hash()); otherwise (None, reason)."""
+    from irbpp_amd.build import source_hash
+    path = os.path.join(ROOT, "profiles", "pmc_hbm.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_hbm.json"
+    try:
+        prof = json.load(open(path))
+    except Exception as e:                      # noqa: BLE001
+        return None, f"unreadable profiles/pmc_hbm.json: {e}"
+    if prof.get("kernel_source_sha") != source_hash():
+        return None, (f"profiles/pmc_hbm.json was taken on kernel sources {prof.get('kernel_source_sha')}, "
+                      f"this run uses {source_hash()}")
+    return prof.get("workloads", {}).get(workload), None
+
+
+def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
+    """prefill (untimed: every bin deep in its own episode, terminal steps and auto-resets in the mix),
+    warm-up, then exactly `steps` timed steps between two barriers.  -> (seconds, kernel ms per placement,
+    episodes finished inside the timed region)."""
+    bins = env.num_bins
     launches = 2 if k > 1 else 1               # transition-kernel launches per placement
     obs_a = env.reset()
     obs_b = torch.empty_like(obs_a)
-    act = torch.empty((a.bins,), dtype=torch.int32, device=dev)
+    act = torch.empty((bins,), dtype=torch.int32, device=dev)
     if k > 1:
-        slot0 = torch.zeros((a.bins,), dtype=torch.int32, device=dev)
-        loc = torch.empty((a.bins, env.loc_obs_len), dtype=torch.float32, device=dev)
+        slot0 = torch.zeros((bins,), dtype=torch.int32, device=dev)
+        loc = torch.empty((bins, env.loc_obs_len), dtype=torch.float32, device=dev)
 
     def one_step(src, dst):
         if k > 1:                              # one hierarchical placement (SURVEY 8d): candidates of the
@@ -263,28 +269,82 @@ def main():
         env.step(act, obs_out=dst)
 
     cur, nxt = obs_a, obs_b
-    for _ in range(a.warmup):
+    for _ in range(prefill + warmup):
         one_step(cur, nxt)
         cur, nxt = nxt, cur
-    env.enable_kernel_timing(a.steps * launches)   # HIP events right around irbpp_env_kernel, on its stream
-
-    def barrier():
-        D.barrier(dev)
-
+    env.enable_kernel_timing(steps * launches)   # HIP events right around irbpp_env_kernel, on its stream
+    done_before = float(env.episode_totals()[0].item())
     barrier()
     t0 = time.perf_counter()
-    for i in range(a.steps):
+    for _ in range(steps):
         one_step(cur, nxt)
         cur, nxt = nxt, cur
     barrier()
     elapsed = time.perf_counter() - t0
     env.check_device_error()
-
-    lds_bytes, kernel_name = env.kernel_info()
-    kernel_ms = float(env.kernel_times_ms().mean()) * launches                   # irbpp_env_kernel alone, per placement
+    kernel_ms = float(env.kernel_times_ms().mean()) * launches       # irbpp_env_kernel alone, per placement
     env.enable_kernel_timing(0)
+    finished = float(env.episode_totals()[0].item()) - done_before
+    return elapsed, kernel_ms, finished
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--prefill", type=int, default=300,
+                    help="untimed steps before the warm-up that bring every bin to a steady-state episode mix")
+    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU")
+    ap.add_argument("--workload", default="blockout")
+    ap.add_argument("--slots", type=int, default=0)
+    ap.add_argument("--pipeline-streams", type=int, default=4,
+                    help="also measure the bins split into this many independently stepping sub-batches (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the 8192-bin extra measurement")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl is RCCL on ROCm "
+                    "(gloo + several ranks on one device is only for dry runs of the multi-rank path)")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    a = ap.parse_args()
+
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        respawn_under_torchrun(a)                          # does not return
+
+    from irbpp_amd import distributed as D
+    cpu = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.workload, a.cpu_budget)       # before HIP is initialised: the pool forks
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus} is running as {world} rank(s): launch one rank per GPU "
+                         f"(torch.distributed.run --nproc-per-node {a.gpus}) or let bench.py spawn them itself")
+    n_dev = torch.cuda.device_count()
+    if a.backend == "nccl" and n_dev < world:
+        raise SystemExit(f"--gpus {world} needs {world} visible GPUs, this node shows {n_dev} "
+                         "(--backend gloo runs several ranks on one device as a dry run only)")
+    rank, world, local_rank = D.init_from_env(a.backend)    # nccl == RCCL on ROCm
+    if a.backend != "nccl":
+        local_rank %= max(1, n_dev)                        # dry run: ranks may share a device
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from irbpp_amd.vec_env import GpuPackingEnv
+    shapes, seqs, kw = make_workload(a.workload)
+    env = GpuPackingEnv(shapes, seqs, a.bins, device=dev, contour_slots=a.slots,
+                        **D.shard(rank, world, a.bins), **kw)
+    hc = env.Hx * env.Hy
+    k = int(kw.get("bufferSize", 1))
+
+    def barrier():
+        D.barrier(dev)
+
+    elapsed, kernel_ms, finished = timed_run(env, a, dev, k, barrier, a.steps, a.prefill, a.warmup)
+    lds_bytes, kernel_name = env.kernel_info()
     elapsed = D.max_over_ranks(elapsed, dev)
+    finished = float(D.reduce_totals(torch.tensor([finished, 0, 0, 0], dtype=torch.float64, device=dev))[0].item())
     tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
+    devices = D.gather_strings(f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} "
+                               f"[{torch.cuda.get_device_properties(local_rank).gcnArchName}]")
 
     # Extra measurement (not `value`): the same bins as S sub-batches on S HIP streams, each
     # stepping on its own; one sub-batch's straggler workgroups overlap the next one's start.
@@ -316,7 +376,7 @@ def main():
                         e.step(sa[i], obs_out=sn[i])
                         so[i], sn[i] = sn[i], so[i]
 
-            for _ in range(a.warmup):
+            for _ in range(a.warmup + (a.prefill if attempt == 1 else 0)):
                 sub_step()
             barrier()
             if attempt == 1:
@@ -330,39 +390,54 @@ def main():
                 e.close()
         pipelined = {"streams": ns, "value": a.bins * world * a.steps / t_pipe, "ms_per_step": t_pipe / a.steps * 1e3}
 
+    bps = algorithmic_bytes_per_step(shapes, hc, k)
+    # north_star's target configuration, 8192 BlockOut bins on ONE GPU, measured the same way (extra, not `value`)
+    extra = None
+    if world == 1 and not a.no_extra and a.workload == "blockout" and a.bins != 8192:
+        env.close()
+        e2 = GpuPackingEnv(shapes, seqs, 8192, device=dev, contour_slots=a.slots, **kw)
+        t2, k2, f2 = timed_run(e2, a, dev, k, barrier, a.steps, a.prefill, a.warmup)
+        extra = {"bins8192_one_gpu": {"value": 8192 * a.steps / t2, "ms_per_step": t2 / a.steps * 1e3, "kernel_ms": k2,
+                                      "roofline_frac": bps * 8192 / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                      "episodes_finished_in_timed_region": f2}}
+        e2.close()
+
     if rank == 0:
         total_steps = a.bins * world * a.steps
-        bps = algorithmic_bytes_per_step(shapes, hc, k)
         achieved = bps * a.bins / (kernel_ms * 1e-3) / 1e9
-        traffic = None
-        prof = os.path.join(ROOT, "profiles", "r01_pmc_hbm.json")
-        if os.path.exists(prof):
-            try:
-                # PMC passes (profiles/r01_pmc_hbm.json) were taken at 4096 bins per launch; bins are
-                # independent, so the traffic of a launch scales with their number
-                traffic = json.load(open(prof)).get(a.workload, {}).get("hbm_bytes_per_launch")
-                if traffic is not None:
-                    traffic = traffic * a.bins / 4096.0
-            except Exception:
-                traffic = None
+        prof, why = pmc_profile(a.workload)
+        traffic, issue = None, None
+        if prof is not None:
+            # HBM bytes per launch from the PMC passes (taken at prof["bins"] bins per launch, beyond the
+            # Infinity Cache); bins are independent, so a launch's traffic scales with their number
+            traffic = prof["hbm_bytes_per_launch"] * a.bins / prof["bins"]
+            issue = prof.get("issue")
         out = {
             "metric": "env steps/sec (placements/sec) across N parallel bins",
             "value": total_steps / elapsed, "unit": "placement-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prefill_steps": a.prefill,
             "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload} {'online' if k == 1 else 'buffered'} (bufferSize={k}), {a.bins} bins/GPU, resolutionA=0.02 "
                                    f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy",
                        "bins_per_gpu": a.bins, "global_bins": a.bins * world, "parallelism": f"bins sharded x{world}"},
+            "ranks": {"world_size": world, "backend": a.backend if world > 1 else None, "devices": devices},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "lds_bytes_per_workgroup": lds_bytes,
                          "algorithmic_bytes_per_step": bps},
-            "episodes": {"finished": float(tot[0]), "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
+            "episodes": {"finished_in_timed_region": finished, "finished_since_reset": float(tot[0]),
+                         "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
                          "mean_items": float(tot[2] / tot[0]) if tot[0] else None},
         }
+        if why is not None:
+            out["roofline"]["traffic_note"] = why
+        if issue is not None:
+            out["roofline"]["issue"] = issue       # the kernel is instruction-issue bound, not HBM bound: SQ busy shares
         if pipelined is not None:
             out["pipelined"] = pipelined
+        if extra is not None:
+            out["extra"] = extra
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)

@@ -16,6 +16,17 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
                "-shared", "-fPIC", "-Wno-unused-value"]
 
 
+def source_hash() -> str:
+    """Short hash of everything the library is compiled from (+ flags): profiles/ stamps its counter passes
+    with it and bench.py only quotes a pass whose stamp matches the sources it runs."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS).encode())
+    for name in sorted(SOURCES):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def _hipcc() -> str:
     for cand in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
         if cand and os.path.exists(cand):

@@ -70,3 +70,12 @@ def barrier(device=None):
         dist.barrier()
     if on_gpu:
         torch.cuda.synchronize(device)
+
+
+def gather_strings(text: str):
+    """One line per rank, gathered on every rank (bench.py: which device did each rank really use)."""
+    if not _active():
+        return [text]
+    out = [None] * dist.get_world_size()
+    dist.all_gather_object(out, text)
+    return out

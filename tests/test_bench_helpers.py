@@ -50,3 +50,39 @@ def test_committed_bench_line_keeps_the_contract():
     assert r["bound"] == "hbm" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert abs(line["value"] - 4096 * line["steps"] / (line["ms_per_step"] * 1e-3 * line["steps"])) < 1.0
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] >= 1
+
+
+def test_gpus_n_never_degrades_to_one_rank():
+    """`python bench.py --gpus 2` launched as a plain process (how the driver launches it) must become two
+    ranks or fail -- never print a 1-GPU line.  Here (no GPU) both spawned ranks refuse: non-zero exit, no JSON."""
+    import subprocess
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0",
+                          "--prefill", "0", "--no-cpu-baseline"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0
+    assert '"n_gpus"' not in res.stdout
+    assert "needs 2 visible GPUs" in res.stderr or "needs 2 visible GPUs" in res.stdout
+
+
+def test_rank_count_mismatch_is_refused(monkeypatch):
+    """A torchrun world of 2 with --gpus 4 is an error, not a silently smaller run."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and "is running as 1 rank(s)" in res.stderr
+
+
+def test_pmc_profile_is_quoted_only_for_matching_kernel_sources(tmp_path, monkeypatch):
+    from irbpp_amd.build import source_hash
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    os.makedirs(tmp_path / "profiles")
+    assert bench.pmc_profile("blockout") == (None, "no profiles/pmc_hbm.json")
+    doc = {"kernel_source_sha": "0" * 16, "workloads": {"blockout": {"bins": 16384, "hbm_bytes_per_launch": 1.0}}}
+    (tmp_path / "profiles" / "pmc_hbm.json").write_text(json.dumps(doc))
+    prof, why = bench.pmc_profile("blockout")
+    assert prof is None and "was taken on kernel sources" in why
+    doc["kernel_source_sha"] = source_hash()
+    (tmp_path / "profiles" / "pmc_hbm.json").write_text(json.dumps(doc))
+    assert bench.pmc_profile("blockout") == ({"bins": 16384, "hbm_bytes_per_launch": 1.0}, None)

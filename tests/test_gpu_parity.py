@@ -561,7 +561,7 @@ def test_tooling_hooks_time_and_locate_every_bin():
 
 @pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60),
                                               ("blockout_k10", 128, 120), ("abc_fine", 48, 40),
-                                              ("blockout_r8", 96, 80)])
+                                              ("blockout_r8", 96, 150)])
 def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
     """Scale check made possible by the C oracle: the bench workloads themselves (every BASELINE config:
     cfg 2 blockout / blockout_r8, cfg 3 general, cfg 4 blockout_k10 through get_action_candidates + step,
@@ -599,3 +599,37 @@ def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
     genv.env.check_device_error()
     genv.close()
     assert ndone >= n // 2
+
+
+def test_bench_gpus2_spawns_two_real_ranks():
+    """`python bench.py --gpus 2` launched as ONE plain process (how the driver launches it) re-executes itself
+    under torch.distributed.run: two ranks, each with its own shard, totals reduced over the process group.
+    One GPU here, so the ranks share the device and talk gloo (dry run of the RCCL path); the line must say
+    n_gpus 2, world_size 2, two device entries and twice the bins."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(var, None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bins", "256",
+                          "--steps", "5", "--warmup", "2", "--prefill", "120", "--no-cpu-baseline", "--pipeline-streams", "0"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks"]["world_size"] == 2 and len(out["ranks"]["devices"]) == 2
+    assert out["config"]["global_bins"] == 512 and out["scaling"] == "weak"
+    assert abs(out["value"] - 512 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
+    # the reduced totals cover both shards: with 120 prefill steps most of the 512 bins finished an episode
+    assert out["episodes"]["finished_since_reset"] > 256
+    # ... and the two shards really were global bins [0,256) and [256,512): same totals as one 512-bin env
+    sh, seqs, kw = __import__("bench").make_workload("blockout")
+    one = GpuPackingEnv(sh, seqs, 512, device=DEV, **kw)
+    obs = one.reset()
+    for _ in range(120 + 2 + 5):
+        obs, _, _ = one.step(one.policy_minz(obs))
+    assert float(one.episode_totals()[0].item()) == out["episodes"]["finished_since_reset"]
+    one.close()
