@@ -285,164 +285,202 @@ __device__ inline int contour_vertices(const uint16_t* img, const uint16_t* imgT
 }
 
 // ---------------------------------------------------------------------------------------
-// Wave-cooperative approxPolyDP + convexity test for ONE (long) border: all 64 lanes of the
-// calling wave take part; the point distances of a pass / slice are computed one point per lane
-// and the arg-max ("first strict maximum in traversal order", as the sequential loops find it)
-// comes from a wave reduction.  Same results as approx_and_convex().
+// approxPolyDP(eps = 1, closed) + find_convex_vetex for SEVERAL borders at once, one contour point
+// per lane ("lane = point"): a wave holds up to 64 points of borders packed back to back.  Same
+// results as approx_and_convex(), but nothing in it is sequential per border:
+//   * the three farthest-point hops are three segmented arg-max rounds (segment = border);
+//   * Douglas-Peucker runs level by level: every lane knows the slice (start, end) it is an interior
+//     point of, all slices of all borders find their farthest point in ONE segmented arg-max round
+//     (segment = slice, keyed by the lane of its start point), split or accept, and the lanes
+//     update their slice.  The recursion of approx.cpp emits the start points of accepted slices
+//     in traversal order, i.e. the polygon is exactly the set of slice boundaries in contour order
+//     starting at the hop phase's start point -- no stack, no output list;
+//   * "first strict maximum in traversal order" = max of (dist << 8 | 255 - t);
+//   * the clean-up pass of approx.cpp only changes the polygon if some triple of consecutive
+//     vertices satisfies its removal test; that is checked for all vertices in parallel and a
+//     border where it fires (<1 % of them) is reported back for the sequential routine;
+//   * convexity is one cross product per vertex with the neighbouring vertices found by bit scans
+//     on the ballot of kept points.
+// The segmented arg-max is an LDS ds_max_u32 into one word per segment; a wave's LDS operations
+// execute in order, so no barrier is needed between the reset, the max and the read-back.
 // ---------------------------------------------------------------------------------------
-// wave64 max-reduction with DPP (no LDS crossbar): quad swaps, row mirrors, then row broadcasts;
-// the total lands in lane 63 and is read back as a wave-uniform scalar.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ uint32_t dpp_u32(uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
-    v = umax(v, dpp_u32<0xB1, 0xF>(v));      // quad_perm [1,0,3,2]
-    v = umax(v, dpp_u32<0x4E, 0xF>(v));      // quad_perm [2,3,0,1]
-    v = umax(v, dpp_u32<0x141, 0xF>(v));     // row_half_mirror
-    v = umax(v, dpp_u32<0x140, 0xF>(v));     // row_mirror: every lane now holds its row's max
-    v = umax(v, dpp_u32<0x142, 0xA>(v));     // row_bcast15 into rows 1 and 3
-    v = umax(v, dpp_u32<0x143, 0xC>(v));     // row_bcast31 into rows 2 and 3
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+#ifndef IRBPP_WAVE_SYNC
+#define IRBPP_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif
+
+// The clean-up pass of approxPolyDP_ (removal of [almost] collinear vertices, in place as approx.cpp does it,
+// including its reads of already rewritten entries after the wrap-around) followed by find_convex_vetex,
+// for ONE polygon held in a lane-indexed register: vertex i of `cnt` in lane i.  The pass is sequential
+// by nature and wave-uniform here (v_readlane at uniform indices); it only runs for the rare border
+// whose polygon it would change.
+__device__ __forceinline__ int put_lane(int lane, int reg, int idx, int val) { return lane == idx ? val : reg; }
+__device__ inline void cleanup_convex_wave(int lane, int dv, int cnt, uint32_t* vrows) {
+    int new_count = cnt;
+    int p2 = cnt - 1;
+    int start_pt = __builtin_amdgcn_readlane(dv, p2);
+    if (++p2 >= cnt) p2 = 0;
+    int wpos = p2;
+    int pt = __builtin_amdgcn_readlane(dv, p2);
+    if (++p2 >= cnt) p2 = 0;
+    for (int i = 0; i < cnt && new_count > 2; ++i) {
+        const int end_pt = __builtin_amdgcn_readlane(dv, p2);
+        if (++p2 >= cnt) p2 = 0;
+        const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
+        const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
+        int dist = ux * dy - uy * dx;
+        dist = dist < 0 ? -dist : dist;
+        const int inner = ux * (IRBPP_PX(end_pt) - IRBPP_PX(pt)) + uy * (IRBPP_PY(end_pt) - IRBPP_PY(pt));
+        if (2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0) {
+            --new_count;
+            start_pt = end_pt;
+            dv = put_lane(lane, dv, wpos, end_pt);
+            if (++wpos >= cnt) wpos = 0;
+            pt = __builtin_amdgcn_readlane(dv, p2);
+            if (++p2 >= cnt) p2 = 0;
+            ++i;
+            continue;
+        }
+        start_pt = pt;
+        dv = put_lane(lane, dv, wpos, pt);
+        if (++wpos >= cnt) wpos = 0;
+        pt = end_pt;
+    }
+    const int m = new_count;
+    const int ia = lane == 0 ? m - 1 : lane - 1, ic = lane == m - 1 ? 0 : lane + 1;
+    const int a = __shfl(dv, ia < 0 ? 0 : ia), c = __shfl(dv, ic > 63 ? 63 : ic), b = dv;
+    if (lane < m) {
+        bool keep = true;
+        if (m > 3)
+            keep = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
+                   (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a)) < 0;
+        if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
+    }
 }
 
-__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
-// v_writelane equivalent: entry `idx` (wave-uniform) of the lane-indexed register `reg` := val
-__device__ __forceinline__ int put_lane(int reg, int idx, int val) { return (int)(threadIdx.x & 63) == idx ? val : reg; }
-
-// Points, the slice stack and the output polygon live in lane-indexed registers (entry i in
-// lane i), read and written with v_readlane / v_writelane at wave-uniform indices; only the
-// per-lane distance reads go to LDS.  Handles borders of up to 64 points.
-__device__ inline bool approx_and_convex_wave(const uint8_t* pts, int count, uint32_t* vrows) {
-    const int lane = threadIdx.x & 63;
-    count = uni(count);
-    const int pv = lane < count ? (int)pts[lane] : 0;            // pv: point j in lane j
-    int sv = 0;                                                  // slice stack, entry i in lane i
-    int dv = 0;                                                  // output polygon, vertex i in lane i
-    int new_count = 0, top = 0;
-    // 1. three farthest-point hops; key = dist<<12 | (4095 - j): max dist, then smallest j
+// lane:  my lane in the wave;  live: I hold a point;  pv: my point (x | y<<4);  j, n: my index in / size of
+// my border;  sb: lane of my border's point 0;  pts: my border's point list in LDS;  slots: 64 words of LDS
+// private to this wave;  vmask: vertex rows of all rotations (wave-uniform), rot: my border's rotation.
+__device__ inline void approx_convex_segmented(int lane, bool live, int pv, int j, int n, int sb, const uint8_t* pts,
+                                               uint32_t* slots, uint32_t* vmask, int rot) {
+    uint32_t* const vrows = vmask + rot * 16;
+    const int px = IRBPP_PX(pv), py = IRBPP_PY(pv);
+    // 1. three farthest-point hops
     int pos = 0, right_start = 0;
     bool le_eps = false;
-    int start_pt = 0;
-    // Lane j holds point j, so a pass / slice needs no memory access: each lane works out its own
-    // position t along the traversal (t = (j - start) mod count) and whether that lies inside.
-    const int px = IRBPP_PX(pv), py = IRBPP_PY(pv);
     for (int it = 0; it < 3; ++it) {
         pos += right_start;
-        if (pos >= count) pos -= count;
-        start_pt = __builtin_amdgcn_readlane(pv, pos);
-        const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
-        int j = lane - pos;
-        if (j < 0) j += count;
-        uint32_t best = 0u;
-        if (lane < count && j >= 1) {
-            const int dx = px - sx, dy = py - sy;
-            best = ((uint32_t)(dx * dx + dy * dy) << 12) | (uint32_t)(4095 - j);
+        if (pos >= n) pos -= n;
+        slots[lane] = 0u;
+        IRBPP_WAVE_SYNC();
+        if (live) {
+            const int sp = pts[pos];
+            int t = j - pos;
+            if (t < 0) t += n;
+            const int dx = px - IRBPP_PX(sp), dy = py - IRBPP_PY(sp);
+            if (t >= 1) atomicMax(&slots[sb], ((uint32_t)(dx * dx + dy * dy) << 8) | (uint32_t)(255 - t));
         }
-        best = wave_max_u32(best);
-        const int max_dist = (int)(best >> 12);
-        if (max_dist > 0) right_start = 4095 - (int)(best & 4095u);
+        IRBPP_WAVE_SYNC();
+        const uint32_t best = live ? slots[sb] : 0u;
+        IRBPP_WAVE_SYNC();
+        const int max_dist = (int)(best >> 8);
+        if (max_dist > 0) right_start = 255 - (int)(best & 255u);
         le_eps = max_dist <= 1;
     }
-    if (!le_eps) {
-        const int s0 = pos;
-        int far = right_start + s0;
-        if (far >= count) far -= count;
-        sv = put_lane(sv, 0, far | (s0 << 16));     // right slice
-        sv = put_lane(sv, 1, s0 | (far << 16));     // slice, processed first
-        top = 2;
-    } else {
-        dv = put_lane(dv, 0, start_pt);
-        new_count = 1;
-    }
-    // 3. Douglas-Peucker: one slice per iteration, its interior points spread over the lanes
-    while (top > 0) {
-        --top;
-        const int sl = __builtin_amdgcn_readlane(sv, top);
-        const int s_start = sl & 0xFFFF, s_end = (int)((unsigned)sl >> 16);
-        start_pt = __builtin_amdgcn_readlane(pv, s_start);
-        int len = s_end - s_start;                  // points from start to end along the closed curve
-        if (len <= 0) len += count;
-        bool le = true;
-        int split = 0;
-        if (len > 1) {
-            const int end_pt = __builtin_amdgcn_readlane(pv, s_end);
-            const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
-            const int dx = IRBPP_PX(end_pt) - sx, dy = IRBPP_PY(end_pt) - sy;
-            int t = lane - s_start;
-            if (t < 0) t += count;
-            uint32_t best = 0u;
-            if (lane < count && t >= 1 && t < len) {
-                int dist = (py - sy) * dx - (px - sx) * dy;
-                dist = dist < 0 ? -dist : dist;
-                best = ((uint32_t)dist << 12) | (uint32_t)(4095 - t);
-            }
-            best = wave_max_u32(best);
-            const int max_dist = (int)(best >> 12);
-            if (max_dist > 0) {
-                split = s_start + 4095 - (int)(best & 4095u);
-                if (split >= count) split -= count;
-            }
-            le = max_dist * max_dist <= dx * dx + dy * dy;
-        }
-        if (le) {
-            dv = put_lane(dv, new_count, start_pt);
-            ++new_count;
-        } else {
-            if (top + 2 > 64) return false;
-            sv = put_lane(sv, top, split | (s_end << 16));
-            sv = put_lane(sv, top + 1, s_start | (split << 16));
-            top += 2;
-        }
-    }
-    // 4. clean-up (inherently sequential, wave-uniform): in place on the register polygon
+    // 2. Douglas-Peucker, all slices of one recursion level per round
+    bool keep, active;
+    int ss = 0, se = 0;
+    const int s0 = pos;
     {
-        const int cnt = new_count;
-        int p2 = cnt - 1;
-        start_pt = __builtin_amdgcn_readlane(dv, p2);
-        if (++p2 >= cnt) p2 = 0;
-        int wpos = p2;
-        int pt = __builtin_amdgcn_readlane(dv, p2);
-        if (++p2 >= cnt) p2 = 0;
-        for (int i = 0; i < cnt && new_count > 2; ++i) {
-            const int end_pt = __builtin_amdgcn_readlane(dv, p2);
-            if (++p2 >= cnt) p2 = 0;
-            const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
-            const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
+        int far = right_start + s0;
+        if (far >= n) far -= n;
+        int t0 = j - s0, len_a = far - s0;
+        if (t0 < 0) t0 += n;
+        if (len_a < 0) len_a += n;
+        keep = live && (le_eps ? j == s0 : (j == s0 || j == far));
+        active = live && !le_eps && !keep;
+        if (t0 < len_a) { ss = s0; se = far; } else { ss = far; se = s0; }
+    }
+    while (__ballot(active) != 0ull) {
+        slots[lane] = 0u;
+        IRBPP_WAVE_SYNC();
+        int t = 0, dx = 0, dy = 0;
+        if (active) {
+            const int a = pts[ss], b = pts[se];
+            dx = IRBPP_PX(b) - IRBPP_PX(a);
+            dy = IRBPP_PY(b) - IRBPP_PY(a);
+            t = j - ss;
+            if (t < 0) t += n;
+            int dist = (py - IRBPP_PY(a)) * dx - (px - IRBPP_PX(a)) * dy;
+            dist = dist < 0 ? -dist : dist;
+            atomicMax(&slots[sb + ss], ((uint32_t)dist << 8) | (uint32_t)(255 - t));
+        }
+        IRBPP_WAVE_SYNC();
+        const uint32_t best = active ? slots[sb + ss] : 0u;
+        IRBPP_WAVE_SYNC();
+        if (active) {
+            const int md = (int)(best >> 8), ts = 255 - (int)(best & 255u);
+            if (md * md <= dx * dx + dy * dy) {
+                active = false;                          // slice accepted: its interior points are dropped
+            } else {
+                int sp = ss + ts;
+                if (sp >= n) sp -= n;
+                if (t == ts) { keep = true; active = false; }
+                else if (t < ts) se = sp;
+                else ss = sp;
+            }
+        }
+    }
+    // 3. the polygon = kept points in contour order; neighbours by bit scans on the ballot
+    const unsigned long long kept = __ballot(keep);
+    const unsigned long long seg = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sb;
+    const unsigned long long kb = kept & seg;
+    const int m = __popcll(kb);
+    bool redo = false, mark = false;
+    int prev_lane = lane, next_lane = lane;
+    if (keep) {
+        const unsigned long long hi = kb & ~((2ull << lane) - 1ull), lo = kb & ((1ull << lane) - 1ull);
+        next_lane = __ffsll((long long)(hi ? hi : kb)) - 1;
+        prev_lane = 63 - __clzll((long long)(lo ? lo : kb));
+    }
+    const int pa = __shfl(pv, prev_lane), pc = __shfl(pv, next_lane);
+    if (keep) {
+        const int ax = IRBPP_PX(pa), ay = IRBPP_PY(pa), cx = IRBPP_PX(pc), cy = IRBPP_PY(pc);
+        if (m > 2) {                                     // removal test of the clean-up pass (start = A, pt = me, end = C)
+            const int dx = cx - ax, dy = cy - ay, ux = px - ax, uy = py - ay;
             int dist = ux * dy - uy * dx;
             dist = dist < 0 ? -dist : dist;
-            const int inner = ux * (IRBPP_PX(end_pt) - IRBPP_PX(pt)) + uy * (IRBPP_PY(end_pt) - IRBPP_PY(pt));
-            if (2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0) {
-                --new_count;
-                start_pt = end_pt;
-                dv = put_lane(dv, wpos, end_pt);
-                if (++wpos >= cnt) wpos = 0;
-                pt = __builtin_amdgcn_readlane(dv, p2);
-                if (++p2 >= cnt) p2 = 0;
-                ++i;
-                continue;
-            }
-            start_pt = pt;
-            dv = put_lane(dv, wpos, pt);
-            if (++wpos >= cnt) wpos = 0;
-            pt = end_pt;
+            const int inner = ux * (cx - px) + uy * (cy - py);
+            redo = 2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0;
         }
+        mark = m <= 3 || (px - ax) * (cy - ay) - (py - ay) * (cx - ax) < 0;       // find_convex_vetex
     }
-    // find_convex_vetex, one vertex per lane (neighbours through the cross-lane network)
-    const int m = new_count;
-    {
-        const int ia = lane == 0 ? m - 1 : lane - 1, ic = lane == m - 1 ? 0 : lane + 1;
-        const int a = __shfl(dv, ia < 0 ? 0 : ia), c = __shfl(dv, ic > 63 ? 63 : ic), b = dv;
-        if (lane < m) {
-            bool keep = true;
-            if (m > 3)
-                keep = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
-                       (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a)) < 0;
-            if (keep) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
+    const unsigned long long flagged = __ballot(redo);
+    const bool border_redo = (flagged & seg) != 0ull;
+    if (mark && !border_redo) atomicOr(&vrows[py], 1u << px);
+    // borders whose polygon the clean-up pass changes (<1 %): one at a time, the polygon gathered into a
+    // lane-indexed register in its own order (it starts at the hop phase's start point)
+    unsigned long long pending = flagged;
+    while (pending != 0ull) {
+        const int l0 = __ffsll((long long)pending) - 1;
+        const int sb0 = __builtin_amdgcn_readlane(sb, l0), n0 = __builtin_amdgcn_readlane(n, l0);
+        const int s00 = __builtin_amdgcn_readlane(s0, l0);
+        const unsigned long long seg0 = (n0 >= 64 ? ~0ull : ((1ull << n0) - 1ull)) << sb0;
+        const unsigned long long kb0 = kept & seg0;
+        pending &= ~seg0;
+        const int cnt = __popcll(kb0);
+        const int first = sb0 + s00;                                 // lane of polygon vertex 0
+        if (keep && ((seg0 >> lane) & 1ull)) {
+            const unsigned long long below = kb0 & ((1ull << lane) - 1ull), below_first = kb0 & ((1ull << first) - 1ull);
+            const int rank = lane >= first ? __popcll(below) - __popcll(below_first)
+                                           : cnt - __popcll(below_first) + __popcll(below);
+            slots[rank] = (uint32_t)pv;
         }
+        IRBPP_WAVE_SYNC();
+        const int dv = lane < cnt ? (int)slots[lane] : 0;
+        IRBPP_WAVE_SYNC();
+        uint32_t* vr0 = vmask + __builtin_amdgcn_readlane(rot, l0) * 16;
+        cleanup_convex_wave(lane, dv, cnt, vr0);
     }
-    return true;
 }
 
 }  // namespace irbpp

@@ -71,14 +71,10 @@ void layout_lds(Params& P, int want_slots) {
     P.mg_ax = div_magic(P.Ax);
     P.mg_ac = div_magic(P.AC);
     P.mg_mbw = div_magic(P.mb_w);
-    P.nslot = want_slots > 0 ? want_slots : 64;                       // candidate starts traced per pass
-    if (P.nslot > 64) P.nslot = 64;                                   // overflow flags are one 64-bit word
-    if (P.nslot < 16) P.nslot = 16;
-    P.slot_cap = 64;                                                  // <= 64: the cooperative path keeps a border in one register per lane
-    P.slot_stk = 12;
-    P.long_border = 12;
-    if (const char* lb = getenv("IRBPP_LONG_BORDER")) P.long_border = atoi(lb);   // tuning knob
-    P.slot_bytes = 2 * P.slot_cap + 4 * P.slot_stk + 4;               // 180 B = 45 dwords: odd stride, lanes hit distinct LDS banks
+    (void)want_slots;
+    P.nslot = 64;                                                     // candidate starts traced per pass (16 per wave)
+    P.slot_cap = 64;                                                  // points of a border: one lane each in the segmented Douglas-Peucker
+    P.slot_bytes = P.slot_cap + 4;                                    // 68 B = 17 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
     P.o_posz = off;      off += align16(P.R * P.AC * 8);
     P.o_lev = off;       off += align16(P.R * P.AC);
@@ -93,22 +89,22 @@ void layout_lds(Params& P, int want_slots) {
     if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
-    P.o_red = off;       off += 512;                                  // reductions, flags, queue copy, long list, border sizes
-    // one region serves, in turn, the heightmap tile (apply + overlap test), the contour slots
-    // and the candidate keys: the tile's float32 copy is written out before the slots reuse it
+    P.o_red = off;       off += 256;                                  // reductions, flags, queue copy
+    // one region serves, in turn, the heightmap tile (apply + overlap test), the contour stage (border
+    // slots, the arg-max words of the segmented Douglas-Peucker, and at its end the 256 candidate starts of
+    // an image batch) and the candidate keys: the tile's float32 copy is written out before the reuse
     const int32_t slots = align16(P.nslot * P.slot_bytes);
-    int32_t scratch = slots;
+    const int32_t dps = 4 * 64 * 4;
+    int32_t scratch = slots + dps + 512;
     const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
     if (scratch < P.Hc * 8) scratch = P.Hc * 8;
     P.scratch_bytes = align16(scratch);
-    // the 256 candidate starts of an image (sub-)batch live behind the slots when the tile left room
-    const bool clist_in_scratch = slots + 512 <= P.scratch_bytes;
-    if (!clist_in_scratch) { P.o_clist = off; off += 512; }
     P.o_hm = off;
     P.o_scratch = off;
-    if (clist_in_scratch) P.o_clist = off + slots;
-    P.big_slot_bytes = clist_in_scratch ? slots : P.scratch_bytes;
+    P.o_dps = off + slots;
+    P.o_clist = off + P.scratch_bytes - 512;
+    P.big_slot_bytes = P.scratch_bytes - 512;          // the serial redo of a border may use everything below the candidate list
     off += P.scratch_bytes;
     if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tuning: caps workgroups per CU
     P.lds_bytes = off;

@@ -90,10 +90,9 @@ struct Params {
     int32_t traj_start, goff, gbins;
     int32_t obs_len0, obs_len1;
     // dynamic-LDS carve-up (byte offsets, all multiples of 16)
-    int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red;
-    int32_t nslot, slot_cap, slot_stk, slot_bytes, scratch_bytes, lds_bytes;
+    int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red, o_dps;
+    int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;
     int32_t big_slot_bytes;   // bytes of the scratch region the serial redo of an oversized border may use
-    int32_t long_border;   // borders with more points than this use the wave-cooperative Douglas-Peucker
     // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid
     // mb[pi][pj] = max of the b x b heightmap block at (pi*step, pj*step) replaces the cell list:

@@ -197,7 +197,7 @@ struct Lds {
     uint16_t* tasklist;     // [ntasks] rot<<8 | level code
     uint16_t* img;          // [2][IMGS][16] level images of the current batch: 16-bit row words, then column words
     uint16_t* clist;        // [256] candidate starts of the image (sub-)batch: image | x0<<6 | y0<<10
-    uint16_t* cn;           // [nslot] point count of each traced border of the current pass
+    uint32_t* dps;          // [WAVES][64] arg-max words of the segmented Douglas-Peucker, one set per wave
     uint32_t* vmask;
     unsigned char* scratch;
     double* redd;
@@ -215,7 +215,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.tasklist = (uint16_t*)(smem + P.o_tasklist);
     L.img = (uint16_t*)(smem + P.o_img);
     L.clist = (uint16_t*)(smem + P.o_clist);
-    L.cn = (uint16_t*)(smem + P.o_red + 256);
+    L.dps = (uint32_t*)(smem + P.o_dps);
     L.vmask = (uint32_t*)(smem + P.o_vmask);
     L.scratch = smem + P.o_scratch;
     L.redd = (double*)(smem + P.o_red);
@@ -252,6 +252,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
+        const long long t_img = prof ? (long long)clock64() : 0;
         for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
         __syncthreads();
         // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
@@ -329,73 +330,89 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         }
         __syncthreads();
         const int total = L.redi[10];
-        // (b) one lane per candidate, nslot per pass, all lanes running the same code
-        for (int c0 = 0; c0 < total; c0 += P.nslot) {
-            const int count = total - c0 < P.nslot ? total - c0 : P.nslot;
+        if (prof && tid == 0) prof[5] += (long long)clock64() - t_img;       // images, transposes, candidate list
+        // (b) 64 candidates per pass, spread over the four waves: candidate c is traced by lane c / 4 of wave
+        // c % 4, and each wave then runs approxPolyDP + convexity on the borders it traced itself, one
+        // contour POINT per lane (approx_convex_segmented), so a pass needs no block barrier between the two
+        constexpr int NPASS = 64, PER_WAVE = NPASS / WAVES;
+        const int wave = tid >> 6, lane = tid & 63;
+        uint32_t* const dps = L.dps + wave * 64;                     // this wave's arg-max words
+        for (int c0 = 0; c0 < total; c0 += NPASS) {
+            const int count = total - c0 < NPASS ? total - c0 : NPASS;
             const long long t_b = prof ? (long long)clock64() : 0;
-            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; L.redi[11] = 0; L.redi[12] = 0; }
+            if (tid == 0) { L.redi[8] = 0; L.redi[9] = 0; }
             __syncthreads();
             // (b1) trace; a candidate that is not the first pixel of its component returns 0 points
-            uint8_t* llist = (uint8_t*)(L.redi + 32);            // borders too long for the lockstep DP
+            const int c = lane * WAVES + wave;
             int my_n = 0, my_r = 0;
-            const SlotMem mine = carve_slot(L.scratch + tid * P.slot_bytes, P.slot_cap, P.slot_stk);
-            if (tid < count) {
-                const uint32_t e = L.clist[c0 + tid];
+            if (lane < PER_WAVE && c < count) {
+                const uint32_t e = L.clist[c0 + c];
                 const int gi = e & 63u;
                 my_r = L.tasklist[base + gi] >> 8;
                 int n = 0;
                 for (int rep = 0; rep < IRBPP_REPS(0); ++rep)
-                    n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u, mine.pts, mine.cap);
-                L.cn[tid] = (uint16_t)(n < 0 ? 0 : (n > 0xFFFF ? 0xFFFF : n));
+                    n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u,
+                                     L.scratch + c * P.slot_bytes, P.slot_cap);
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
-                else if (n > mine.cap) atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
-                else if (n > P.long_border) llist[atomicAdd(&L.redi[11], 1)] = (uint8_t)tid;
+                else if (n > P.slot_cap) atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
                 else my_n = n;
             }
-            __syncthreads();
-            // (b2) short borders: Douglas-Peucker + convexity per lane, still in lockstep
-            for (int rep = 0; rep < IRBPP_REPS(1); ++rep)
-            if (my_n > 0 && !approx_and_convex(mine.pts, my_n, mine.dst, mine.stk, mine.cap_stk, L.vmask + my_r * 16))
-                atomicOr(&L.redi[8 + (tid >> 5)], 1 << (tid & 31));
-            // (b3) long borders: each wave pulls one at a time and works on it with all 64 lanes
-            {
-                const int nlong = L.redi[11];
-                for (int guard2 = 0; guard2 < 64; ++guard2) {
-                    int li = 0;
-                    if ((tid & 63) == 0) li = atomicAdd(&L.redi[12], 1);
-                    li = __shfl(li, 0);
-                    if (li >= nlong) break;
-                    const int c = llist[li];
-                    const int r = L.tasklist[base + (L.clist[c0 + c] & 63u)] >> 8;
-                    const SlotMem m = carve_slot(L.scratch + c * P.slot_bytes, P.slot_cap, P.slot_stk);
-                    for (int rep = 0; rep < IRBPP_REPS(1); ++rep)
-                    if (!approx_and_convex_wave(m.pts, (int)L.cn[c], L.vmask + r * 16) && (tid & 63) == 0)
-                        atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
+            const long long t_tr = prof ? (long long)clock64() : 0;
+            // (b2) this wave's borders, packed back to back over the lanes: as many whole borders per
+            // round as fit into 64 points
+            for (int rep = 0; rep < IRBPP_REPS(1); ++rep) {
+            uint32_t todo = (uint32_t)__ballot(my_n > 0);
+            while (todo) {
+                uint32_t sel = 0u;
+                int sum = 0, mine = -1, sb = 0, nn = 1;
+                for (uint32_t bb = todo; bb; bb &= bb - 1u) {
+                    const int i = __ffs((int)bb) - 1;
+                    const int ni = __builtin_amdgcn_readlane(my_n, i);
+                    if (sum + ni > 64) break;
+                    if (lane >= sum && lane < sum + ni) { mine = i; sb = sum; nn = ni; }
+                    sel |= 1u << i;
+                    sum += ni;
                 }
+                todo &= ~sel;
+                const bool live = mine >= 0;
+                const int mc = (live ? mine : 0) * WAVES + wave;          // my border's slot
+                const uint8_t* pts = L.scratch + mc * P.slot_bytes;
+                const int jj = lane - sb;
+                const int pv = live ? (int)pts[jj] : 0;
+                const int rr = __shfl(my_r, live ? mine : 0);
+                approx_convex_segmented(lane, live, pv, jj, nn, sb, pts, dps, L.vmask, rr);
             }
+            }
+            const long long t_dp = prof ? (long long)clock64() : 0;
             __syncthreads();
-            // (b4) a border that outgrew its slot (points or stack): lane 0 redoes it in one big slot,
-            // so slot capacity never changes results
+            const long long t_bar = prof ? (long long)clock64() : 0;
+            // (b3) a border that outgrew its slot (more than 64 points: pathological speckle): lane 0 redoes it
+            // with the sequential routine in one big slot
             {
                 const unsigned long long redo = ((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8];
                 if (redo != 0ull) {
                     if (tid == 0) {
                         const int cap = (P.big_slot_bytes / 6) & ~3;
                         const SlotMem m = carve_slot(L.scratch, cap, cap);
-                        for (int c = 0; c < count; ++c) {
-                            if (!((redo >> c) & 1ull)) continue;
-                            const uint32_t e = L.clist[c0 + c];
+                        for (int cc = 0; cc < count; ++cc) {
+                            if (!((redo >> cc) & 1ull)) continue;
+                            const uint32_t e = L.clist[c0 + cc];
                             const int gi = e & 63u;
                             const int r = L.tasklist[base + gi] >> 8;
                             if (contour_vertices(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u, m,
-                                                 L.vmask + r * 16) == 2)
-                                atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                                                 L.vmask + r * 16) != 0)
+                                atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);          // never silently drop a border
                         }
                     }
                     __syncthreads();
                 }
             }
-            if (prof && tid == 0) { prof[6] += (long long)clock64() - t_b; prof[7] += count; }
+            if (prof && tid == 0) {                 // wave 0's view of the pass
+                const long long t_e = (long long)clock64();
+                prof[6] += t_e - t_b; prof[7] += count;
+                prof[11] += t_tr - t_b; prof[12] += t_dp - t_tr; prof[13] += t_bar - t_dp; prof[14] += t_e - t_bar;
+                prof[15] += __popcll(((unsigned long long)(unsigned)L.redi[9] << 32) | (unsigned)L.redi[8]);
+            }
         }
         }
     }
@@ -649,7 +666,9 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     __syncthreads();
     stamp(io, b, 2);
 
-    if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * PHASE_ROW + 5] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 6] = 0; io.phase_cycles[(size_t)b * PHASE_ROW + 7] = 0; }
+    if (io.phase_cycles && tid == 0)
+        for (int k = 5; k < PHASE_ROW; ++k)
+            if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
     for (int rep = 0; rep < IRBPP_REPS(4); ++rep)
     contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * PHASE_ROW : nullptr);
     stamp(io, b, 3);

@@ -17,6 +17,12 @@ struct { unsigned x; } threadIdx = {0};
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) (v)
 #define __shfl(v, l) (v)
+#define IRBPP_WAVE_SYNC()
+static inline unsigned long long __ballot(bool p) { return p ? 1ull : 0ull; }
+static inline unsigned atomicMax(uint32_t* p, uint32_t v) { const unsigned o = *p; if (v > o) *p = v; return o; }
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 #include "../../irbpp_amd/csrc/contours_device.h"
 

@@ -45,22 +45,53 @@ static inline int emu_dpp(int old, int v, int ctrl, int row_mask) {
 #define __builtin_amdgcn_readfirstlane(v) xchg((v), 0)
 #define __builtin_amdgcn_update_dpp(old, v, ctrl, rm, bm, bc) emu_dpp((old), (v), (ctrl), (rm))
 #define __shfl(v, l) xchg((v), (l))
+// a wave executes one instruction for all lanes before the next: where lanes talk through LDS the
+// device code has a scheduling-only wave barrier, which here is a real one
+#define IRBPP_WAVE_SYNC() pthread_barrier_wait(&g_bar)
+static unsigned long long g_bal;
+static inline unsigned long long __ballot(bool p) {
+    if ((threadIdx.x & 63) == 0) g_bal = 0ull;
+    pthread_barrier_wait(&g_bar);
+    if (p) __atomic_fetch_or(&g_bal, 1ull << (threadIdx.x & 63), __ATOMIC_RELAXED);
+    pthread_barrier_wait(&g_bar);
+    const unsigned long long r = g_bal;
+    pthread_barrier_wait(&g_bar);
+    return r;
+}
+static inline unsigned atomicMax(uint32_t* p, uint32_t v) {
+    uint32_t o = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (o < v && !__atomic_compare_exchange_n(p, &o, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return o;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
+static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
 #include "../../irbpp_amd/csrc/contours_device.h"
 
-extern "C" int host_approx_and_convex_wave(const uint8_t* pts, int count, uint32_t* vrows) {
-    memset(vrows, 0, 16 * sizeof(uint32_t));
+// Several borders packed back to back over the 64 lanes, exactly as the contour stage of the kernel packs
+// them: counts[b] points each (sum <= 64), pts = the borders' point lists one after the other.
+// vrows[b*16 .. b*16+15] receives the vertex bits of border b (border b plays 'rotation' b).
+extern "C" int host_approx_convex_segmented(const uint8_t* pts, const int* counts, int n_borders, uint32_t* vrows, int* redo) {
+    memset(vrows, 0, (size_t)n_borders * 16 * sizeof(uint32_t));
+    memset(redo, 0, (size_t)n_borders * sizeof(int));
     pthread_barrier_init(&g_bar, nullptr, 64);
-    int ok[64];
+    static uint32_t slots[64];
     std::vector<std::thread> lanes;
     for (int l = 0; l < 64; ++l)
         lanes.emplace_back([&, l] {
             threadIdx.x = (unsigned)l;
-            ok[l] = irbpp::approx_and_convex_wave(pts, count, vrows) ? 1 : 0;
+            int off = 0, mine = -1, sb = 0, nn = 1;
+            for (int b = 0; b < n_borders; ++b) {
+                if (l >= off && l < off + counts[b]) { mine = b; sb = off; nn = counts[b]; }
+                off += counts[b];
+            }
+            const bool live = mine >= 0;
+            const uint8_t* my_pts = pts + sb;
+            const int j = l - sb;
+            irbpp::approx_convex_segmented(l, live, live ? my_pts[j] : 0, j, nn, sb, my_pts, slots, vrows, live ? mine : 0);
         });
     for (auto& t : lanes) t.join();
     pthread_barrier_destroy(&g_bar);
-    for (int l = 1; l < 64; ++l)
-        if (ok[l] != ok[0]) return -1;                     // the result must be wave-uniform
-    return ok[0];
+    return 0;
 }

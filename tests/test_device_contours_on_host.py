@@ -34,8 +34,8 @@ def wave():
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-value",
                     "-I", os.path.join(HERE, "host", "stub"), WAVE_SRC, "-o", WAVE_OUT], check=True)
     lib = C.CDLL(WAVE_OUT)
-    lib.host_approx_and_convex_wave.argtypes = [u8p, C.c_int, u32p]
-    lib.host_approx_and_convex_wave.restype = C.c_int
+    lib.host_approx_convex_segmented.argtypes = [u8p, C.POINTER(C.c_int), C.c_int, u32p, C.POINTER(C.c_int)]
+    lib.host_approx_convex_segmented.restype = C.c_int
     return lib
 
 
@@ -166,33 +166,88 @@ def test_flattened_douglas_peucker_on_synthetic_polygons(host):
         assert got == _oracle_vertices(poly)
 
 
-def test_wave_cooperative_douglas_peucker_in_lockstep_emulation(wave):
-    """approx_and_convex_wave: the routine the kernel uses for borders of more than 12 points."""
-    vrows = (C.c_uint32 * 16)()
-    done = 0
-    for img in _images(300, 60):
+def _cleanup_changes(poly):
+    """Does the final clean-up pass of approxPolyDP change this contour's Douglas-Peucker polygon?  Checked with
+    an independent recursion that stops before the clean-up (hops, then split-or-accept per slice)."""
+    P, n = np.array(poly, dtype=np.int64), len(poly)
+    if n == 1:
+        return False
+    pos = rs = md = 0
+    for _ in range(3):
+        pos, md = (pos + rs) % n, 0
+        for j in range(1, n):
+            d = int(((P[(pos + j) % n] - P[pos]) ** 2).sum())
+            if d > md:
+                md, rs = d, j
+    if md <= 1:
+        return False
+    s0, far = pos, (pos + rs) % n
+    keep, work = {s0, far}, [(s0, far), (far, s0)]
+    while work:
+        a, b = work.pop()
+        ln = (b - a) % n or n
+        dx, dy = (P[b] - P[a]).tolist()
+        best, sp = 0, -1
+        for t in range(1, ln):
+            q = P[(a + t) % n]
+            d = abs(int((q[1] - P[a][1]) * dx - (q[0] - P[a][0]) * dy))
+            if d > best:
+                best, sp = d, (a + t) % n
+        if best * best > dx * dx + dy * dy:
+            keep.add(sp)
+            work += [(a, sp), (sp, b)]
+    before = [tuple(int(v) for v in P[j]) for j in sorted(keep, key=lambda j: (j - s0) % n)]
+    c = np.array(poly, dtype=np.int32).reshape(-1, 1, 2)
+    after = [tuple(int(v) for v in q) for q in OC.approx_poly_dp(c, 1, True).reshape(-1, 2)]
+    return before != after
+
+
+def test_segmented_douglas_peucker_in_lockstep_emulation(wave):
+    """approx_convex_segmented: approxPolyDP + convexity for several borders at once, one contour point per
+    lane, as the kernel runs it.  Borders are packed back to back (<= 64 points per call) exactly like the
+    contour stage packs them, including borders whose polygon the sequential clean-up pass of approxPolyDP
+    changes (handled wave-uniformly inside the routine)."""
+    def run(polys):
+        counts = (C.c_int * len(polys))(*[len(q) for q in polys])
+        flat = [x | (y << 4) for q in polys for x, y in q]
+        arr = (C.c_uint8 * max(1, len(flat)))(*flat)
+        vrows = (C.c_uint32 * (16 * len(polys)))()
+        redo = (C.c_int * len(polys))()
+        assert wave.host_approx_convex_segmented(arr, counts, len(polys), vrows, redo) == 0
+        for b, q in enumerate(polys):
+            got = {(x, y) for y in range(16) for x in range(16) if (vrows[b * 16 + y] >> x) & 1}
+            assert got == _oracle_vertices(q), q
+        return sum(1 for q in polys if _cleanup_changes(q))
+
+    done = flagged = 0
+    batch, room = [], 64
+    for img in _images(300, 70):
         outer, _, _ = _oracle_outer(img)
         for c in outer:
-            if not 1 <= len(c) <= 64 or (len(c) <= 12 and done % 4):      # mostly the long ones
+            if not 1 <= len(c) <= 64:
                 continue
-            arr = (C.c_uint8 * len(c))(*[x | (y << 4) for x, y in c])
-            assert wave.host_approx_and_convex_wave(arr, len(c), vrows) == 1
-            got = {(x, y) for y in range(16) for x in range(16) if (vrows[y] >> x) & 1}
-            assert got == _oracle_vertices(c), c
-            done += 1
+            if len(c) > room:
+                flagged += run(batch)
+                done += len(batch)
+                batch, room = [], 64
+            batch.append(c)
+            room -= len(c)
+    flagged += run(batch)
+    done += len(batch)
     rng = np.random.RandomState(11)
-    for _ in range(40):                                               # arbitrary closed walks, up to the 64-point limit
-        n = rng.randint(1, 65)
-        x, y = rng.randint(0, 16), rng.randint(0, 16)
-        poly = [(x, y)]
-        while len(poly) < n:
-            x = int(np.clip(x + rng.randint(-1, 2), 0, 15))
-            y = int(np.clip(y + rng.randint(-1, 2), 0, 15))
-            if (x, y) != poly[-1]:
-                poly.append((x, y))
-        arr = (C.c_uint8 * len(poly))(*[px | (py << 4) for px, py in poly])
-        assert wave.host_approx_and_convex_wave(arr, len(poly), vrows) == 1
-        got = {(xx, yy) for yy in range(16) for xx in range(16) if (vrows[yy] >> xx) & 1}
-        assert got == _oracle_vertices(poly), poly
-        done += 1
-    assert done > 60                                                  # (each call is 64 threads and ~10^3 barriers)
+    for _ in range(60):                                               # arbitrary closed walks, packed three to a wave
+        polys = []
+        for n in (rng.randint(1, 30), rng.randint(1, 20), rng.randint(1, 15)):
+            x, y = rng.randint(0, 16), rng.randint(0, 16)
+            poly = [(x, y)]
+            while len(poly) < n:
+                x = int(np.clip(x + rng.randint(-1, 2), 0, 15))
+                y = int(np.clip(y + rng.randint(-1, 2), 0, 15))
+                if (x, y) != poly[-1]:
+                    poly.append((x, y))
+            polys.append(poly)
+        flagged += run(polys)
+        done += 3
+    full = [(i % 16, (i // 16) * 2 + (i % 2)) for i in range(64)]     # one border filling all 64 lanes
+    flagged += run([full])
+    assert done > 300 and flagged >= 3                                # the clean-up branch was exercised

@@ -38,7 +38,7 @@ for _ in range(a.steps):
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
     acc.append(np.diff(c[:, :5], axis=1))
-    extra.append(c[:, 5:8].copy())
+    extra.append(np.concatenate([c[:, 5:8], c[:, 11:16]], axis=1))
 d = np.concatenate(acc)
 ncand = (obs[:, :2500].reshape(a.bins, 500, 5)[:, :, 4] == 1).sum(1).float()
 out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
@@ -51,5 +51,8 @@ out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
 ex = np.concatenate(extra)
 out["contour_detail"] = {"extract_mean": float(ex[:, 0].mean()), "extract_max": float(ex[:, 0].max()),
                          "process_mean": float(ex[:, 1].mean()), "process_max": float(ex[:, 1].max()),
-                         "borders_mean": float(ex[:, 2].mean()), "borders_max": float(ex[:, 2].max())}
+                         "borders_mean": float(ex[:, 2].mean()), "borders_max": float(ex[:, 2].max()),
+                         "wave0_trace_mean": float(ex[:, 3].mean()), "wave0_dp_mean": float(ex[:, 4].mean()),
+                         "wave0_barrier_wait_mean": float(ex[:, 5].mean()), "redo_mean": float(ex[:, 6].mean()),
+                         "redo_borders_mean": float(ex[:, 7].mean())}
 print(json.dumps(out))
