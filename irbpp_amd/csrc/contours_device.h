@@ -27,6 +27,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef IRBPP_TRACE_ITER
+#define IRBPP_TRACE_ITER()       // host tooling counts the iterations of the border walk here
+#endif
+
 namespace irbpp {
 
 struct SlotMem {
@@ -75,71 +79,94 @@ __device__ __forceinline__ int run_backward(uint32_t line, uint32_t side, int p)
     return z ? p - (31 - __clz((int)z)) : p + 1;
 }
 
-// icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border starting at (x0,y0).  The
-// 3-row window around the current pixel stays in registers; axis-aligned runs are jumped in one
-// go.  img = 16 row words, imgT = 16 column words (bit y of word x).  Returns the number of
-// points produced (stored only while they fit in cap); 0 if the walk met a pixel that precedes
-// (x0,y0) in raster order, i.e. (x0,y0) is not the first pixel of its component and the border
-// belongs to another start (or is a hole border); -1 if the iteration guard tripped.
-__device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
-    uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
-    uint32_t nb = nb_mask(ra, rb, rc, x0);
+// icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border starting at (x0,y0), as a resumable
+// walk: trace_init() + one trace_step() per direction change / diagonal step, so that a wave can keep all
+// its lanes busy by handing a lane the next border as soon as its current one is closed (trace kernel), or
+// simply loop to the end (trace_border).  The neighbour mask of the current pixel stays in the state;
+// axis-aligned runs are jumped in one go.  img = 16 row words, imgT = 16 column words (bit y of word x).
+struct TraceState {
+    int x0, y0, x1, y1, s;        // start pixel, its first neighbour, the first direction
+    int x3, y3, cur_s, prev_s;    // current pixel, direction back to the previous pixel, last move
+    uint32_t nb;                  // 8-bit neighbour mask of the current pixel
+    int n;                        // points produced so far (stored only while they fit)
+};
+constexpr int TRACE_RUNNING = -2;
+
+// Returns 1 for an isolated pixel (its single point stored), else TRACE_RUNNING.
+__device__ inline int trace_init(TraceState& t, const uint16_t* img, int x0, int y0, uint8_t* pts, int cap) {
+    const uint32_t ra = y0 > 0 ? img[y0 - 1] : 0u, rb = img[y0], rc = y0 < 15 ? img[y0 + 1] : 0u;
+    t.nb = nb_mask(ra, rb, rc, x0);
     // clockwise search 3,2,1,0,7,6,5 (s_end = 4: the west pixel is background) for the first neighbour
-    const uint32_t rot = ((nb << 4) | (nb >> 4)) & 0xFFu;         // direction 3 -> bit 7
+    const uint32_t rot = ((t.nb << 4) | (t.nb >> 4)) & 0xFFu;     // direction 3 -> bit 7
+    t.x0 = t.x3 = x0;
+    t.y0 = t.y3 = y0;
+    t.n = 0;
     if (rot == 0u) {                                              // isolated pixel
         if (cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
+        t.s = t.x1 = t.y1 = t.cur_s = t.prev_s = 0;
         return 1;
     }
-    const int s = (3 - (7 - (31 - __clz((int)rot)))) & 7;
-    int x3 = x0, y3 = y0;
-    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
-    int prev_s = s ^ 4;
-    int cur_s = s;
-    int n = 0;
-    for (int guard = 0; guard < 4096; ++guard) {
-        // counter-clockwise search cur_s+1, cur_s+2, ... for the next border pixel
-        const int k2 = (cur_s + 1) & 7;
-        const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
-        const int s2 = (k2 + __ffs((int)r2) - 1) & 7;
-        int x4 = x3 + dir_dx(s2), y4 = y3 + dir_dy(s2);
-        if (s2 != prev_s) {                                       // CHAIN_APPROX_SIMPLE
-            if (n < cap) pts[n] = (uint8_t)(x3 | (y3 << 4));
-            ++n;
-        }
-        prev_s = s2;
-        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-        // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run.
-        // Branch-free on purpose: the lanes of a wave walk different borders in lockstep.
-        {
-            const bool horiz = (s2 & 3) == 0;                     // E or W: walk a row, else a column
-            const bool fwd = s2 == 0 || s2 == 6;                  // E or S: towards higher bits
-            const uint16_t* base = horiz ? img : imgT;
-            const int li = horiz ? y4 : x4;
-            const int si = (horiz == fwd) ? li + 1 : li - 1;      // E: row below, W: row above, S: column left, N: column right
-            int p = horiz ? x4 : y4;
-            const uint32_t line = base[li];
-            const uint32_t side = base[si & 15];
-            const uint32_t side_ok = (unsigned)si < 16u ? side : 0u;
-            const int lf = run_forward(line, side_ok, p), lb = run_backward(line, side_ok, p);
-            const int L = (s2 & 1) ? 0 : (fwd ? lf : -lb);
-            p += L;
-            x4 = horiz ? p : x4;
-            y4 = horiz ? y4 : p;
-        }
-        // a run that ends on the start pixel, moving opposite to the first step, closes the border
-        if (x4 == x0 && y4 == y0 && s2 == (s ^ 4)) return n;
-        // run interiors lie between their end points in raster order, so testing end points suffices
-        if (y4 * 16 + x4 < y0 * 16 + x0) return 0;
-        const uint32_t a = img[(y4 - 1) & 15], b = img[y4], c = img[(y4 + 1) & 15];
-        ra = y4 > 0 ? a : 0u;
-        rb = b;
-        rc = y4 < 15 ? c : 0u;
-        x3 = x4;
-        y3 = y4;
-        cur_s = (s2 + 4) & 7;
-        nb = nb_mask(ra, rb, rc, x3);
+    t.s = (3 - (7 - (31 - __clz((int)rot)))) & 7;
+    t.x1 = x0 + dir_dx(t.s);
+    t.y1 = y0 + dir_dy(t.s);
+    t.prev_s = t.s ^ 4;
+    t.cur_s = t.s;
+    return TRACE_RUNNING;
+}
+
+// One step of the walk.  Returns TRACE_RUNNING, or the final number of points: 0 if the walk met a pixel
+// that precedes (x0,y0) in raster order, i.e. (x0,y0) is not the first pixel of its component and the
+// border belongs to another start (or is a hole border).
+__device__ inline int trace_step(TraceState& t, const uint16_t* img, const uint16_t* imgT, uint8_t* pts, int cap) {
+    IRBPP_TRACE_ITER();
+    // counter-clockwise search cur_s+1, cur_s+2, ... for the next border pixel
+    const int k2 = (t.cur_s + 1) & 7;
+    const uint32_t r2 = ((t.nb >> k2) | (t.nb << (8 - k2))) & 0xFFu;   // direction k2 -> bit 0
+    const int s2 = (k2 + __ffs((int)r2) - 1) & 7;
+    int x4 = t.x3 + dir_dx(s2), y4 = t.y3 + dir_dy(s2);
+    if (s2 != t.prev_s) {                                         // CHAIN_APPROX_SIMPLE
+        if (t.n < cap) pts[t.n] = (uint8_t)(t.x3 | (t.y3 << 4));
+        ++t.n;
     }
-    return -1;
+    t.prev_s = s2;
+    if (x4 == t.x0 && y4 == t.y0 && t.x3 == t.x1 && t.y3 == t.y1) return t.n;
+    // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run.
+    // Branch-free on purpose: the lanes of a wave walk different borders in lockstep.
+    {
+        const bool horiz = (s2 & 3) == 0;                         // E or W: walk a row, else a column
+        const bool fwd = s2 == 0 || s2 == 6;                      // E or S: towards higher bits
+        const uint16_t* base = horiz ? img : imgT;
+        const int li = horiz ? y4 : x4;
+        const int si = (horiz == fwd) ? li + 1 : li - 1;          // E: row below, W: row above, S: column left, N: column right
+        int p = horiz ? x4 : y4;
+        const uint32_t line = base[li];
+        const uint32_t side = base[si & 15];
+        const uint32_t side_ok = (unsigned)si < 16u ? side : 0u;
+        const int lf = run_forward(line, side_ok, p), lb = run_backward(line, side_ok, p);
+        const int L = (s2 & 1) ? 0 : (fwd ? lf : -lb);
+        p += L;
+        x4 = horiz ? p : x4;
+        y4 = horiz ? y4 : p;
+    }
+    // a run that ends on the start pixel, moving opposite to the first step, closes the border
+    if (x4 == t.x0 && y4 == t.y0 && s2 == (t.s ^ 4)) return t.n;
+    // run interiors lie between their end points in raster order, so testing end points suffices
+    if (y4 * 16 + x4 < t.y0 * 16 + t.x0) return 0;
+    const uint32_t a = img[(y4 - 1) & 15], b = img[y4], c = img[(y4 + 1) & 15];
+    t.x3 = x4;
+    t.y3 = y4;
+    t.cur_s = (s2 + 4) & 7;
+    t.nb = nb_mask(y4 > 0 ? a : 0u, b, y4 < 15 ? c : 0u, x4);
+    return TRACE_RUNNING;
+}
+
+// The whole border in one go: number of points, 0 if (x0,y0) does not start an outer border, -1 if the
+// iteration guard tripped.
+__device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, int x0, int y0, uint8_t* pts, int cap) {
+    TraceState t;
+    int r = trace_init(t, img, x0, y0, pts, cap);
+    for (int guard = 0; guard < 4096 && r == TRACE_RUNNING; ++guard) r = trace_step(t, img, imgT, pts, cap);
+    return r == TRACE_RUNNING ? -1 : r;
 }
 
 #define IRBPP_PX(p) ((int)((p) & 15))
@@ -357,129 +384,270 @@ __device__ inline void cleanup_convex_wave(int lane, int dv, int cnt, uint32_t* 
     }
 }
 
-// lane:  my lane in the wave;  live: I hold a point;  pv: my point (x | y<<4);  j, n: my index in / size of
-// my border;  sb: lane of my border's point 0;  pts: my border's point list in LDS;  slots: 64 words of LDS
-// private to this wave;  vmask: vertex rows of all rotations (wave-uniform), rot: my border's rotation.
-__device__ inline void approx_convex_segmented(int lane, bool live, int pv, int j, int n, int sb, const uint8_t* pts,
-                                               uint32_t* slots, uint32_t* vmask, int rot) {
-    uint32_t* const vrows = vmask + rot * 16;
-    const int px = IRBPP_PX(pv), py = IRBPP_PY(pv);
+// The same clean-up + convexity for a polygon of more than 64 vertices (a border of more than 64 points whose
+// polygon the clean-up changes: rarest of the rare), by one lane on a byte array it may overwrite.
+__device__ inline void cleanup_convex_serial(uint8_t* dst, int cnt, uint32_t* vrows) {
+    int new_count = cnt;
+    int pos = cnt - 1;
+    uint8_t start_pt = dst[pos];
+    if (++pos >= cnt) pos = 0;
+    int wpos = pos;
+    uint8_t pt = dst[pos];
+    if (++pos >= cnt) pos = 0;
+    for (int i = 0; i < cnt && new_count > 2; ++i) {
+        const uint8_t end_pt = dst[pos];
+        if (++pos >= cnt) pos = 0;
+        const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
+        const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
+        int dist = ux * dy - uy * dx;
+        dist = dist < 0 ? -dist : dist;
+        const int inner = ux * (IRBPP_PX(end_pt) - IRBPP_PX(pt)) + uy * (IRBPP_PY(end_pt) - IRBPP_PY(pt));
+        if (2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0) {
+            --new_count;
+            dst[wpos] = start_pt = end_pt;
+            if (++wpos >= cnt) wpos = 0;
+            pt = dst[pos];
+            if (++pos >= cnt) pos = 0;
+            ++i;
+            continue;
+        }
+        dst[wpos] = start_pt = pt;
+        if (++wpos >= cnt) wpos = 0;
+        pt = end_pt;
+    }
+    const int m = new_count;
+    if (m <= 3) {
+        for (int i = 0; i < m; ++i) atomicOr(&vrows[IRBPP_PY(dst[i])], 1u << IRBPP_PX(dst[i]));
+    } else {
+        uint8_t a = dst[m - 1], b = dst[0];
+        for (int i = 0; i < m; ++i) {
+            const uint8_t c = dst[i == m - 1 ? 0 : i + 1];
+            const int cross = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
+                              (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a));
+            if (cross < 0) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
+            a = b;
+            b = c;
+        }
+    }
+}
+
+// A wave serves 64 * P contour points per round: position q = u * 64 + lane, u < P, borders packed back to
+// back over the positions (a border of up to 64 * P points fits).  Per position:
+//   live: a point sits here;  pv: the point (x | y<<4);  j, n: its index in / the size of its border;
+//   sb: position of its border's point 0;  pts: its border's point list in LDS;  rot: row block of its
+//   border's vertex bits in `vmask`.
+// slots: 64 * P words of LDS private to this wave;  scratch: 64 * P bytes of LDS private to this wave.
+template <int P>
+__device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], const int (&pv)[P], const int (&j)[P],
+                                               const int (&n)[P], const int (&sb)[P], const uint8_t* const (&pts)[P],
+                                               const int (&rot)[P], uint32_t* slots, uint8_t* scratch, uint32_t* vmask) {
+    int px[P], py[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) { px[u] = IRBPP_PX(pv[u]); py[u] = IRBPP_PY(pv[u]); }
     // 1. three farthest-point hops
-    int pos = 0, right_start = 0;
-    bool le_eps = false;
+    int pos[P], right_start[P];
+    bool le_eps[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) { pos[u] = 0; right_start[u] = 0; le_eps[u] = false; }
     for (int it = 0; it < 3; ++it) {
-        pos += right_start;
-        if (pos >= n) pos -= n;
-        slots[lane] = 0u;
-        IRBPP_WAVE_SYNC();
-        if (live) {
-            const int sp = pts[pos];
-            int t = j - pos;
-            if (t < 0) t += n;
-            const int dx = px - IRBPP_PX(sp), dy = py - IRBPP_PY(sp);
-            if (t >= 1) atomicMax(&slots[sb], ((uint32_t)(dx * dx + dy * dy) << 8) | (uint32_t)(255 - t));
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            pos[u] += right_start[u];
+            if (pos[u] >= n[u]) pos[u] -= n[u];
+            slots[u * 64 + lane] = 0u;
         }
         IRBPP_WAVE_SYNC();
-        const uint32_t best = live ? slots[sb] : 0u;
-        IRBPP_WAVE_SYNC();
-        const int max_dist = (int)(best >> 8);
-        if (max_dist > 0) right_start = 255 - (int)(best & 255u);
-        le_eps = max_dist <= 1;
-    }
-    // 2. Douglas-Peucker, all slices of one recursion level per round
-    bool keep, active;
-    int ss = 0, se = 0;
-    const int s0 = pos;
-    {
-        int far = right_start + s0;
-        if (far >= n) far -= n;
-        int t0 = j - s0, len_a = far - s0;
-        if (t0 < 0) t0 += n;
-        if (len_a < 0) len_a += n;
-        keep = live && (le_eps ? j == s0 : (j == s0 || j == far));
-        active = live && !le_eps && !keep;
-        if (t0 < len_a) { ss = s0; se = far; } else { ss = far; se = s0; }
-    }
-    while (__ballot(active) != 0ull) {
-        slots[lane] = 0u;
-        IRBPP_WAVE_SYNC();
-        int t = 0, dx = 0, dy = 0;
-        if (active) {
-            const int a = pts[ss], b = pts[se];
-            dx = IRBPP_PX(b) - IRBPP_PX(a);
-            dy = IRBPP_PY(b) - IRBPP_PY(a);
-            t = j - ss;
-            if (t < 0) t += n;
-            int dist = (py - IRBPP_PY(a)) * dx - (px - IRBPP_PX(a)) * dy;
-            dist = dist < 0 ? -dist : dist;
-            atomicMax(&slots[sb + ss], ((uint32_t)dist << 8) | (uint32_t)(255 - t));
-        }
-        IRBPP_WAVE_SYNC();
-        const uint32_t best = active ? slots[sb + ss] : 0u;
-        IRBPP_WAVE_SYNC();
-        if (active) {
-            const int md = (int)(best >> 8), ts = 255 - (int)(best & 255u);
-            if (md * md <= dx * dx + dy * dy) {
-                active = false;                          // slice accepted: its interior points are dropped
-            } else {
-                int sp = ss + ts;
-                if (sp >= n) sp -= n;
-                if (t == ts) { keep = true; active = false; }
-                else if (t < ts) se = sp;
-                else ss = sp;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            if (live[u]) {
+                const int sp = pts[u][pos[u]];
+                int t = j[u] - pos[u];
+                if (t < 0) t += n[u];
+                const int dx = px[u] - IRBPP_PX(sp), dy = py[u] - IRBPP_PY(sp);
+                if (t >= 1) atomicMax(&slots[sb[u]], ((uint32_t)(dx * dx + dy * dy) << 8) | (uint32_t)(255 - t));
             }
         }
-    }
-    // 3. the polygon = kept points in contour order; neighbours by bit scans on the ballot
-    const unsigned long long kept = __ballot(keep);
-    const unsigned long long seg = (n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << sb;
-    const unsigned long long kb = kept & seg;
-    const int m = __popcll(kb);
-    bool redo = false, mark = false;
-    int prev_lane = lane, next_lane = lane;
-    if (keep) {
-        const unsigned long long hi = kb & ~((2ull << lane) - 1ull), lo = kb & ((1ull << lane) - 1ull);
-        next_lane = __ffsll((long long)(hi ? hi : kb)) - 1;
-        prev_lane = 63 - __clzll((long long)(lo ? lo : kb));
-    }
-    const int pa = __shfl(pv, prev_lane), pc = __shfl(pv, next_lane);
-    if (keep) {
-        const int ax = IRBPP_PX(pa), ay = IRBPP_PY(pa), cx = IRBPP_PX(pc), cy = IRBPP_PY(pc);
-        if (m > 2) {                                     // removal test of the clean-up pass (start = A, pt = me, end = C)
-            const int dx = cx - ax, dy = cy - ay, ux = px - ax, uy = py - ay;
-            int dist = ux * dy - uy * dx;
-            dist = dist < 0 ? -dist : dist;
-            const int inner = ux * (cx - px) + uy * (cy - py);
-            redo = 2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0;
+        IRBPP_WAVE_SYNC();
+        uint32_t best[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) best[u] = live[u] ? slots[sb[u]] : 0u;
+        IRBPP_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            const int max_dist = (int)(best[u] >> 8);
+            if (max_dist > 0) right_start[u] = 255 - (int)(best[u] & 255u);
+            le_eps[u] = max_dist <= 1;
         }
-        mark = m <= 3 || (px - ax) * (cy - ay) - (py - ay) * (cx - ax) < 0;       // find_convex_vetex
     }
-    const unsigned long long flagged = __ballot(redo);
-    const bool border_redo = (flagged & seg) != 0ull;
-    if (mark && !border_redo) atomicOr(&vrows[py], 1u << px);
-    // borders whose polygon the clean-up pass changes (<1 %): one at a time, the polygon gathered into a
-    // lane-indexed register in its own order (it starts at the hop phase's start point)
-    unsigned long long pending = flagged;
-    while (pending != 0ull) {
-        const int l0 = __ffsll((long long)pending) - 1;
-        const int sb0 = __builtin_amdgcn_readlane(sb, l0), n0 = __builtin_amdgcn_readlane(n, l0);
-        const int s00 = __builtin_amdgcn_readlane(s0, l0);
-        const unsigned long long seg0 = (n0 >= 64 ? ~0ull : ((1ull << n0) - 1ull)) << sb0;
-        const unsigned long long kb0 = kept & seg0;
-        pending &= ~seg0;
-        const int cnt = __popcll(kb0);
-        const int first = sb0 + s00;                                 // lane of polygon vertex 0
-        if (keep && ((seg0 >> lane) & 1ull)) {
-            const unsigned long long below = kb0 & ((1ull << lane) - 1ull), below_first = kb0 & ((1ull << first) - 1ull);
-            const int rank = lane >= first ? __popcll(below) - __popcll(below_first)
-                                           : cnt - __popcll(below_first) + __popcll(below);
-            slots[rank] = (uint32_t)pv;
+    // 2. Douglas-Peucker, all slices of one recursion level per round
+    bool keep[P], active[P];
+    int ss[P], se[P], s0[P];
+    bool any_active = false;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        s0[u] = pos[u];
+        int far = right_start[u] + s0[u];
+        if (far >= n[u]) far -= n[u];
+        int t0 = j[u] - s0[u], len_a = far - s0[u];
+        if (t0 < 0) t0 += n[u];
+        if (len_a < 0) len_a += n[u];
+        keep[u] = live[u] && (le_eps[u] ? j[u] == s0[u] : (j[u] == s0[u] || j[u] == far));
+        active[u] = live[u] && !le_eps[u] && !keep[u];
+        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; } else { ss[u] = far; se[u] = s0[u]; }
+        any_active |= active[u];
+    }
+    while (__ballot(any_active) != 0ull) {
+#pragma unroll
+        for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
+        IRBPP_WAVE_SYNC();
+        int t[P], dx[P], dy[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            t[u] = dx[u] = dy[u] = 0;
+            if (active[u]) {
+                const int a = pts[u][ss[u]], b = pts[u][se[u]];
+                dx[u] = IRBPP_PX(b) - IRBPP_PX(a);
+                dy[u] = IRBPP_PY(b) - IRBPP_PY(a);
+                t[u] = j[u] - ss[u];
+                if (t[u] < 0) t[u] += n[u];
+                int dist = (py[u] - IRBPP_PY(a)) * dx[u] - (px[u] - IRBPP_PX(a)) * dy[u];
+                dist = dist < 0 ? -dist : dist;
+                atomicMax(&slots[sb[u] + ss[u]], ((uint32_t)dist << 8) | (uint32_t)(255 - t[u]));
+            }
         }
         IRBPP_WAVE_SYNC();
-        const int dv = lane < cnt ? (int)slots[lane] : 0;
+        uint32_t best[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) best[u] = active[u] ? slots[sb[u] + ss[u]] : 0u;
         IRBPP_WAVE_SYNC();
-        uint32_t* vr0 = vmask + __builtin_amdgcn_readlane(rot, l0) * 16;
-        cleanup_convex_wave(lane, dv, cnt, vr0);
+        any_active = false;
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            if (active[u]) {
+                const int md = (int)(best[u] >> 8), ts = 255 - (int)(best[u] & 255u);
+                if (md * md <= dx[u] * dx[u] + dy[u] * dy[u]) {
+                    active[u] = false;                   // slice accepted: its interior points are dropped
+                } else {
+                    int sp = ss[u] + ts;
+                    if (sp >= n[u]) sp -= n[u];
+                    if (t[u] == ts) { keep[u] = true; active[u] = false; }
+                    else if (t[u] < ts) se[u] = sp;
+                    else ss[u] = sp;
+                }
+            }
+            any_active |= active[u];
+        }
+    }
+    // 3. the polygon = kept points in contour order: every kept point files its index at its rank among the
+    // kept points of its border (bit counts on the ballots), neighbours are the entries next to it
+    unsigned long long kept[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) kept[u] = __ballot(keep[u]);
+    int m[P], rank[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        m[u] = 0;
+        rank[u] = 0;
+        const int q = u * 64 + lane;
+#pragma unroll
+        for (int w = 0; w < P; ++w) {                    // kept points of my border in word w: all, and those before me
+            int lo = sb[u] - 64 * w, hi = sb[u] + n[u] - 64 * w, me = q - 64 * w;
+            lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
+            hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
+            me = me < lo ? lo : (me > hi ? hi : me);
+            const unsigned long long below_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
+            const unsigned long long below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
+            const unsigned long long below_me = me >= 64 ? ~0ull : ((1ull << me) - 1ull);
+            m[u] += __popcll(kept[w] & below_hi & ~below_lo);
+            rank[u] += __popcll(kept[w] & below_me & ~below_lo);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+        if (keep[u]) slots[sb[u] + rank[u]] = (uint32_t)j[u];
+    IRBPP_WAVE_SYNC();
+    int ja[P], jc[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        ja[u] = jc[u] = 0;
+        if (keep[u]) {
+            ja[u] = (int)slots[sb[u] + (rank[u] == 0 ? m[u] - 1 : rank[u] - 1)];
+            jc[u] = (int)slots[sb[u] + (rank[u] == m[u] - 1 ? 0 : rank[u] + 1)];
+        }
+    }
+    bool redo[P], mark[P];
+    bool any_redo = false;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        redo[u] = mark[u] = false;
+        if (keep[u]) {
+            const int pa = pts[u][ja[u]], pc = pts[u][jc[u]];
+            const int ax = IRBPP_PX(pa), ay = IRBPP_PY(pa), cx = IRBPP_PX(pc), cy = IRBPP_PY(pc);
+            if (m[u] > 2) {                              // removal test of the clean-up pass (start = A, pt = me, end = C)
+                const int ddx = cx - ax, ddy = cy - ay, ux = px[u] - ax, uy = py[u] - ay;
+                int dist = ux * ddy - uy * ddx;
+                dist = dist < 0 ? -dist : dist;
+                const int inner = ux * (cx - px[u]) + uy * (cy - py[u]);
+                redo[u] = 2 * dist * dist <= ddx * ddx + ddy * ddy && ddx != 0 && ddy != 0 && inner >= 0;
+            }
+            mark[u] = m[u] <= 3 || (px[u] - ax) * (cy - ay) - (py[u] - ay) * (cx - ax) < 0;       // find_convex_vetex
+        }
+        any_redo |= redo[u];
+    }
+    // a border with a removable vertex tells all its points through its first slot word ... which holds the
+    // polygon list; use the scratch bytes instead: one flag byte per border at its first position
+    if (__ballot(any_redo) == 0ull) {                    // the common case: no clean-up anywhere in the wave
+#pragma unroll
+        for (int u = 0; u < P; ++u)
+            if (mark[u]) atomicOr(&vmask[rot[u] * 16 + py[u]], 1u << px[u]);
+        return;
+    }
+#pragma unroll
+    for (int u = 0; u < P; ++u) scratch[u * 64 + lane] = 0;
+    IRBPP_WAVE_SYNC();
+#pragma unroll
+    for (int u = 0; u < P; ++u)
+        if (redo[u]) scratch[sb[u]] = 1;
+    IRBPP_WAVE_SYNC();
+    bool flagged[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        flagged[u] = live[u] && scratch[sb[u]] != 0;
+        if (mark[u] && !flagged[u]) atomicOr(&vmask[rot[u] * 16 + py[u]], 1u << px[u]);
+    }
+    IRBPP_WAVE_SYNC();
+    // borders whose polygon the clean-up pass changes (<1 %): one at a time, the polygon in its own order (it
+    // starts at the hop phase's start point) in a lane-indexed register, or serially if it has > 64 vertices
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        unsigned long long pending = __ballot(flagged[u] && j[u] == 0);       // first points of flagged borders in word u
+        while (pending != 0ull) {
+            const int l0 = __ffsll((long long)pending) - 1;
+            pending &= pending - 1ull;
+            const int sb0 = __builtin_amdgcn_readlane(sb[u], l0), cnt = __builtin_amdgcn_readlane(m[u], l0);
+            const int s00 = __builtin_amdgcn_readlane(s0[u], l0), rot0 = __builtin_amdgcn_readlane(rot[u], l0);
+            const unsigned long long ptr_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)pts[u], l0);
+            const unsigned long long ptr_hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)pts[u] >> 32), l0);
+            const uint8_t* pts0 = (const uint8_t*)(ptr_lo | (ptr_hi << 32));
+            // rank of the start point s0 in the polygon list: the list is sorted by index
+            int r0 = 0;
+            for (int i = 0; i < cnt; ++i) r0 += (int)slots[sb0 + i] < s00 ? 1 : 0;
+            if (cnt <= 64) {
+                int k = lane + r0;
+                if (k >= cnt) k -= cnt;
+                const int dv = lane < cnt ? (int)pts0[slots[sb0 + k]] : 0;
+                cleanup_convex_wave(lane, dv, cnt, vmask + rot0 * 16);
+            } else {
+                for (int i = lane; i < cnt; i += 64) {
+                    int k = i + r0;
+                    if (k >= cnt) k -= cnt;
+                    scratch[i] = pts0[slots[sb0 + k]];
+                }
+                IRBPP_WAVE_SYNC();
+                if (lane == 0) cleanup_convex_serial(scratch, cnt, vmask + rot0 * 16);
+                IRBPP_WAVE_SYNC();
+            }
+        }
     }
 }
 

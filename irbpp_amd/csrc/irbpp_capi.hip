@@ -24,6 +24,7 @@ struct irbpp_env {
     Tables T;
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
+    int trace_bpw = irbpp::TRACE_BPW;      // bins per wave of the trace kernel (<= TRACE_BPW, what its LDS staging holds)
     long long* phase_cycles = nullptr;
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
@@ -94,7 +95,7 @@ void layout_lds(Params& P, int want_slots) {
     // slots, the arg-max words of the segmented Douglas-Peucker, and at its end the 256 candidate starts of
     // an image batch) and the candidate keys: the tile's float32 copy is written out before the reuse
     const int32_t slots = align16(P.nslot * P.slot_bytes);
-    const int32_t dps = 4 * 64 * 4;
+    const int32_t dps = 4 * 64 * 4 + 4 * 64;           // arg-max words and scratch bytes of the segmented Douglas-Peucker
     int32_t scratch = slots + dps + 512;
     const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
@@ -173,6 +174,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.obs_len1 = 5 * P.S + 9 + P.Hc;
     P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
     if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
+    P.split = 1;                                            // transition -> trace -> emit kernels
+    if (const char* sp = getenv("IRBPP_SPLIT")) P.split = atoi(sp) != 0;    // 0: the fused single-kernel path (A/B tool)
+    if (const char* bw = getenv("IRBPP_TRACE_BPW")) env->trace_bpw = atoi(bw) > 0 && atoi(bw) <= TRACE_BPW ? atoi(bw) : TRACE_BPW;
     layout_lds(P, cfg->contour_slots);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
@@ -182,6 +186,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
         hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            P.lds_bytes) != hipSuccess ||
+        hipFuncSetAttribute((const void*)irbpp_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess) {
@@ -200,6 +206,13 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(cost, N);
     ALLOC(order, N);
     ALLOC(err, 1);
+    ALLOC(w_posz, N * P.R * P.AC);
+    ALLOC(w_vmask, N * P.R * 16);
+    ALLOC(w_meta, N * WMETA);
+    ALLOC(w_img, N * WIMG * 32);
+    ALLOC(w_imgrot, N * WIMG);
+    ALLOC(w_cand, N * WCAND);
+    ALLOC(w_big, N * 6 * TRACE_BIG);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     *out = env;
@@ -323,6 +336,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                             P.lds_bytes) != hipSuccess ||
         hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
+            hipFuncSetAttribute((const void*)irbpp_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
             hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess)
             return IRBPP_ERR_HIP;
     }
@@ -364,6 +378,17 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int gri
     else
         hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
                            env->P, env->T, env->S, io, mode);
+    // split pipeline: a location observation is finished by the trace kernel (TRACE_BINS bins per workgroup)
+    // and the emit kernel (one workgroup per bin), on the same stream
+    const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
+    if (env->P.split && observes) {
+        const int32_t* map = (mode == MODE_STEP || mode == MODE_CANDS) ? env->S.order : io.bin_list;
+        const int bpw = env->trace_bpw;
+        hipLaunchKernelGGL(irbpp_trace_kernel, dim3((grid + bpw - 1) / bpw), dim3(64), 0, (hipStream_t)stream,
+                           env->P, env->S, map, grid, bpw, env->phase_cycles);
+        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
+                           env->P, env->T, env->S, io, mode);
+    }
     if (pairs) {
         hipEventRecord(env->timing[2 * slot + 1], (hipStream_t)stream);
         env->timing_next = (slot + 1) % pairs;

@@ -18,6 +18,13 @@ namespace irbpp {
 // batch holds CONTOUR_IPT * 16 level images of 16x16 pixels (row words + column words, 16 bit each).
 constexpr int CONTOUR_IPT = 2;
 
+// Split pipeline (Params.split): the transition kernel stops after the overlap test and hands the contour
+// work of a bin to the trace kernel through global memory -- up to WIMG level images (16 row + 16 column
+// words each) and WCAND candidate start pixels per bin; a bin that exceeds either resolves its contours
+// inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
+// several bins per wave, which is what keeps its lanes busy: one bin alone has ~25 borders to follow.
+constexpr int WIMG = 16 * CONTOUR_IPT, WCAND = 256, WMETA = 8;
+
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
     int32_t ax, ay;        // footprint in action cells:    ceil(round(extents,6)/resA)  (space.py:106)
@@ -79,6 +86,14 @@ struct State {
     int32_t* item_cost;    // [n_shapes] running mean of the cycles a transition observing that item took
     int32_t* order;        // [N] launch order of the bins: most expensive first
     int32_t* err;          // [1] device error word
+    // split pipeline: per-bin hand-over between the transition, trace and emit kernels (L2 / Infinity Cache resident)
+    double* w_posz;        // [N][R*AC] posZValid of the observed item
+    uint32_t* w_vmask;     // [N][R*16] vertex bits: isolated pixels from the transition kernel, the rest from the trace kernel
+    int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
+    uint16_t* w_img;       // [N][WIMG][32] level images: 16 row words then 16 column words
+    uint8_t* w_imgrot;     // [N][WIMG] rotation of each level image
+    uint16_t* w_cand;      // [N][WCAND] candidate starts: image | x0<<6 | y0<<10
+    uint8_t* w_big;        // [trace waves][6 * 768] scratch of the sequential redo of a border with more than 64 points
 };
 
 struct Params {
@@ -105,6 +120,7 @@ struct Params {
     // launch prices that phase at full chip load.  1 trace, 2 Douglas-Peucker, 4 overlap loops, 8 emit,
     // 16 whole contour stage.
     int32_t dbg_repeat;
+    int32_t split;         // 1: transition kernel -> trace kernel -> emit kernel; 0: everything in the transition kernel
 };
 
 enum Mode : int32_t {

@@ -228,10 +228,12 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
 // invalid), `valid` given per thread/rotation through L.lev (255 = masked).  On return
 // L.vmask[r*16 + row] has bit col set for every candidate (row, col) of rotation r.
 // ---------------------------------------------------------------------------------------
-__device__ inline void contour_stage(const Params& P, const State& S, const Lds& L, long long* prof) {
-    const int tid = threadIdx.x;
-    const int R = P.R, AC = P.AC;
-    // task list: one task per (rotation, present level)
+constexpr int CONTOUR_IMGS = CONTOUR_IPT * (BLOCK / 16);         // level images per batch
+constexpr int CONTOUR_CLIST = 256;                               // candidate starts listed at a time
+
+// task list: one task (level image) per (rotation, present level), in (rotation, level) order
+__device__ inline int contour_tasks(const Params& P, const Lds& L) {
+    const int tid = threadIdx.x, R = P.R;
     int ntasks = 0;
     for (int r = 0; r < R; ++r) ntasks += __popcll(L.present[r]);
     for (int t = tid; t < R * 64; t += BLOCK) {
@@ -245,91 +247,119 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             L.taskidx[t] = (uint16_t)idx;
         }
     }
+    return ntasks;
+}
+
+// level images of the batch starting at task `base`: 16-bit row words, then the transposed copy
+__device__ inline void contour_images(const Params& P, const Lds& L, int base) {
+    const int tid = threadIdx.x, R = P.R, AC = P.AC;
+    constexpr int IPT = CONTOUR_IPT, IMGS = CONTOUR_IMGS;
     const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
-    constexpr int IPT = CONTOUR_IPT;                 // (image, row) pairs per thread
-    constexpr int IMGS = IPT * (BLOCK / 16);         // level images per batch
+    uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
+    uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
+    for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
+    __syncthreads();
+    // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
+    // lanes of a lane group are the 16 columns of row X, and the ballot of "my cell belongs to
+    // image ti" IS that row of the image.  Only this lane group ever writes word (ti, X).
+    for (int r = 0; r < R; ++r) {
+        const int code = tid < AC ? (int)L.lev[r * AC + tid] : 255;
+        int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
+        if (ti >= IMGS) ti = -1;
+        if (P.Ay != 16) {                    // lane groups are not image rows: plain LDS atomics
+            if (ti >= 0) {
+                const int w = ti * 16 + X;
+                atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
+            }
+            continue;
+        }
+        unsigned long long todo = __ballot(ti >= 0);
+        while (todo) {
+            const int t0 = __builtin_amdgcn_readlane(ti, __ffsll((long long)todo) - 1);
+            const unsigned long long bal = __ballot(ti == t0);
+            todo &= ~bal;
+            if ((tid & 15) == 0) {
+                const uint32_t rowbits = (uint32_t)(bal >> (tid & 48)) & 0xFFFFu;
+                if (rowbits) rows[t0 * 16 + X] = (uint16_t)rowbits;
+            }
+        }
+    }
+    __syncthreads();
+    // transposed copy (column words) for the vertical run jumps: thread (g, y) gathers column y
+    for (int h = 0; h < IPT; ++h) {
+        const int gg = g + h * (BLOCK / 16);
+        uint32_t col = 0u;
+        for (int k = 0; k < 16; ++k) col |= (((uint32_t)rows[gg * 16 + k] >> y) & 1u) << k;
+        cols[gg * 16 + y] = (uint16_t)col;
+    }
+    __syncthreads();
+}
+
+// candidate starts of the batch: one thread per (image, row), pure bit operations; isolated pixels are
+// marked as vertices on the spot.  Returns the number of candidates of the whole batch.
+__device__ inline int contour_candidates(const Params& P, const Lds& L, int base, int ntasks, uint32_t (&my_cand)[CONTOUR_IPT]) {
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, y = tid & 15;
+    const uint16_t* const rows = L.img;
+    int my_count = 0;
+    for (int h = 0; h < CONTOUR_IPT; ++h) {
+        const int gg = g + h * (BLOCK / 16);
+        const bool live = base + gg < ntasks;
+        const uint32_t row_bits = live ? (uint32_t)rows[gg * 16 + y] : 0u;
+        const uint32_t up_bits = (live && y > 0) ? (uint32_t)rows[gg * 16 + y - 1] : 0u;
+        const uint32_t down_bits = (live && y < 15) ? (uint32_t)rows[gg * 16 + y + 1] : 0u;
+        uint32_t cand = start_candidates(row_bits, up_bits);
+        // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
+        // returns the point and find_convex_vetex keeps every vertex of a polygon with <= 3 of
+        // them (cvTools.py:42-43).  Mark it directly; it never needs a trace lane.
+        const uint32_t iso = cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
+        if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
+        cand &= ~iso;
+        my_cand[h] = cand;
+        my_count += __popc(cand);
+    }
+    return block_sum_int(my_count, L.redi);
+}
+
+// the candidates of the batch (nsub == 1) or of its image `sub` into L.clist; returns their number
+__device__ inline int contour_list(const Lds& L, const uint32_t (&my_cand)[CONTOUR_IPT], int nsub, int sub) {
+    const int tid = threadIdx.x;
+    const int g = tid >> 4, y = tid & 15;
+    __syncthreads();
+    if (tid == 0) L.redi[10] = 0;
+    __syncthreads();
+    for (int h = 0; h < CONTOUR_IPT; ++h) {
+        const int gg = g + h * (BLOCK / 16);
+        if (nsub == 1 || gg == sub) {
+            uint32_t cand = my_cand[h];
+            while (cand) {
+                const int x = __ffs((int)cand) - 1;
+                cand &= cand - 1u;
+                L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(gg | (x << 6) | (y << 10));
+            }
+        }
+    }
+    __syncthreads();
+    return L.redi[10];
+}
+
+__device__ inline void contour_stage(const Params& P, const State& S, const Lds& L, long long* prof) {
+    const int tid = threadIdx.x;
+    constexpr int IMGS = CONTOUR_IMGS, CLIST = CONTOUR_CLIST;
+    const int ntasks = contour_tasks(P, L);
     uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
         const long long t_img = prof ? (long long)clock64() : 0;
-        for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
-        __syncthreads();
-        // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
-        // lanes of a lane group are the 16 columns of row X, and the ballot of "my cell belongs to
-        // image ti" IS that row of the image.  Only this lane group ever writes word (ti, X).
-        for (int r = 0; r < R; ++r) {
-            const int code = tid < AC ? (int)L.lev[r * AC + tid] : 255;
-            int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
-            if (ti >= IMGS) ti = -1;
-            if (P.Ay != 16) {                    // lane groups are not image rows: plain LDS atomics
-                if (ti >= 0) {
-                    const int w = ti * 16 + X;
-                    atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
-                }
-                continue;
-            }
-            unsigned long long todo = __ballot(ti >= 0);
-            while (todo) {
-                const int t0 = __builtin_amdgcn_readlane(ti, __ffsll((long long)todo) - 1);
-                const unsigned long long bal = __ballot(ti == t0);
-                todo &= ~bal;
-                if ((tid & 15) == 0) {
-                    const uint32_t rowbits = (uint32_t)(bal >> (tid & 48)) & 0xFFFFu;
-                    if (rowbits) rows[t0 * 16 + X] = (uint16_t)rowbits;
-                }
-            }
-        }
-        __syncthreads();
-        // transposed copy (column words) for the vertical run jumps: thread (g, y) gathers column y
-        for (int h = 0; h < IPT; ++h) {
-            const int gg = g + h * (BLOCK / 16);
-            uint32_t col = 0u;
-            for (int k = 0; k < 16; ++k) col |= (((uint32_t)rows[gg * 16 + k] >> y) & 1u) << k;
-            cols[gg * 16 + y] = (uint16_t)col;
-        }
-        __syncthreads();
-        // (a) candidate starts: one thread per (image, row), pure bit operations.  The list holds
-        // CLIST entries; a batch with more candidates (pathological speckle) is walked one image at
-        // a time (an image has at most 64: every other pixel of every other row).
-        constexpr int CLIST = 256;
-        uint32_t my_cand[IPT];
-        int my_count = 0;
-        for (int h = 0; h < IPT; ++h) {
-            const int gg = g + h * (BLOCK / 16);
-            const bool live = base + gg < ntasks;
-            const uint32_t row_bits = live ? (uint32_t)rows[gg * 16 + y] : 0u;
-            const uint32_t up_bits = (live && y > 0) ? (uint32_t)rows[gg * 16 + y - 1] : 0u;
-            const uint32_t down_bits = (live && y < 15) ? (uint32_t)rows[gg * 16 + y + 1] : 0u;
-            uint32_t cand = start_candidates(row_bits, up_bits);
-            // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
-            // returns the point and find_convex_vetex keeps every vertex of a polygon with <= 3 of
-            // them (cvTools.py:42-43).  Mark it directly; it never needs a trace lane.
-            const uint32_t iso = cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
-            if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
-            cand &= ~iso;
-            my_cand[h] = cand;
-            my_count += __popc(cand);
-        }
-        const int batch_total = block_sum_int(my_count, L.redi);
+        contour_images(P, L, base);
+        // (a) candidate starts.  The list holds CLIST entries; a batch with more candidates (pathological
+        // speckle) is walked one image at a time (an image has at most 64: every other pixel of every other row).
+        uint32_t my_cand[CONTOUR_IPT];
+        const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
-        __syncthreads();
-        if (tid == 0) L.redi[10] = 0;
-        __syncthreads();
-        for (int h = 0; h < IPT; ++h) {
-            const int gg = g + h * (BLOCK / 16);
-            if (nsub == 1 || gg == sub) {
-                uint32_t cand = my_cand[h];
-                while (cand) {
-                    const int x = __ffs((int)cand) - 1;
-                    cand &= cand - 1u;
-                    L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(gg | (x << 6) | (y << 10));
-                }
-            }
-        }
-        __syncthreads();
-        const int total = L.redi[10];
+        const int total = contour_list(L, my_cand, nsub, sub);
         if (prof && tid == 0) prof[5] += (long long)clock64() - t_img;       // images, transposes, candidate list
         // (b) 64 candidates per pass, spread over the four waves: candidate c is traced by lane c / 4 of wave
         // c % 4, and each wave then runs approxPolyDP + convexity on the borders it traced itself, one
@@ -380,7 +410,12 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                 const int jj = lane - sb;
                 const int pv = live ? (int)pts[jj] : 0;
                 const int rr = __shfl(my_r, live ? mine : 0);
-                approx_convex_segmented(lane, live, pv, jj, nn, sb, pts, dps, L.vmask, rr);
+                {
+                    const bool live1[1] = {live};
+                    const int pv1[1] = {pv}, j1[1] = {jj}, n1[1] = {nn}, sb1[1] = {sb}, r1[1] = {rr};
+                    const uint8_t* const p1[1] = {pts};
+                    approx_convex_segmented<1>(lane, live1, pv1, j1, n1, sb1, p1, r1, dps, (uint8_t*)(L.dps + WAVES * 64) + wave * 64, L.vmask);
+                }
             }
             }
             const long long t_dp = prof ? (long long)clock64() : 0;
@@ -648,6 +683,10 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     return block_sum_int(my_valid, L.redi);                  // np.sum(naiveMask) for prejudge
 }
 
+__device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
+                                        int nvalid, float* obs);
+__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int item, int nvalid);
+
 // ---------------------------------------------------------------------------------------
 // Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
 // ---------------------------------------------------------------------------------------
@@ -669,10 +708,25 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     if (io.phase_cycles && tid == 0)
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
+    if (P.split) {                       // the trace and emit kernels take it from here
+        split_handover(P, S, L, b, item, nvalid);
+        return;
+    }
     for (int rep = 0; rep < IRBPP_REPS(4); ++rep)
     contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * PHASE_ROW : nullptr);
     stamp(io, b, 3);
+    emit_observation(P, S, io, L, b, item, nvalid, obs);
+}
 
+// ---------------------------------------------------------------------------------------
+// Candidate rows, selection / padding and the float32 observation (binPhy.py:204-227) from L.vmask and
+// L.posz; also records the candidate keys for the next step's action_to_position.
+// ---------------------------------------------------------------------------------------
+__device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
+                                        int nvalid, float* obs) {
+    const int tid = threadIdx.x;
+    const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
+    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
     uint32_t* okey = keys + R * AC;                 // [S]
@@ -767,6 +821,320 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         S.bs[b].nvalid = nvalid;
     }
     stamp(io, b, 4);
+}
+
+// ---------------------------------------------------------------------------------------
+// Split pipeline, hand-over of one bin from the transition kernel: level images, candidate starts, the
+// vertex bits of isolated pixels, posZValid and the scalars of the observation go to global memory for
+// the trace and emit kernels.  A bin with more level images or candidates than the hand-over holds
+// (speckled height fields) resolves its contours right here instead and hands over nothing to trace.
+// ---------------------------------------------------------------------------------------
+__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int item, int nvalid) {
+    const int tid = threadIdx.x;
+    const KernArgsPtr ka = cold_args();
+    const int ntasks = contour_tasks(P, L);
+    int nimg = 0, ncand = 0;
+    bool here = ntasks > WIMG;
+    if (!here && ntasks > 0) {
+        contour_images(P, L, 0);
+        uint32_t my_cand[CONTOUR_IPT];
+        const int batch_total = contour_candidates(P, L, 0, ntasks, my_cand);
+        if (batch_total > WCAND) here = true;
+        else {
+            nimg = ntasks;
+            ncand = contour_list(L, my_cand, 1, 0);
+        }
+    }
+    if (here) {
+        __syncthreads();
+        contour_stage(P, S, L, nullptr);             // vertex bits of isolated pixels set above are simply set again
+        __syncthreads();
+    }
+    double* gz = ka->S.w_posz + (size_t)b * P.R * P.AC;
+    for (int i = tid; i < P.R * P.AC; i += BLOCK) gz[i] = L.posz[i];
+    uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
+    for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
+    if (nimg > 0) {
+        // rows [IMGS][16] and columns [IMGS][16] in LDS -> [image][16 rows | 16 columns] in global, as dwords
+        uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * WIMG * 32);
+        const uint32_t* lr = (const uint32_t*)L.img;
+        const uint32_t* lc = (const uint32_t*)(L.img + CONTOUR_IMGS * 16);
+        for (int i = tid; i < nimg * 16; i += BLOCK) {
+            const int t = i >> 4, w = i & 15;
+            gi[i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
+        }
+        uint8_t* gr = ka->S.w_imgrot + (size_t)b * WIMG;
+        for (int i = tid; i < nimg; i += BLOCK) gr[i] = (uint8_t)(L.tasklist[i] >> 8);
+        uint16_t* gc = ka->S.w_cand + (size_t)b * WCAND;
+        for (int i = tid; i < ncand; i += BLOCK) gc[i] = L.clist[i];
+    }
+    if (tid == 0) {
+        int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
+        m[0] = nimg;
+        m[1] = ncand;
+        m[2] = nvalid;
+        m[3] = item;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const Lds L = carve_lds(smem, P);
+    const bool some = mode == MODE_RESET && io.bin_list != nullptr;
+    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x]
+                  : some ? io.bin_list[blockIdx.x] : (int)blockIdx.x;
+    const int tid = threadIdx.x;
+    if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
+    float* obs = io.obs + (size_t)(some ? (int)blockIdx.x : b) * io.obs_stride;
+    const double* gz = S.w_posz + (size_t)b * P.R * P.AC;
+    for (int i = tid; i < P.R * P.AC; i += BLOCK) L.posz[i] = gz[i];
+    const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
+    for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
+    const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
+    __syncthreads();
+    stamp(io, b, 3);
+    emit_observation(P, S, io, L, b, item, nvalid, obs);
+}
+
+// ---------------------------------------------------------------------------------------
+// Split pipeline, middle kernel: border following + approxPolyDP + convexity.  One bin has ~25 borders to
+// follow, a handful of them long: traced one lane each inside the bin's own workgroup, a wave spends most
+// of its instructions with a few lanes alive.  Here a workgroup is ONE wave that owns `bpw` consecutive
+// bins and treats their candidate starts as a queue:
+//   * a lane whose border is closed takes the next candidate from the queue (trace_init / trace_step are
+//     resumable), so the lanes stay busy whatever the mix of short and long borders;
+//   * closed borders wait in their lane's slot until 64 contour points are ready, then one round of
+//     approx_convex_segmented (one lane per POINT) serves them all;
+//   * no block barriers, no staging: level images are read where the transition kernel left them (L2), the
+//     vertex bits go straight to the bins' rows in global memory (one atomic OR per vertex).
+// ---------------------------------------------------------------------------------------
+// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
+// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
+// 0 that a shift brings in from outside the row is the identity of both sum and max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
+    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
+    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
+    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
+    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
+    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+    v = imax(v, dpp_shift<0x111, 0xF>(v));
+    v = imax(v, dpp_shift<0x112, 0xF>(v));
+    v = imax(v, dpp_shift<0x114, 0xF>(v));
+    v = imax(v, dpp_shift<0x118, 0xF>(v));
+    v = imax(v, dpp_shift<0x142, 0xA>(v));
+    v = imax(v, dpp_shift<0x143, 0xC>(v));
+    return v;
+}
+
+constexpr int TRACE_P = 2;                                            // contour points per lane and polygon round
+constexpr int TRACE_CAP = 64 * TRACE_P, TRACE_SLOT = TRACE_CAP + 4;   // points per border slot; 33 dwords: odd stride
+constexpr int TRACE_BIG = 768, TRACE_BIGL = 256;                      // point capacities of the sequential redo (global / LDS)
+constexpr int TRACE_BPW = 4;                                         // bins per wave the LDS staging is sized for
+constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
+
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ map, const int count, const int bpw,
+                   long long* prof) {
+    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, KSTEPS = 4, PP = TRACE_P, DP_TRIGGER = 64 * PP - 24, G = TRACE_BPW;
+    __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];            // one border per lane
+    __shared__ __attribute__((aligned(16))) uint16_t simg[G * WIMG * TRACE_ISTRIDE];   // this wave's level images
+    __shared__ uint16_t scand[G * WCAND];                                        // the queue: image (7 bit) | x0<<8 | y0<<12
+    __shared__ uint8_t srot[G * WIMG];
+    __shared__ uint32_t dps[64 * PP];
+    __shared__ uint8_t dpscratch[64 * PP];
+    __shared__ __attribute__((aligned(16))) uint8_t bigslot[6 * TRACE_BIGL];      // sequential redo of a border of more than CAP points
+    const int lane = threadIdx.x;
+    const long long t_start = prof ? (long long)clock64() : 0;
+    long long c_trace = 0, c_dp = 0, n_outer = 0, n_dp = 0;
+    // ---- the wave's bins and everything they handed over, staged in two rounds of loads
+    int bins[G], nts[G], ncs[G];
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        const int qk = (int)blockIdx.x * bpw + k;
+        int b = -1;
+        if (k < bpw && qk < count) {
+            b = map ? map[qk] : qk;
+            if (b < 0 || b >= P.N) b = -1;
+        }
+        bins[k] = b;
+    }
+#pragma unroll
+    for (int k = 0; k < G; ++k) {
+        nts[k] = bins[k] >= 0 ? S.w_meta[(size_t)bins[k] * WMETA] : 0;
+        ncs[k] = bins[k] >= 0 ? S.w_meta[(size_t)bins[k] * WMETA + 1] : 0;
+    }
+    int total = 0;
+    {
+        uint32_t iv[G][8];                       // WIMG images x 16 dwords = 8 dwords per lane and bin
+        uint32_t cv[G][WCAND / 64];
+        uint8_t rv[G];
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            const uint32_t* gi = (const uint32_t*)(S.w_img + (size_t)(bins[k] < 0 ? 0 : bins[k]) * WIMG * 32);
+            const uint16_t* gc = S.w_cand + (size_t)(bins[k] < 0 ? 0 : bins[k]) * WCAND;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) iv[k][u] = lane + 64 * u < nts[k] * 16 ? gi[lane + 64 * u] : 0u;
+#pragma unroll
+            for (int u = 0; u < WCAND / 64; ++u) cv[k][u] = lane + 64 * u < ncs[k] ? gc[lane + 64 * u] : 0u;
+            rv[k] = lane < nts[k] ? S.w_imgrot[(size_t)bins[k] * WIMG + lane] : 0;
+        }
+#pragma unroll
+        for (int k = 0; k < G; ++k) {
+            uint32_t* li = (uint32_t*)simg;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = lane + 64 * u;
+                if (i < nts[k] * 16) li[(k * WIMG + (i >> 4)) * (TRACE_ISTRIDE / 2) + (i & 15)] = iv[k][u];
+            }
+#pragma unroll
+            for (int u = 0; u < WCAND / 64; ++u) {
+                const int i = lane + 64 * u;
+                if (i < ncs[k]) {
+                    const uint32_t e = cv[k][u];
+                    scand[total + i] = (uint16_t)((k * WIMG + (e & 63u)) | (((e >> 6) & 15u) << 8) | (((e >> 10) & 15u) << 12));
+                }
+            }
+            if (lane < nts[k]) srot[k * WIMG + lane] = rv[k];
+            total += ncs[k];
+        }
+    }
+    if (total == 0) return;
+    const long long t_staged = prof ? (long long)clock64() : 0;
+    IRBPP_WAVE_SYNC();
+    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the staging stores have landed before any lane reads them
+    int qi = 0;                                  // queue head
+    TraceState t = {};
+    bool active = false;
+    int wn = 0;                                  // points of the closed border waiting in my slot
+    int rk = 0, steps = 0;
+    const uint16_t* im = simg;
+    uint8_t* const my_slot = slots + lane * SLOT;
+    for (;;) {
+        // ---- idle lanes take the next candidates
+        {
+            const unsigned long long idle = __ballot(!active && wn == 0);
+            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
+            if (((idle >> lane) & 1ull) != 0ull && qi + rank < total) {
+                const uint32_t e = scand[qi + rank];
+                const int gimg = (int)(e & 127u);
+                im = simg + gimg * TRACE_ISTRIDE;
+                int b = bins[0];
+#pragma unroll
+                for (int k = 1; k < G; ++k) b = (gimg >> 5) == k ? bins[k] : b;
+                rk = b * P.R + (int)srot[gimg];
+                steps = 0;
+                const int r = trace_init(t, im, (e >> 8) & 15u, (e >> 12) & 15u, my_slot, CAP);
+                if (r == TRACE_RUNNING) active = true;
+                else wn = r;
+            }
+            const int nidle = __popcll(idle);
+            qi = qi + nidle < total ? qi + nidle : total;
+        }
+        if (__ballot(active || wn > 0) == 0ull) break;           // queue drained, nothing in flight
+        const long long t_a = prof ? (long long)clock64() : 0;
+        ++n_outer;
+        // ---- a few steps of every open border
+        for (int k = 0; k < KSTEPS; ++k) {
+            if (active) {
+                const int r = trace_step(t, im, im + 16, my_slot, CAP);
+                if (++steps > 4096) { atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD); active = false; }
+                else if (r != TRACE_RUNNING) {
+                    active = false;
+                    wn = r;                                       // 0: not the first pixel of its component
+                }
+            }
+        }
+        // ---- a border of more than 64 points (speckle): redone sequentially in this wave's global scratch
+        {
+            unsigned long long big = __ballot(wn > CAP);
+            while (big != 0ull) {
+                const int l0 = __ffsll((long long)big) - 1;
+                big &= big - 1ull;
+                if (lane == l0) {
+                    // in LDS up to TRACE_BIGL points; beyond that (never seen) in this wave's global scratch
+                    int rc;
+                    if (wn <= TRACE_BIGL) {
+                        SlotMem m;
+                        m.pts = bigslot; m.dst = bigslot + TRACE_BIGL; m.stk = (uint32_t*)(bigslot + 2 * TRACE_BIGL);
+                        m.cap = TRACE_BIGL; m.cap_stk = TRACE_BIGL;
+                        rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
+                    } else {
+                        uint8_t* g = S.w_big + (size_t)blockIdx.x * (6 * TRACE_BIG);
+                        SlotMem m;
+                        m.pts = g; m.dst = g + TRACE_BIG; m.stk = (uint32_t*)(g + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
+                        rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
+                    }
+                    if (rc != 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                    wn = 0;
+                }
+            }
+        }
+        const long long t_b = prof ? (long long)clock64() : 0;
+        c_trace += t_b - t_a;
+        // ---- polygon approximation: when a wave-full of points waits, or when nobody is tracing any more
+        for (;;) {
+            const int incl = wave_inclusive_sum(wn), excl = incl - wn;
+            const int waiting = __builtin_amdgcn_readlane(incl, 63);
+            if (waiting == 0 || (waiting < DP_TRIGGER && __ballot(active) != 0ull)) break;
+            const unsigned long long todo = __ballot(wn > 0);
+            const int first = __ffsll((long long)todo) - 1;
+            const int base = __builtin_amdgcn_readlane(excl, first);
+            const unsigned long long sel = __ballot(wn > 0 && incl - base <= 64 * PP);
+            // which border does the point at position q = u * 64 + lane belong to: border lanes drop their id at
+            // the position of their first point, a running maximum over the positions spreads it
+#pragma unroll
+            for (int u = 0; u < PP; ++u) dps[u * 64 + lane] = 0u;
+            IRBPP_WAVE_SYNC();
+            if ((sel >> lane) & 1ull) dps[excl - base] = (uint32_t)lane + 1u;
+            IRBPP_WAVE_SYNC();
+            int mark[PP];
+#pragma unroll
+            for (int u = 0; u < PP; ++u) mark[u] = (int)dps[u * 64 + lane];
+            IRBPP_WAVE_SYNC();
+            bool live[PP];
+            int pv[PP], jj[PP], nn[PP], sbq[PP], prk[PP];
+            const uint8_t* pts[PP];
+            int carry = 0;
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const int run = imax(wave_inclusive_max(mark[u]), carry);
+                carry = __builtin_amdgcn_readlane(run, 63);
+                const int owner = run - 1;                                    // lane that traced this position's border
+                const int on = owner >= 0 ? owner : 0;
+                nn[u] = __shfl(wn, on);
+                sbq[u] = __shfl(excl, on) - base;
+                prk[u] = __shfl(rk, on);
+                live[u] = owner >= 0 && u * 64 + lane < sbq[u] + nn[u];
+                pts[u] = slots + on * SLOT;
+                jj[u] = u * 64 + lane - sbq[u];
+                if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
+                pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
+            }
+            approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+            if ((sel >> lane) & 1ull) wn = 0;
+            ++n_dp;
+        }
+        if (prof) c_dp += (long long)clock64() - t_b;
+    }
+    if (prof && lane == 0) {                     // tooling: this wave's account, in the row of its first bin
+        long long* row = prof + (size_t)bins[0] * PHASE_ROW;
+        row[11] = (long long)clock64() - t_start;
+        row[12] = t_staged - t_start;
+        row[13] = c_trace;
+        row[14] = c_dp;
+        row[15] = n_outer | (n_dp << 20) | ((long long)total << 40);
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -24,6 +24,8 @@ static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v
 static inline int __ffsll(long long v) { return __builtin_ffsll(v); }
 static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned long long)v) : 64; }
 
+static long g_trace_iters = 0;
+#define IRBPP_TRACE_ITER() (++g_trace_iters)
 #include "../../irbpp_amd/csrc/contours_device.h"
 
 using namespace irbpp;
@@ -42,6 +44,9 @@ extern "C" {
 void host_start_candidates(const uint16_t* rows, uint32_t* out) {
     for (int y = 0; y < 16; ++y) out[y] = start_candidates(rows[y], y ? rows[y - 1] : 0u);
 }
+
+// tooling: iterations of the border walk since the last call
+long host_trace_iters(void) { const long v = g_trace_iters; g_trace_iters = 0; return v; }
 
 // Returns trace_border's value; pts receives min(n, cap) points as x | y<<4.
 int host_trace_border(const uint16_t* rows, int x0, int y0, uint8_t* pts, int cap) {

@@ -69,29 +69,47 @@ static inline int __clzll(long long v) { return v ? __builtin_clzll((unsigned lo
 
 #include "../../irbpp_amd/csrc/contours_device.h"
 
-// Several borders packed back to back over the 64 lanes, exactly as the contour stage of the kernel packs
-// them: counts[b] points each (sum <= 64), pts = the borders' point lists one after the other.
-// vrows[b*16 .. b*16+15] receives the vertex bits of border b (border b plays 'rotation' b).
-extern "C" int host_approx_convex_segmented(const uint8_t* pts, const int* counts, int n_borders, uint32_t* vrows, int* redo) {
+// Several borders packed back to back over the 64 * P positions of a wave (position q = u * 64 + lane),
+// exactly as the kernels pack them: counts[b] points each (sum <= 64 * P), pts = the borders' point lists one
+// after the other.  vrows[b*16 .. b*16+15] receives the vertex bits of border b (border b plays 'rotation' b).
+template <int P>
+static int run_segmented(const uint8_t* pts, const int* counts, int n_borders, uint32_t* vrows) {
     memset(vrows, 0, (size_t)n_borders * 16 * sizeof(uint32_t));
-    memset(redo, 0, (size_t)n_borders * sizeof(int));
     pthread_barrier_init(&g_bar, nullptr, 64);
-    static uint32_t slots[64];
+    static uint32_t slots[64 * 4];
+    static uint8_t scratch[64 * 4];
     std::vector<std::thread> lanes;
     for (int l = 0; l < 64; ++l)
         lanes.emplace_back([&, l] {
             threadIdx.x = (unsigned)l;
-            int off = 0, mine = -1, sb = 0, nn = 1;
-            for (int b = 0; b < n_borders; ++b) {
-                if (l >= off && l < off + counts[b]) { mine = b; sb = off; nn = counts[b]; }
-                off += counts[b];
+            bool live[P];
+            int pv[P], j[P], n[P], sb[P], rot[P];
+            const uint8_t* pp[P];
+            for (int u = 0; u < P; ++u) {
+                const int q = u * 64 + l;
+                int off = 0, mine = -1, sbb = 0, nn = 1;
+                for (int b = 0; b < n_borders; ++b) {
+                    if (q >= off && q < off + counts[b]) { mine = b; sbb = off; nn = counts[b]; }
+                    off += counts[b];
+                }
+                live[u] = mine >= 0;
+                pp[u] = pts + sbb;
+                j[u] = live[u] ? q - sbb : 0;
+                n[u] = nn;
+                sb[u] = live[u] ? sbb : 0;
+                rot[u] = live[u] ? mine : 0;
+                pv[u] = live[u] ? pp[u][j[u]] : 0;
             }
-            const bool live = mine >= 0;
-            const uint8_t* my_pts = pts + sb;
-            const int j = l - sb;
-            irbpp::approx_convex_segmented(l, live, live ? my_pts[j] : 0, j, nn, sb, my_pts, slots, vrows, live ? mine : 0);
+            irbpp::approx_convex_segmented<P>(l, live, pv, j, n, sb, pp, rot, slots, scratch, vrows);
         });
     for (auto& t : lanes) t.join();
     pthread_barrier_destroy(&g_bar);
     return 0;
+}
+
+extern "C" int host_approx_convex_segmented(const uint8_t* pts, const int* counts, int n_borders, uint32_t* vrows, int points_per_lane) {
+    if (points_per_lane == 1) return run_segmented<1>(pts, counts, n_borders, vrows);
+    if (points_per_lane == 2) return run_segmented<2>(pts, counts, n_borders, vrows);
+    if (points_per_lane == 4) return run_segmented<4>(pts, counts, n_borders, vrows);
+    return -1;
 }

@@ -34,7 +34,7 @@ def wave():
     subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-pthread", "-Wno-unused-value",
                     "-I", os.path.join(HERE, "host", "stub"), WAVE_SRC, "-o", WAVE_OUT], check=True)
     lib = C.CDLL(WAVE_OUT)
-    lib.host_approx_convex_segmented.argtypes = [u8p, C.POINTER(C.c_int), C.c_int, u32p, C.POINTER(C.c_int)]
+    lib.host_approx_convex_segmented.argtypes = [u8p, C.POINTER(C.c_int), C.c_int, u32p, C.c_int]
     lib.host_approx_convex_segmented.restype = C.c_int
     return lib
 
@@ -202,52 +202,61 @@ def _cleanup_changes(poly):
     return before != after
 
 
-def test_segmented_douglas_peucker_in_lockstep_emulation(wave):
-    """approx_convex_segmented: approxPolyDP + convexity for several borders at once, one contour point per
-    lane, as the kernel runs it.  Borders are packed back to back (<= 64 points per call) exactly like the
-    contour stage packs them, including borders whose polygon the sequential clean-up pass of approxPolyDP
-    changes (handled wave-uniformly inside the routine)."""
+@pytest.mark.parametrize("ppl", [1, 2])
+def test_segmented_douglas_peucker_in_lockstep_emulation(wave, ppl):
+    """approx_convex_segmented<P>: approxPolyDP + convexity for several borders at once, P contour points per
+    lane (64 * P per wave and round), as the kernels run it.  Borders are packed back to back exactly like the
+    kernels pack them, including borders whose polygon the sequential clean-up pass of approxPolyDP changes
+    (handled wave-uniformly inside the routine) and, for P = 2, borders of more than 64 points."""
+    room0 = 64 * ppl
+
     def run(polys):
         counts = (C.c_int * len(polys))(*[len(q) for q in polys])
         flat = [x | (y << 4) for q in polys for x, y in q]
         arr = (C.c_uint8 * max(1, len(flat)))(*flat)
         vrows = (C.c_uint32 * (16 * len(polys)))()
-        redo = (C.c_int * len(polys))()
-        assert wave.host_approx_convex_segmented(arr, counts, len(polys), vrows, redo) == 0
+        assert wave.host_approx_convex_segmented(arr, counts, len(polys), vrows, ppl) == 0
         for b, q in enumerate(polys):
             got = {(x, y) for y in range(16) for x in range(16) if (vrows[b * 16 + y] >> x) & 1}
             assert got == _oracle_vertices(q), q
         return sum(1 for q in polys if _cleanup_changes(q))
 
+    def walk(rng, n):
+        x, y = rng.randint(0, 16), rng.randint(0, 16)
+        poly = [(x, y)]
+        while len(poly) < n:
+            x = int(np.clip(x + rng.randint(-1, 2), 0, 15))
+            y = int(np.clip(y + rng.randint(-1, 2), 0, 15))
+            if (x, y) != poly[-1]:
+                poly.append((x, y))
+        return poly
+
     done = flagged = 0
-    batch, room = [], 64
+    batch, room = [], room0
     for img in _images(300, 70):
         outer, _, _ = _oracle_outer(img)
         for c in outer:
-            if not 1 <= len(c) <= 64:
+            if not 1 <= len(c) <= room0:
                 continue
             if len(c) > room:
                 flagged += run(batch)
                 done += len(batch)
-                batch, room = [], 64
+                batch, room = [], room0
             batch.append(c)
             room -= len(c)
     flagged += run(batch)
     done += len(batch)
     rng = np.random.RandomState(11)
-    for _ in range(60):                                               # arbitrary closed walks, packed three to a wave
-        polys = []
-        for n in (rng.randint(1, 30), rng.randint(1, 20), rng.randint(1, 15)):
-            x, y = rng.randint(0, 16), rng.randint(0, 16)
-            poly = [(x, y)]
-            while len(poly) < n:
-                x = int(np.clip(x + rng.randint(-1, 2), 0, 15))
-                y = int(np.clip(y + rng.randint(-1, 2), 0, 15))
-                if (x, y) != poly[-1]:
-                    poly.append((x, y))
-            polys.append(poly)
+    for _ in range(60 // ppl):                                        # arbitrary closed walks, packed three to a wave
+        polys = [walk(rng, rng.randint(1, 30 * ppl)), walk(rng, rng.randint(1, 20 * ppl)), walk(rng, rng.randint(1, 15))]
         flagged += run(polys)
         done += 3
-    full = [(i % 16, (i // 16) * 2 + (i % 2)) for i in range(64)]     # one border filling all 64 lanes
+    full = [(i % 16, (i // 16) * 2 + (i % 2)) for i in range(64)]     # one border filling 64 lanes
     flagged += run([full])
+    if ppl == 2:                                                      # borders of more than 64 points, alone and straddling the words
+        for seed in range(12):
+            r2 = np.random.RandomState(100 + seed)
+            flagged += run([walk(r2, r2.randint(65, 129))])
+            flagged += run([walk(r2, r2.randint(20, 50)), walk(r2, r2.randint(40, 78))])
+            done += 3
     assert done > 300 and flagged >= 3                                # the clean-up branch was exercised
