@@ -54,7 +54,7 @@ typedef struct {
     int32_t global_offset;   /* global index of this device's bin 0 (multi-GPU sharding)         */
     int32_t global_bins;     /* bins over all ranks = trajectory stride between episodes         */
     int32_t device;          /* HIP device ordinal                                               */
-    int32_t contour_slots;   /* 0 = default; contour tasks traced concurrently per bin           */
+    int32_t reserved;        /* 0 (was a tuning knob of an earlier kernel; kept so the struct layout is stable) */
 } irbpp_config;
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
@@ -67,6 +67,8 @@ typedef struct {
     double*  ratio_dev;       /* info['ratio']   = get_ratio(),  valid where done                */
     double*  ep_reward_dev;   /* sum of the episode's rewards (Monitor 'r' before round(.,6))    */
     int32_t* ep_len_dev;      /* Monitor 'l'                                                     */
+    int32_t* err_dev;         /* copy of the device error word after this step (one int32, not per bin):
+                                 callers that fetch the outputs with one D2H copy get it for free   */
 } irbpp_step_out;
 
 const char* irbpp_status_string(int status);

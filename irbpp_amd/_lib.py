@@ -17,13 +17,14 @@ class IrbppConfig(C.Structure):
         ("resolution_a", C.c_double), ("resolution_h", C.c_double), ("resolution_z", C.c_double),
         ("bin", C.c_double * 3), ("scale_z", C.c_double),
         ("traj_start", C.c_int32), ("global_offset", C.c_int32), ("global_bins", C.c_int32),
-        ("device", C.c_int32), ("contour_slots", C.c_int32),
+        ("device", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
 class IrbppStepOut(C.Structure):
     _fields_ = [("reward_dev", C.c_void_p), ("done_dev", C.c_void_p), ("counter_dev", C.c_void_p),
-                ("ratio_dev", C.c_void_p), ("ep_reward_dev", C.c_void_p), ("ep_len_dev", C.c_void_p)]
+                ("ratio_dev", C.c_void_p), ("ep_reward_dev", C.c_void_p), ("ep_len_dev", C.c_void_p),
+                ("err_dev", C.c_void_p)]
 
 
 # every entry point include/irbpp.h declares: name -> (restype, argtypes)

@@ -24,7 +24,7 @@ struct irbpp_env {
     Tables T;
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
-    int trace_bpw = irbpp::TRACE_BPW;      // bins per wave of the trace kernel (<= TRACE_BPW, what its LDS staging holds)
+    int trace_bpw = 2;                     // bins per wave of the trace kernel: 1, 2 or 4
     long long* phase_cycles = nullptr;
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
@@ -65,14 +65,13 @@ inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
 
 // dynamic-LDS carve-up of the transition kernel (and the division constants of its grid sizes)
-void layout_lds(Params& P, int want_slots) {
+void layout_lds(Params& P) {
     P.mg_hy = div_magic(P.Hy);
     P.mg_step = div_magic(P.step);
     P.mg_ay = div_magic(P.Ay);
     P.mg_ax = div_magic(P.Ax);
     P.mg_ac = div_magic(P.AC);
     P.mg_mbw = div_magic(P.mb_w);
-    (void)want_slots;
     P.nslot = 64;                                                     // candidate starts traced per pass (16 per wave)
     P.slot_cap = 64;                                                  // points of a border: one lane each in the segmented Douglas-Peucker
     P.slot_bytes = P.slot_cap + 4;                                    // 68 B = 17 dwords: odd stride, lanes hit distinct LDS banks
@@ -176,8 +175,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
     P.split = 1;                                            // transition -> trace -> emit kernels
     if (const char* sp = getenv("IRBPP_SPLIT")) P.split = atoi(sp) != 0;    // 0: the fused single-kernel path (A/B tool)
-    if (const char* bw = getenv("IRBPP_TRACE_BPW")) env->trace_bpw = atoi(bw) > 0 && atoi(bw) <= TRACE_BPW ? atoi(bw) : TRACE_BPW;
-    layout_lds(P, cfg->contour_slots);                      // redone by irbpp_load_shapes if the block path applies
+    if (const char* bw = getenv("IRBPP_TRACE_BPW")) { const int v = atoi(bw); env->trace_bpw = v == 1 || v == 2 || v == 4 ? v : 2; }
+    layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
@@ -330,7 +329,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         env->P.block_b = block_b;
         env->P.mb_h = mb_h;
         env->P.mb_w = mb_w;
-        layout_lds(env->P, env->cfg.contour_slots);
+        layout_lds(env->P);
         if (env->P.lds_bytes > 160 * 1024) return IRBPP_ERR_ARG;
         if (hipFuncSetAttribute((const void*)irbpp_env_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
                             P.lds_bytes) != hipSuccess ||
@@ -364,33 +363,44 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 // six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
 static bool use_wide_kernel(const Params& P) { return 6 * P.lds_bytes > 150 * 1024; }
 
-static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int grid = 0) {
-    if (grid <= 0) grid = env->P.N;
-    io.phase_cycles = env->phase_cycles;
+// One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the
+// transition kernel and, in the split pipeline, trace and emit -- on one stream.
+static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
+    io.block_off = first;
     if (mode == MODE_STEP || mode == MODE_CANDS)      // most expensive bins first (see irbpp_env_kernel)
-        hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, env->S.cost, env->S.order,
-                           env->P.N);
-    const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
-    if (pairs) hipEventRecord(env->timing[2 * slot], (hipStream_t)stream);
+        hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, st, env->S.cost, env->S.order, first, n);
     if (!use_wide_kernel(env->P))
-        hipLaunchKernelGGL(irbpp_env_kernel, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
-                           env->P, env->T, env->S, io, mode);
+        hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     else
-        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
-                           env->P, env->T, env->S, io, mode);
-    // split pipeline: a location observation is finished by the trace kernel (TRACE_BINS bins per workgroup)
-    // and the emit kernel (one workgroup per bin), on the same stream
+        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
+    // split pipeline: a location observation is finished by the trace kernel (one wave per `bpw` bins) and the
+    // emit kernel (one workgroup per bin), on the same stream
     const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
     if (env->P.split && observes) {
         const int32_t* map = (mode == MODE_STEP || mode == MODE_CANDS) ? env->S.order : io.bin_list;
         const int bpw = env->trace_bpw;
-        hipLaunchKernelGGL(irbpp_trace_kernel, dim3((grid + bpw - 1) / bpw), dim3(64), 0, (hipStream_t)stream,
-                           env->P, env->S, map, grid, bpw, env->phase_cycles);
-        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(grid), dim3(256), env->P.lds_bytes, (hipStream_t)stream,
-                           env->P, env->T, env->S, io, mode);
+        const dim3 tg((n + bpw - 1) / bpw);
+        if (bpw == 1) hipLaunchKernelGGL(irbpp_trace_kernel_1, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
+        else if (bpw == 2) hipLaunchKernelGGL(irbpp_trace_kernel_2, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
+        else hipLaunchKernelGGL(irbpp_trace_kernel_4, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
+        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
+}
+
+// A transition of `grid` launch slots (all bins, or the listed ones) on the caller's stream.  (Cutting it into
+// groups on library-owned streams, forked from and joined to the caller's stream with events, was measured and
+// dropped: the eight cross-queue dependencies per step cost more than the overlapped launch tails give back,
+// 18.5 -> 11.8 M steps/s.  Overlap across sub-batches is offered one level up instead, where no join is needed:
+// vec_env.GroupedPackingEnv steps independent groups of bins on their own streams.)
+static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int grid = 0) {
+    if (grid <= 0) grid = env->P.N;
+    io.phase_cycles = env->phase_cycles;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
+    if (pairs) hipEventRecord(env->timing[2 * slot], st);
+    launch_group(env, io, mode, st, 0, grid);
     if (pairs) {
-        hipEventRecord(env->timing[2 * slot + 1], (hipStream_t)stream);
+        hipEventRecord(env->timing[2 * slot + 1], st);
         env->timing_next = (slot + 1) % pairs;
         if (env->timing_used < pairs) env->timing_used++;
     }
@@ -437,7 +447,10 @@ int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const
         io.ep_reward = out->ep_reward_dev;
         io.ep_len = out->ep_len_dev;
     }
-    return launch_env(env, io, MODE_STEP, stream);
+    const int rc = launch_env(env, io, MODE_STEP, stream);
+    if (rc == IRBPP_OK && out && out->err_dev)
+        HIP_TRY(hipMemcpyAsync(out->err_dev, env->S.err, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return rc;
 }
 
 int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev, float* loc_obs_dev, void* stream) {

@@ -147,6 +147,7 @@ struct StepIO {
     int32_t heur_method;        // 1 MINZ, 2 DBLF, 3 FIRSTFIT, 4 HM (space.py:168-218)
     int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
     const int32_t* bin_list;    // MODE_RESET on a subset (reset_specific): workgroup i resets bin bin_list[i]
+    int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
 };
 
 }  // namespace irbpp

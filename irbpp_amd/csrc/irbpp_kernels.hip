@@ -885,11 +885,11 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const Lds L = carve_lds(smem, P);
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;
-    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x]
-                  : some ? io.bin_list[blockIdx.x] : (int)blockIdx.x;
+    const int slot = (int)blockIdx.x + io.block_off;
+    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
-    float* obs = io.obs + (size_t)(some ? (int)blockIdx.x : b) * io.obs_stride;
+    float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
     const double* gz = S.w_posz + (size_t)b * P.R * P.AC;
     for (int i = tid; i < P.R * P.AC; i += BLOCK) L.posz[i] = gz[i];
     const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
@@ -939,21 +939,20 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
 
 constexpr int TRACE_P = 2;                                            // contour points per lane and polygon round
 constexpr int TRACE_CAP = 64 * TRACE_P, TRACE_SLOT = TRACE_CAP + 4;   // points per border slot; 33 dwords: odd stride
-constexpr int TRACE_BIG = 768, TRACE_BIGL = 256;                      // point capacities of the sequential redo (global / LDS)
+constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
 constexpr int TRACE_BPW = 4;                                         // bins per wave the LDS staging is sized for
 constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
 
-extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ map, const int count, const int bpw,
-                   long long* prof) {
-    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, KSTEPS = 4, PP = TRACE_P, DP_TRIGGER = 64 * PP - 24, G = TRACE_BPW;
+template <int G>                                 // bins per wave: sizes the LDS staging (images, queue)
+__device__ __forceinline__ void trace_wave(const Params& P, const State& S, const int32_t* __restrict__ map, const int first,
+                                           const int count, long long* prof) {
+    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, KSTEPS = 4, PP = TRACE_P, DP_TRIGGER = 64 * PP - 24, bpw = G;
     __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];            // one border per lane
     __shared__ __attribute__((aligned(16))) uint16_t simg[G * WIMG * TRACE_ISTRIDE];   // this wave's level images
     __shared__ uint16_t scand[G * WCAND];                                        // the queue: image (7 bit) | x0<<8 | y0<<12
     __shared__ uint8_t srot[G * WIMG];
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
-    __shared__ __attribute__((aligned(16))) uint8_t bigslot[6 * TRACE_BIGL];      // sequential redo of a border of more than CAP points
     const int lane = threadIdx.x;
     const long long t_start = prof ? (long long)clock64() : 0;
     long long c_trace = 0, c_dp = 0, n_outer = 0, n_dp = 0;
@@ -961,9 +960,9 @@ irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ ma
     int bins[G], nts[G], ncs[G];
 #pragma unroll
     for (int k = 0; k < G; ++k) {
-        const int qk = (int)blockIdx.x * bpw + k;
+        const int qk = first + (int)blockIdx.x * bpw + k;
         int b = -1;
-        if (k < bpw && qk < count) {
+        if (k < bpw && qk < first + count) {
             b = map ? map[qk] : qk;
             if (b < 0 || b >= P.N) b = -1;
         }
@@ -1062,19 +1061,11 @@ irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ ma
                 const int l0 = __ffsll((long long)big) - 1;
                 big &= big - 1ull;
                 if (lane == l0) {
-                    // in LDS up to TRACE_BIGL points; beyond that (never seen) in this wave's global scratch
-                    int rc;
-                    if (wn <= TRACE_BIGL) {
-                        SlotMem m;
-                        m.pts = bigslot; m.dst = bigslot + TRACE_BIGL; m.stk = (uint32_t*)(bigslot + 2 * TRACE_BIGL);
-                        m.cap = TRACE_BIGL; m.cap_stk = TRACE_BIGL;
-                        rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
-                    } else {
-                        uint8_t* g = S.w_big + (size_t)blockIdx.x * (6 * TRACE_BIG);
-                        SlotMem m;
-                        m.pts = g; m.dst = g + TRACE_BIG; m.stk = (uint32_t*)(g + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
-                        rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
-                    }
+                    // more than 128 points: not seen in any workload; sequential, in this wave's global scratch
+                    uint8_t* g = S.w_big + ((size_t)first / bpw + blockIdx.x) * (6 * TRACE_BIG);
+                    SlotMem m;
+                    m.pts = g; m.dst = g + TRACE_BIG; m.stk = (uint32_t*)(g + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
+                    const int rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
                     if (rc != 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                     wn = 0;
                 }
@@ -1137,6 +1128,19 @@ irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ ma
     }
 }
 
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_trace_kernel_1(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
+    trace_wave<1>(P, S, map, first, count, prof);
+}
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_trace_kernel_2(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
+    trace_wave<2>(P, S, map, first, count, prof);
+}
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_trace_kernel_4(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
+    trace_wave<4>(P, S, map, first, count, prof);
+}
+
 // ---------------------------------------------------------------------------------------
 // The environment transition kernel: one workgroup per bin.
 // ---------------------------------------------------------------------------------------
@@ -1166,8 +1170,8 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     // cycle counts of the previous transition): with ~2.7 bins per resident workgroup slot the
     // stragglers would otherwise decide the kernel's duration.
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;          // reset_specific
-    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[blockIdx.x]
-                  : some ? io.bin_list[blockIdx.x] : (int)blockIdx.x;
+    const int slot = (int)blockIdx.x + io.block_off;
+    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
         if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
@@ -1176,7 +1180,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     const long long t_begin = (long long)clock64();
     double* ghm = S.hm + (size_t)b * P.Hc;
     int32_t* q = S.queue + (size_t)b * P.K;
-    float* obs = io.obs ? io.obs + (size_t)(some ? (int)blockIdx.x : b) * io.obs_stride : nullptr;
+    float* obs = io.obs ? io.obs + (size_t)(some ? slot : b) * io.obs_stride : nullptr;
 
     stamp(io, b, 0);
     // stage the heightmap tile
@@ -1360,7 +1364,9 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
 // Counting sort of the bins by descending cost (256 buckets between the smallest and the largest
 // hint) -> S.order.  One workgroup; runs before every transition launch (a few microseconds).
 extern "C" __global__ void __launch_bounds__(1024)
-irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
+irbpp_order_kernel(const int32_t* cost_all, int32_t* order_all, int base, int N) {
+    const int32_t* cost = cost_all + base;           // grouped stepping: bins base .. base + N - 1 are one launch group
+    int32_t* order = order_all + base;
     __shared__ int hist[256];
     __shared__ int start[256];
     __shared__ int lo_hi[2];
@@ -1377,8 +1383,12 @@ irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
     if ((tid & 63) == 0) { atomicMin(&lo_hi[0], lo); atomicMax(&lo_hi[1], hi); }
     __syncthreads();
     lo = lo_hi[0];
-    const float scale = 255.0f / (float)(lo_hi[1] - lo + 1);
-    for (int b = tid; b < N; b += 1024) atomicAdd(&hist[255 - (int)((float)(cost[b] - lo) * scale)], 1);   // bucket 0 = most expensive
+    const float scale = 255.0f / ((float)lo_hi[1] - (float)lo + 1.0f);       // in float: hi - lo + 1 may not fit an int
+    auto bucket = [&](int c) {                       // bucket 0 = most expensive
+        const int k = 255 - (int)(((float)c - (float)lo) * scale);
+        return k < 0 ? 0 : (k > 255 ? 255 : k);
+    };
+    for (int b = tid; b < N; b += 1024) atomicAdd(&hist[bucket(cost[b])], 1);
     __syncthreads();
     if (tid < 64) {                                  // exclusive scan of the 256 counts by one wave
         int v[4], sum = 0;
@@ -1389,7 +1399,7 @@ irbpp_order_kernel(const int32_t* cost, int32_t* order, int N) {
         for (int i = 0; i < 4; ++i) { start[tid * 4 + i] = acc; acc += v[i]; }
     }
     __syncthreads();
-    for (int b = tid; b < N; b += 1024) order[atomicAdd(&start[255 - (int)((float)(cost[b] - lo) * scale)], 1)] = b;
+    for (int b = tid; b < N; b += 1024) order[atomicAdd(&start[bucket(cost[b])], 1)] = base + b;
 }
 
 // Space.get_heuristic_action (space.py:162-218) for the item of the last observation: its own

@@ -51,7 +51,7 @@ class GpuPackingEnv(object):
                  resolutionA: float = 0.02, resolutionH: float = 0.01, resolutionZ: float = 0.01,
                  bin_dimension=BIN_DIMENSION, selectedAction: int = 500, bufferSize: int = 1,
                  scale_z: float = 100.0, traj_start: int = 1, global_offset: int = 0,
-                 global_bins: Optional[int] = None, device="cuda:0", contour_slots: int = 0):
+                 global_bins: Optional[int] = None, device="cuda:0"):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("GpuPackingEnv needs a HIP device; irbpp_amd has no CPU fallback")
@@ -70,7 +70,7 @@ class GpuPackingEnv(object):
             resolution_a=resolutionA, resolution_h=resolutionH, resolution_z=resolutionZ,
             bin=(C.c_double * 3)(*bin_r), scale_z=scale_z, traj_start=traj_start,
             global_offset=global_offset, global_bins=self.num_bins if global_bins is None else global_bins,
-            device=dev_index, contour_slots=contour_slots)
+            device=dev_index, reserved=0)
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _lib.check(self.lib.irbpp_create(C.byref(cfg), C.byref(self._h)), "irbpp_create")
@@ -85,15 +85,19 @@ class GpuPackingEnv(object):
         assert seq.ndim == 2
         _lib.check(self.lib.irbpp_load_sequences(self._h, seq.ctypes.data_as(_lib.c_i32_p), seq.shape[0], seq.shape[1]),
                    "irbpp_load_sequences")
-        # one contiguous block for the small per-step outputs -> a single D2H copy for callers that need it
+        # ONE contiguous block for the small per-step outputs and the error word -> one pinned D2H copy
         n = self.num_bins
-        self._out_f64 = torch.zeros((3, n), dtype=torch.float64, device=self.device)   # reward, ratio, ep_reward
-        self._out_i32 = torch.zeros((2, n), dtype=torch.int32, device=self.device)     # counter, ep_len
-        self._out_done = torch.zeros((n,), dtype=torch.uint8, device=self.device)
+        off_err = (33 * n + 3) & ~3
+        self._out = torch.zeros((off_err + 4,), dtype=torch.uint8, device=self.device)
+        self._out_host = torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True)
+        self._out_f64 = self._out[:24 * n].view(torch.float64).view(3, n)           # reward, ratio, ep_reward
+        self._out_i32 = self._out[24 * n:32 * n].view(torch.int32).view(2, n)       # counter, ep_len
+        self._out_done = self._out[32 * n:33 * n]
+        self._out_err = self._out[off_err:off_err + 4].view(torch.int32)
         self._step_out = _lib.IrbppStepOut(
             reward_dev=self._out_f64[0].data_ptr(), ratio_dev=self._out_f64[1].data_ptr(),
             ep_reward_dev=self._out_f64[2].data_ptr(), counter_dev=self._out_i32[0].data_ptr(),
-            ep_len_dev=self._out_i32[1].data_ptr(), done_dev=self._out_done.data_ptr())
+            ep_len_dev=self._out_i32[1].data_ptr(), done_dev=self._out_done.data_ptr(), err_dev=self._out_err.data_ptr())
 
     # -- set-up ------------------------------------------------------------------------------
     def _load_shapes(self, shapes: ShapeSet):
@@ -221,7 +225,8 @@ class GpuPackingEnv(object):
         """Tooling: (LDS bytes per workgroup, name of the transition-kernel build that launches)."""
         lds, wide = C.c_int32(0), C.c_int32(0)
         _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(wide)), "irbpp_debug_kernel_info")
-        return lds.value, "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
+        name = "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
+        return lds.value, name + " + irbpp_trace_kernel + irbpp_emit_kernel"
 
     def enable_kernel_timing(self, capacity: int) -> None:
         """Tooling: bracket the transition kernel of the next ``capacity`` launches with HIP events
@@ -243,11 +248,20 @@ class GpuPackingEnv(object):
                    f"device error flags={flags.value}")
 
     def step_info_host(self):
-        """One synchronising copy of the small per-step outputs -> dict of numpy arrays."""
-        f64 = self._out_f64.cpu().numpy()
-        i32 = self._out_i32.cpu().numpy()
-        done = self._out_done.cpu().numpy().astype(bool)
-        return dict(reward=f64[0], ratio=f64[1], ep_reward=f64[2], counter=i32[0], ep_len=i32[1], done=done)
+        """ONE pinned asynchronous D2H copy of the small per-step outputs + the device error word, then one
+        stream synchronisation -> dict of numpy arrays.  Raises if a kernel raised its error word."""
+        n = self.num_bins
+        st = torch.cuda.current_stream(self.device)
+        self._out_host.copy_(self._out, non_blocking=True)
+        st.synchronize()
+        h = self._out_host.numpy()
+        err = int(h[-4:].view(np.int32)[0])
+        if err:
+            raise _lib.IrbppError(f"device error flags={err}: " + _lib.load().irbpp_status_string(-4).decode())
+        f64 = h[:24 * n].view(np.float64).reshape(3, n)
+        i32 = h[24 * n:32 * n].view(np.int32).reshape(2, n)
+        return dict(reward=f64[0].copy(), ratio=f64[1].copy(), ep_reward=f64[2].copy(), counter=i32[0].copy(),
+                    ep_len=i32[1].copy(), done=h[32 * n:33 * n].astype(bool))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -259,6 +273,120 @@ class GpuPackingEnv(object):
             self.close()
         except Exception:
             pass
+
+
+class GroupedPackingEnv(object):
+    """``num_bins`` bins as ``num_groups`` independent groups, each a GpuPackingEnv on its own HIP stream.
+
+    Bins never interact, so a batch can be stepped as several sub-batches that do not wait for each other:
+    the straggler workgroups at the end of one group's kernels overlap the next group's work, which a single
+    launch over all bins cannot do (and joining the groups after every step costs more than it gives back,
+    see irbpp_capi.hip).  This is the shape of an actor loop with double-buffered environment groups: act on
+    group g while the other groups step.  Group g owns the global bins [g*n/G, (g+1)*n/G) and row block g of
+    every [num_bins, ...] tensor; trajectories are assigned by global bin index, so results are the same as
+    one GpuPackingEnv over all bins (tests/test_gpu_parity.py).  Nothing here synchronises except
+    ``synchronize()`` and ``reset()``."""
+
+    def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_bins: int, num_groups: int = 4, *, device="cuda:0",
+                 global_offset: int = 0, global_bins: Optional[int] = None, **kw):
+        if num_groups < 1 or num_bins % num_groups != 0:
+            raise ValueError("num_bins must be a multiple of num_groups")
+        self.device = torch.device(device)
+        self.num_bins, self.num_groups, self.per = int(num_bins), int(num_groups), num_bins // num_groups
+        total = num_bins if global_bins is None else global_bins
+        self.groups = [GpuPackingEnv(shapes, sequences, self.per, device=device, global_offset=global_offset + g * self.per,
+                                     global_bins=total, **kw) for g in range(num_groups)]
+        # one group: the caller's current stream; several: a stream each
+        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(num_groups)] if num_groups > 1 \
+            else [torch.cuda.current_stream(self.device)]
+        e = self.groups[0]
+        self.obs_len, self.loc_obs_len, self.K, self.S, self.n_rot = e.obs_len, e.loc_obs_len, e.K, e.S, e.n_rot
+        self.Hx, self.Hy, self.Ax, self.Ay = e.Hx, e.Hy, e.Ax, e.Ay
+
+    def rows(self, g: int) -> slice:
+        return slice(g * self.per, (g + 1) * self.per)
+
+    def reset(self) -> torch.Tensor:
+        """All groups; the result is complete when this returns to the current stream."""
+        obs = torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        for g, (e, st) in enumerate(zip(self.groups, self.streams)):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                _lib.check(e.lib.irbpp_reset(e._h, _ptr(obs[self.rows(g)]), e._stream()), "irbpp_reset")
+            cur.wait_stream(st)
+        return obs
+
+    def step_group(self, g: int, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+        """Group g alone, on its stream: (obs, reward, done) of its ``per`` bins."""
+        with torch.cuda.stream(self.streams[g]):
+            return self.groups[g].step(actions, obs_out=obs_out)
+
+    def policy_minz_group(self, g: int, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None):
+        with torch.cuda.stream(self.streams[g]):
+            return self.groups[g].policy_minz(loc_obs, actions_out=actions_out)
+
+    def get_action_candidates_group(self, g: int, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+        with torch.cuda.stream(self.streams[g]):
+            return self.groups[g].get_action_candidates(order_actions, obs_out=obs_out)
+
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Every group on its own stream (no join): row block g of the result belongs to stream g until
+        ``synchronize()``.  ``actions`` must be ready on the current stream."""
+        obs = obs_out if obs_out is not None else \
+            torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        for g in range(self.num_groups):
+            self.streams[g].wait_stream(cur)
+            self.step_group(g, actions[self.rows(g)], obs_out=obs[self.rows(g)])
+        return obs
+
+    def get_action_candidates(self, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        obs = obs_out if obs_out is not None else \
+            torch.empty((self.num_bins, self.loc_obs_len), dtype=torch.float32, device=self.device)
+        cur = torch.cuda.current_stream(self.device)
+        for g in range(self.num_groups):
+            self.streams[g].wait_stream(cur)
+            self.get_action_candidates_group(g, order_actions[self.rows(g)], obs_out=obs[self.rows(g)])
+        return obs
+
+    def reset_bins(self, bins: torch.Tensor) -> torch.Tensor:
+        """PackingGame.reset of the listed bins (distinct global-to-this-env indices), rows in list order."""
+        self.synchronize()
+        idx = bins.cpu().numpy()
+        out = torch.empty((len(idx), self.obs_len), dtype=torch.float32, device=self.device)
+        for g in range(self.num_groups):
+            sel = np.nonzero(idx // self.per == g)[0]
+            if len(sel):
+                local = torch.from_numpy((idx[sel] - g * self.per).astype(np.int32)).to(self.device)
+                out[torch.from_numpy(sel).to(self.device)] = self.groups[g].reset_bins(local)
+        torch.cuda.synchronize(self.device)
+        return out
+
+    def synchronize(self) -> None:
+        for st in self.streams:
+            st.synchronize()
+
+    def episode_totals(self) -> torch.Tensor:
+        self.synchronize()
+        return torch.stack([e.episode_totals() for e in self.groups]).sum(0)
+
+    def get_heightmaps(self) -> torch.Tensor:
+        self.synchronize()
+        return torch.cat([e.get_heightmaps() for e in self.groups])
+
+    def check_device_error(self) -> None:
+        for e in self.groups:
+            e.check_device_error()
+
+    def step_info_host(self):
+        self.synchronize()
+        parts = [e.step_info_host() for e in self.groups]
+        return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+
+    def close(self):
+        for e in self.groups:
+            e.close()
 
 
 class _Infos(Sequence):
@@ -288,8 +416,15 @@ class GpuVecEnv(object):
     closed = False
 
     def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0",
-                 allow_early_resets: bool = True, **env_kw):
-        self.env = GpuPackingEnv(shapes, sequences, num_envs, device=device, **env_kw)
+                 allow_early_resets: bool = True, num_groups: int = 1, **env_kw):
+        """``num_groups`` > 1: the envs are stepped as that many independent groups on their own HIP streams
+        (GroupedPackingEnv); ``step()`` still covers all envs, and ``step_async(actions, group=g)`` /
+        ``step_wait(group=g)`` let an actor loop work on one group while the others step."""
+        self.num_groups = int(num_groups)
+        if self.num_groups > 1:
+            self.env = GroupedPackingEnv(shapes, sequences, num_envs, self.num_groups, device=device, **env_kw)
+        else:
+            self.env = GpuPackingEnv(shapes, sequences, num_envs, device=device, **env_kw)
         self.allow_early_resets = allow_early_resets                       # Monitor's flag (monitor.py:44-48)
         self.num_envs = num_envs
         self.device = self.env.device
@@ -299,6 +434,7 @@ class GpuVecEnv(object):
         self.action_space = Discrete(self.env.K if self.env.K > 1 else self.env.S)
         self.waiting_step = False
         self._pending = None
+        self._group_pending = {}
         self.tstart = time.time()
 
     def _actions_to_device(self, actions) -> torch.Tensor:
@@ -315,19 +451,37 @@ class GpuVecEnv(object):
         self.tstart = time.time()
         return self.env.reset()
 
-    def step_async(self, actions) -> None:
+    def step_async(self, actions, group: Optional[int] = None) -> None:
+        """All envs, or (grouped envs only) the envs of one group: ``actions`` then has that group's length."""
+        if group is not None:
+            if self._group_pending.get(group) is not None:
+                raise RuntimeError("already running an async step")
+            e = self.env.groups[group]
+            a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(actions).reshape(-1)))
+            with torch.cuda.stream(self.env.streams[group]):
+                obs, _, _ = e.step(a.reshape(-1).to(device=self.device, dtype=torch.int32, non_blocking=True))
+            self._group_pending[group] = obs
+            return
         if self.waiting_step:
             raise RuntimeError("already running an async step")          # vec_env.py:7-16
-        obs, _, _ = self.env.step(self._actions_to_device(actions))
-        self._pending = obs
+        res = self.env.step(self._actions_to_device(actions))
+        self._pending = res if isinstance(res, torch.Tensor) else res[0]
         self.waiting_step = True
 
-    def step_wait(self):
+    def step_wait(self, group: Optional[int] = None):
+        if group is not None:
+            obs = self._group_pending.get(group)
+            if obs is None:
+                raise RuntimeError("not running an async step")
+            with torch.cuda.stream(self.env.streams[group]):
+                h = self.env.groups[group].step_info_host()
+            self._group_pending[group] = None
+            reward = torch.from_numpy(h["reward"]).unsqueeze(dim=1).float()
+            return obs, reward, h["done"], _Infos(h, round(time.time() - self.tstart, 6))
         if not self.waiting_step:
             raise RuntimeError("not running an async step")              # vec_env.py:19-27
         obs = self._pending
-        h = self.env.step_info_host()                                    # the only sync point of a step
-        self.env.check_device_error()                                    # kernels raise an error word; fail loudly
+        h = self.env.step_info_host()                # ONE D2H copy per (group of) envs, error word included: the sync point
         self._pending = None
         self.waiting_step = False
         reward = torch.from_numpy(h["reward"]).unsqueeze(dim=1).float()   # envs.py:164
@@ -337,11 +491,19 @@ class GpuVecEnv(object):
         self.step_async(actions)
         return self.step_wait()
 
-    def get_action_candidates(self, order_actions) -> torch.Tensor:
-        """Location observations [N, 5S+9+Hc].  The trainer wraps the return value with
-        ``torch.from_numpy(np.array(..))`` (trainer.py:267-268); a device tensor also supports
-        ``np.array`` after ``.cpu()``, and callers that accept tensors can skip the round trip."""
-        return self.env.get_action_candidates(self._actions_to_device(order_actions))
+    # False (default): get_action_candidates returns a host float32 array, which the unmodified trainer can wrap
+    # with ``torch.from_numpy(np.array(..)).float().to(device)`` (trainer.py:267-268) -- at the price of a PCIe
+    # round trip of N x 14 KB.  True: the device tensor itself (callers that accept tensors skip the trip).
+    candidates_on_device = False
+
+    def get_action_candidates(self, order_actions):
+        """Location observations [N, 5S+9+Hc] of the chosen buffer slots (shmem_vec_env.py:99-102)."""
+        loc = self.env.get_action_candidates(self._actions_to_device(order_actions))
+        if self.candidates_on_device:
+            return loc
+        if self.num_groups > 1:
+            self.env.synchronize()
+        return loc.cpu().numpy()
 
     def reset_specific(self, indexs) -> torch.Tensor:
         """shmem_vec_env.py:113-117: reset the listed envs only; their observations in list order."""

@@ -149,10 +149,12 @@ def test_kat5_buffer_pop_order():
     shapes = _boxes([(0.03, 0.03, 0.03), (0.06, 0.06, 0.06), (0.09, 0.09, 0.09), (0.12, 0.12, 0.12)])
     seq = np.tile(np.array([[2, 1, 3, 0, 1, 2, 3, 0]], dtype=np.int32), (4, 1))
     env = GpuVecEnv(shapes, seq, 1, device=DEV, bufferSize=3)
+    env.candidates_on_device = False
     order = env.reset().cpu().numpy()[0]
     assert order.shape == (3 + 1024,)
     np.testing.assert_array_equal(order[:3], [2, 1, 3])
-    loc = env.get_action_candidates(np.array([1])).cpu().numpy()[0]
+    loc = env.get_action_candidates(np.array([1]))[0]            # drop-in default: a host array (trainer.py:267-268)
+    assert isinstance(loc, np.ndarray) and loc.dtype == np.float32
     assert loc.shape == (5 * S + 9 + 1024,) and loc[5 * S] == 1.0                     # built for item b = 1
     rows = _rows(loc)
     np.testing.assert_array_equal(rows[:8], np.array(KAT1_ROWS, dtype=np.float32))    # the 0.06 box of KAT-1

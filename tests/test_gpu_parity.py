@@ -16,6 +16,7 @@ from oracle.space import Space
 from helpers import golden_scenario, minz_action
 
 pytestmark = pytest.mark.gpu
+GpuVecEnv.candidates_on_device = True        # these tests feed the location observations back to device kernels
 S = 500
 DEV = "cuda:0"
 
@@ -518,7 +519,7 @@ def test_abi_rejects_calls_out_of_order():
     lib = _lib.load()
     cfg = _lib.IrbppConfig(num_bins=2, n_rot=2, selected=500, buffer_size=1, resolution_a=0.02, resolution_h=0.01,
                            resolution_z=0.01, bin=(C.c_double * 3)(0.32, 0.32, 0.3), scale_z=100.0, traj_start=1,
-                           global_offset=0, global_bins=2, device=0, contour_slots=0)
+                           global_offset=0, global_bins=2, device=0, reserved=0)
     h = C.c_void_p()
     assert lib.irbpp_create(C.byref(cfg), C.byref(h)) == 0
     obs = torch.zeros((2, 3533), dtype=torch.float32, device=DEV)
@@ -615,7 +616,7 @@ def test_bench_gpus2_spawns_two_real_ranks():
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(var, None)
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bins", "256",
-                          "--steps", "5", "--warmup", "2", "--prefill", "120", "--no-cpu-baseline", "--pipeline-streams", "0"],
+                          "--steps", "5", "--warmup", "2", "--prefill", "120", "--no-cpu-baseline"],
                          capture_output=True, text=True, timeout=600, env=env)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]

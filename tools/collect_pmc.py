@@ -49,7 +49,7 @@ entry = {"bins": bins, "kernel": env, "FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_av
          "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
          "hbm_bytes_per_bin_step": (2 * fk + wk) * 1024 / bins,
          "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --bins %d --workload %s "
-                    "--no-cpu-baseline --pipeline-streams 0 --no-extra (each counter group in its own pass)" % (bins, workload)}
+                    "--no-cpu-baseline --no-extra (each counter group in its own pass)" % (bins, workload)}
 if pol:
     entry["calibration"] = {"policy_kernel_FETCH_SIZE_KB": tail_avg(f[pol[0]]["FETCH_SIZE"]),
                             "policy_kernel_true_read_bytes": bins * 2500 * 4,

@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$R/gpurun_out/$1; WL=${2:-blockout}; BINS=${3:-16384}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --workload $WL --no-cpu-baseline --pipeline-streams 0 --no-extra"
+B="python $R/bench.py --workload $WL --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o r02 -- $B --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 P="$B --bins $BINS --steps 60 --warmup 10 --prefill 150"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r02 -- $P > "$OUT/bench_pmc_fetch.json" 2> "$OUT/fetch.err"

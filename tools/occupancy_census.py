@@ -22,11 +22,10 @@ ap.add_argument("--workload", default="blockout")
 ap.add_argument("--bins", type=int, default=4096)
 ap.add_argument("--warm", type=int, default=120)
 ap.add_argument("--steps", type=int, default=6)
-ap.add_argument("--slots", type=int, default=0)
 a = ap.parse_args()
 
 shapes, seqs, kw = make_workload(a.workload)
-env = GpuPackingEnv(shapes, seqs, a.bins, device="cuda:0", contour_slots=a.slots, **kw)
+env = GpuPackingEnv(shapes, seqs, a.bins, device="cuda:0", **kw)
 obs = env.reset()
 for _ in range(a.warm):
     obs, _, _ = env.step(env.policy_minz(obs))

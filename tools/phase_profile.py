@@ -21,11 +21,10 @@ ap.add_argument("--workload", default="blockout")
 ap.add_argument("--bins", type=int, default=4096)
 ap.add_argument("--warm", type=int, default=120)
 ap.add_argument("--steps", type=int, default=8)
-ap.add_argument("--slots", type=int, default=0)
 a = ap.parse_args()
 
 shapes, seqs, kw = make_workload(a.workload)
-env = GpuPackingEnv(shapes, seqs, a.bins, device="cuda:0", contour_slots=a.slots, **kw)
+env = GpuPackingEnv(shapes, seqs, a.bins, device="cuda:0", **kw)
 obs = env.reset()
 for _ in range(a.warm):
     obs, _, _ = env.step(env.policy_minz(obs))
@@ -41,7 +40,7 @@ for _ in range(a.steps):
     extra.append(np.concatenate([c[:, 5:8], c[:, 11:16]], axis=1))
 d = np.concatenate(acc)
 ncand = (obs[:, :2500].reshape(a.bins, 500, 5)[:, :, 4] == 1).sum(1).float()
-out = {"workload": a.workload, "bins": a.bins, "slots": a.slots,
+out = {"workload": a.workload, "bins": a.bins, 
        "mean_cycles": {n: float(d[:, i].mean()) for i, n in enumerate(names)},
        "p99_cycles": {n: float(np.percentile(d[:, i], 99)) for i, n in enumerate(names)},
        "max_cycles": {n: float(d[:, i].max()) for i, n in enumerate(names)},
