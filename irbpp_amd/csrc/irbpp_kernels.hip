@@ -1243,14 +1243,18 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             if (round6_scaled(tx + sr.ext_x - P.bin_x) > 0.0 || round6_scaled(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
         }
         double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)
+        // The reference reads the drop height before it looks at `success`, and appends the placement to
+        // self.packed either way (binPhy.py:266,296): with a placement log attached, a refused placement needs
+        // its height too.
+        const bool in_grid = item0 >= 0 && rot < P.R && lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay;
+        if (in_grid && (ok || cold_args()->S.log_meta != nullptr)) {
+            const Cell* cells = T.bcell + sr.ob;
+            const double* h0 = L.hm + lx * P.Ay + ly;
+            double m = sr.has_out ? 0.0 : -1e300;
+            for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, h0[cells[e].off] - cells[e].v);
+            z = block_max_f64(m, L.redd);
+        }
         if (ok) {
-            if (lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay) {
-                const Cell* cells = T.bcell + sr.ob;
-                const double* h0 = L.hm + lx * P.Ay + ly;
-                double m = sr.has_out ? 0.0 : -1e300;
-                for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, h0[cells[e].off] - cells[e].v);
-                z = block_max_f64(m, L.redd);
-            }
             // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
             const double top = z * P.scale_z + sr.ext_z * P.scale_z;
             if (round6_scaled(top - P.ibin_z) > 0.0) ok = false;
@@ -1307,6 +1311,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 if (ka->io.ratio) ka->io.ratio[b] = ratio;
                 if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
                 if (ka->io.ep_len) ka->io.ep_len[b] = epl;
+                if (ka->S.log_meta && counter < ka->S.log_cap) {       // the refused placement is in self.packed too (binPhy.py:296)
+                    ka->S.log_meta[(size_t)b * ka->S.log_cap + counter] = (uint32_t)(item0 & 0xFFFF) | ((uint32_t)(rot & 15) << 16) |
+                                                                   ((uint32_t)(lx & 15) << 20) | ((uint32_t)(ly & 15) << 24);
+                    ka->S.log_z[(size_t)b * ka->S.log_cap + counter] = z;
+                }
                 double* tot = ka->S.totals + (size_t)b * 4;
                 tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
                 // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset

@@ -30,12 +30,15 @@ def rotation_quaternion_xyzw(rot_idx: int) -> np.ndarray:
 
 def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] = None, device="cuda:0",
              names: Optional[Dict[int, str]] = None, traj_start: int = 1, max_steps: int = 4096,
-             log_capacity: int = 256, **env_kw):
+             log_capacity: int = 256, save: Optional[str] = None, **env_kw):
     """Run ``n_episodes`` evaluation episodes, one per bin.
 
     ``policy(env, obs) -> int32[N] device tensor`` picks the actions; default = the scripted MINZ
     policy kernel.  Returns a dict with the statistics ``tools.test`` prints and ``trajs``: a list
-    over episodes of lists of ``[item_id, name, positionFLB(3), quaternion_xyzw(4)]``.
+    over episodes of ``env.packed`` (binPhy.py:296), i.e. one row ``[item_id, name, positionFLB(3),
+    quaternion_xyzw(4)]`` per placement INCLUDING the refused one that ended the episode (the reference
+    appends before it looks at ``success``).  ``save``: also write them as ``tools.test`` does
+    (``np.save(.../trajs.npy, all_episodes)``, tools.py:339-340,354): an object array, one entry per episode.
     """
     env = GpuPackingEnv(shapes, sequences, n_episodes, device=device, traj_start=traj_start,
                         global_bins=n_episodes, **env_kw)
@@ -65,9 +68,11 @@ def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] =
                 k = int(h["counter"][b])
                 ratio[b], reward_sum[b], length[b] = h["ratio"][b], h["ep_reward"][b], h["ep_len"][b]
                 ep = []
-                for i in range(min(k, log_capacity)):
+                for i in range(min(k + 1, log_capacity)):        # k accepted placements + the refused one
                     w = int(m[row, i])
                     item, rot, lx, ly = w & 0xFFFF, (w >> 16) & 15, (w >> 20) & 15, (w >> 24) & 15
+                    if item == 0xFFFF:                            # trajectory exhausted: no item to place (None)
+                        break
                     flb = np.round((lx * res_a, ly * res_a, bin_z), decimals=6) * scale     # addObject (Interface.py:201)
                     flb[2] = z[row, i] * scale[2]                                           # adjustHeight (Interface.py:185-187)
                     ep.append([item, names[item] if names else "%d.obj" % item, flb / scale, rotation_quaternion_xyzw(rot)])
@@ -78,6 +83,8 @@ def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] =
     env.check_device_error()
     env.close()
     done = finished
+    if save is not None:
+        save_trajs(save, [trajs[b] for b in range(n) if done[b]])
     return {
         "episodes": int(done.sum()), "unfinished": int((~done).sum()),
         "avg_reward": float(reward_sum[done].mean()), "var_reward": float(reward_sum[done].var()),
@@ -85,3 +92,15 @@ def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] =
         "mean_ratio": float(ratio[done].mean()), "var_ratio": float(ratio[done].var()),
         "ratio": ratio, "reward_sum": reward_sum, "length": length, "trajs": trajs,
     }
+
+
+def save_trajs(path: str, all_episodes) -> None:
+    """``np.save(path, all_episodes)`` as tools.test calls it (tools.py:339-340,354) under the reference's numpy
+    1.21: a list of episodes of different lengths becomes a 1-D object array of lists; current numpy refuses that
+    implicit conversion, so the container is built explicitly.  ``np.load(path, allow_pickle=True)`` reads it."""
+    import os
+    arr = np.empty(len(all_episodes), dtype=object)
+    for i, ep in enumerate(all_episodes):
+        arr[i] = ep
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    np.save(path, arr, allow_pickle=True)

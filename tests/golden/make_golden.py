@@ -10,6 +10,7 @@ What executes from /root/reference, unmodified:
     environment/physics0/cvTools.py   find_out_contour, find_convex_vetex, convexHulls,
                                       getConvexHullActions
     environment/physics0/IRcreator.py ItemCreator, LoadItemCreator
+    tools.py                          test (the evaluation loop, with a stub agent), get_mask_from_state
     environment/physics0/binPhy.py    PackingGame.__init__/reset/cur_observation/
                                       get_action_candidates/action_to_position/prejudge/
                                       step/get_ratio/get_item_ratio
@@ -328,6 +329,52 @@ def ircreator_trace():
     return dict(seqs=np.array(seqs), trace=np.array(trace))
 
 
+def tools_test_golden(episodes=5):
+    """The reference's own evaluation loop ``tools.test`` (tools.py:303-358) with a stub agent that plays the
+    scripted MINZ policy: statistics it returns and the ``trajs.npy`` it writes (``env.packed`` of every episode:
+    rows ``[item id, name, positionFLB, quaternion xyzw]``, binPhy.py:296)."""
+    import importlib
+    ref_tools = importlib.import_module("tools")
+    blk = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    seqs = synthetic.make_sequences(blk.n_shapes, 16, 80, seed=1)
+    ref_tools.make_eval_env = lambda args: make_reference_env(blk, seqs)
+
+    class _Net(object):
+        training = True
+
+        def eval(self):
+            self.training = False
+
+        def train(self):
+            self.training = True
+
+    class _Agent(object):
+        online_net = _Net()
+
+        def act_e_greedy(self, state, mask, epsilon):
+            return torch.tensor(minz_action(state[0].numpy().astype(np.float64), 500))
+
+    args = types.SimpleNamespace(evaluation_episodes_test=episodes, device="cpu", bufferSize=1, selectedAction=500, action_space=500)
+    real_save = np.save
+    # numpy 1.21 (the reference's pin) turns a ragged list into an object array inside np.save; numpy >= 1.24 refuses
+    ref_tools.np.save = lambda path, a: real_save(path, np.array(a, dtype=object), allow_pickle=True)
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "logs", "evaluation", "golden"))
+    os.chdir(tmp)
+    try:
+        avg_reward, avg_length = ref_tools.test(args, _Agent(), False, "golden", "")
+    finally:
+        os.chdir(cwd)
+        ref_tools.np.save = real_save
+    trajs = np.load(os.path.join(tmp, "logs", "evaluation", "golden", "trajs.npy"), allow_pickle=True)
+    ep_len = np.array([len(ep) for ep in trajs])
+    rows = [row for ep in trajs for row in ep]
+    return dict(seq=seqs, ep_len=ep_len, ids=np.array([r[0] for r in rows]), names=np.array([r[1] for r in rows]),
+                pos=np.array([np.asarray(r[2], dtype=np.float64) for r in rows]),
+                quat=np.array([np.asarray(r[3], dtype=np.float64) for r in rows]),
+                avg_reward=np.array(avg_reward), avg_length=np.array(avg_length))
+
+
 def main():
     cube = synthetic.cube_shapes()
     blk = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
@@ -341,6 +388,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "hier_blockout_k3.npz"), seq=seq_b, **run_hier(blk, seq_b, 90, 3))
     np.savez_compressed(os.path.join(OUT, "cvtools_cases.npz"), **cvtools_cases())
     np.savez_compressed(os.path.join(OUT, "ircreator_trace.npz"), **ircreator_trace())
+    np.savez_compressed(os.path.join(OUT, "tools_test.npz"), **tools_test_golden())
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

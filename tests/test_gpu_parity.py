@@ -376,13 +376,66 @@ def test_batched_evaluation_matches_sequential_reference_protocol():
                 break
         assert out["ratio"][ep] == info["ratio"] and out["length"][ep] == steps
         assert out["reward_sum"][ep] == rsum
-        placed = env.packed[:-1]                     # the last entry is the failed placement (binPhy.py:296-311)
-        assert len(out["trajs"][ep]) == len(placed) == info["counter"]
+        placed = env.packed                          # the last entry is the refused placement (binPhy.py:296-311)
+        assert len(out["trajs"][ep]) == len(placed) == info["counter"] + 1
         for got, (item, rot, lx, ly, height) in zip(out["trajs"][ep], placed):
             assert got[0] == item and got[1] == "%d.obj" % item
             np.testing.assert_allclose(got[2], [lx * 0.02, ly * 0.02, height], rtol=0, atol=1e-12)
             np.testing.assert_array_equal(got[3], rotation_quaternion_xyzw(rot))
     assert abs(out["mean_ratio"] - np.mean(out["ratio"])) < 1e-15
+
+
+def test_evaluation_writes_the_reference_trajs_file(golden_dir, tmp_path):
+    """evaluate(save=...) against the golden of the reference's own tools.test (tests/golden/make_golden.py):
+    ``trajs.npy`` as an object array, one ``env.packed`` list per episode, rows [id, name, positionFLB, quaternion]."""
+    from irbpp_amd.evaluate import evaluate
+    g = np.load(os.path.join(golden_dir, "tools_test.npz"))
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    path = str(tmp_path / "logs" / "evaluation" / "run" / "trajs.npy")
+    out = evaluate(sh, g["seq"], len(g["ep_len"]), device=DEV, save=path)
+    trajs = np.load(path, allow_pickle=True)
+    assert trajs.dtype == object and len(trajs) == len(g["ep_len"])
+    row = 0
+    for ep, want_len in zip(trajs, g["ep_len"]):
+        assert len(ep) == want_len
+        for i, (item, name, pos, quat) in enumerate(ep):
+            assert item == g["ids"][row] and name == g["names"][row]
+            # the cell a refused "action 0" points at when no candidate was valid depends on numpy's unstable argsort
+            if i < want_len - 1 or g["pos"][row][2] < 1e3:
+                np.testing.assert_allclose(pos, g["pos"][row], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(quat, g["quat"][row], rtol=0, atol=1e-12)
+            row += 1
+    assert abs(out["avg_reward"] - float(g["avg_reward"])) < 1e-9 and out["avg_length"] == float(g["avg_length"])
+
+
+def test_dataset_directory_with_meshes_is_rasterised_and_cached(tmp_path):
+    """load_reference_dataset on a directory without a shotInfo cache: the meshes are ray-cast on the GPU, the tables
+    equal the analytic ones, and the cache the reference reads at start-up (tools.py:258-277) is written."""
+    import torch as _t
+    from irbpp_amd import dataset, meshes
+    blk = synthetic.blockout_shapes(n_shapes=6, n_rot=4, seed=0)
+    ms = {k: meshes.voxel_mesh(o, 0.04) for k, o in enumerate(synthetic.blockout_voxels(6, 0))}
+    names = {k: "poly%d.obj" % k for k in range(6)}
+    seqs = synthetic.make_sequences(6, 8, 40, seed=2)
+    root = str(tmp_path)
+    dataset.save_reference_dataset(root, "blk6", names, seqs, ms)
+    shapes, seqs2, names2 = dataset.load_reference_dataset(root, "blk6", 0.01, n_rot=4, device=DEV)
+    assert shapes.meta["tables_from"] == "rasteriser" and names2 == names
+    np.testing.assert_allclose(shapes.extents, blk.extents, rtol=0, atol=1e-12)
+    for k in range(6):
+        for r in range(4):
+            for got, ref in zip(shapes.tables[k][r], blk.tables[k][r]):
+                np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12)
+    cache = dataset.shot_info_dir(root, "blk6", 0.01)
+    T, B, mH, mB = _t.load(os.path.join(cache, "5_3.pt"), weights_only=False)        # as tools.py:271-272 reads it
+    np.testing.assert_array_equal(T, shapes.tables[5][3][0])
+    again, _, _ = dataset.load_reference_dataset(root, "blk6", 0.01, n_rot=4)        # now from the cache, no device
+    assert again.meta["tables_from"] == "cache"
+    genv = GpuVecEnv(again, seqs2, 3, device=DEV)                                    # and it drives the environment
+    obs = genv.reset()
+    for _ in range(5):
+        obs, _, _, _ = genv.step(genv.env.policy_minz(obs).cpu().numpy())
+    genv.close()
 
 
 def test_shot_item_rasteriser_matches_oracle_and_analytic_tables():
