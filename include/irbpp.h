@@ -54,7 +54,10 @@ typedef struct {
     int32_t global_offset;   /* global index of this device's bin 0 (multi-GPU sharding)         */
     int32_t global_bins;     /* bins over all ranks = trajectory stride between episodes         */
     int32_t device;          /* HIP device ordinal                                               */
-    int32_t reserved;        /* 0 (was a tuning knob of an earlier kernel; kept so the struct layout is stable) */
+    int32_t stability;       /* stand-in for the rigid-body settling the path leaves out (Interface.py:271-310):
+                                0 off; 1 every accepted placement is also rated by a static support test
+                                (irbpp_step_out::stable_dev), results otherwise unchanged; 2 a placement that
+                                fails the test is refused like one that does not fit (episode ends)          */
 } irbpp_config;
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
@@ -67,6 +70,8 @@ typedef struct {
     double*  ratio_dev;       /* info['ratio']   = get_ratio(),  valid where done                */
     double*  ep_reward_dev;   /* sum of the episode's rewards (Monitor 'r' before round(.,6))    */
     int32_t* ep_len_dev;      /* Monitor 'l'                                                     */
+    uint8_t* stable_dev;      /* irbpp_config::stability >= 1: 1 iff the placement of this step rests stably
+                                 (0 also where the step placed nothing); NULL to skip                    */
     int32_t* err_dev;         /* copy of the device error word after this step (one int32, not per bin):
                                  callers that fetch the outputs with one D2H copy get it for free   */
 } irbpp_step_out;
@@ -184,6 +189,24 @@ int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream);
  * placement overwrites them, so read them right after the step that reported done.  NULL, NULL
  * switches the log off. */
 int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, int32_t capacity);
+
+/* Caller side: the N per-env prioritised replay memories of main.py:61-63 as one tensor set.
+ * replaces: SegmentTree.find/_retrieve (memory.py:72-86) for `draws` values per env.
+ * tree_dev float32[n_env][2*capacity-1] (implicit heap, leaves at capacity-1..), values_dev float32[n_env][draws];
+ * outputs [n_env][draws]: leaf value, data index (tree index - capacity + 1), tree index. */
+int irbpp_sumtree_find(const float* tree_dev, int32_t n_env, int32_t capacity, const float* values_dev, int32_t draws,
+                       float* prob_dev, int64_t* data_idx_dev, int64_t* tree_idx_dev, void* stream);
+/* replaces: SegmentTree.update/_propagate (memory.py:47-58) for `leaves` (tree index, value) pairs per env, applied
+ * in list order, every ancestor recomputed as left + right in float32; max_dev float32[n_env] is SegmentTree.max.
+ * env_mask_dev (may be NULL) uint8[n_env]: envs with 0 are skipped.  IRBPP_ERR_ARG if 2*capacity-1 > 16384 (the
+ * caller then keeps its own path). */
+int irbpp_sumtree_update(float* tree_dev, float* max_dev, int32_t n_env, int32_t capacity, const int64_t* tree_idx_dev,
+                         const float* priority_dev, int32_t leaves, const uint8_t* env_mask_dev, void* stream);
+/* replaces: the tail of Agent.act (agent.py:55-58) with get_mask_from_state (tools.py:298-299) fused in:
+ * action[e] = argmax_i q[e][i] over the candidates i whose validity flag obs[e][5*i+4] is non-zero (first maximum;
+ * 0x7fffffff never occurs: with no valid candidate every q is -inf and index 0 wins, like torch.argmax). */
+int irbpp_masked_argmax(const float* q_dev, int32_t q_stride, const float* obs_dev, int32_t obs_stride, int32_t selected,
+                        int32_t n_env, int64_t* action_dev, void* stream);
 
 /* Tooling: when cycles_dev != NULL every later transition launch stores, per bin, one row
  * int64[num_bins][16]: shader-clock stamps 0 start, 1 action applied, 2 overlap test done,

@@ -17,14 +17,14 @@ class IrbppConfig(C.Structure):
         ("resolution_a", C.c_double), ("resolution_h", C.c_double), ("resolution_z", C.c_double),
         ("bin", C.c_double * 3), ("scale_z", C.c_double),
         ("traj_start", C.c_int32), ("global_offset", C.c_int32), ("global_bins", C.c_int32),
-        ("device", C.c_int32), ("reserved", C.c_int32),
+        ("device", C.c_int32), ("stability", C.c_int32),
     ]
 
 
 class IrbppStepOut(C.Structure):
     _fields_ = [("reward_dev", C.c_void_p), ("done_dev", C.c_void_p), ("counter_dev", C.c_void_p),
                 ("ratio_dev", C.c_void_p), ("ep_reward_dev", C.c_void_p), ("ep_len_dev", C.c_void_p),
-                ("err_dev", C.c_void_p)]
+                ("stable_dev", C.c_void_p), ("err_dev", C.c_void_p)]
 
 
 # every entry point include/irbpp.h declares: name -> (restype, argtypes)
@@ -51,6 +51,12 @@ SIGNATURES = {
     "irbpp_set_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_placement_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "irbpp_sumtree_find": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
+                                     C.c_void_p, C.c_void_p]),
+    "irbpp_sumtree_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
+    "irbpp_masked_argmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                      C.c_void_p]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
     "irbpp_debug_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "irbpp_debug_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),

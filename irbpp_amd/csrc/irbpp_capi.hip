@@ -15,6 +15,7 @@
 #include "../../include/irbpp.h"
 #include "irbpp_device.h"
 #include "irbpp_kernels.hip"      // single translation unit: kernels + host ABI
+#include "irbpp_replay.hip"
 
 using namespace irbpp;
 
@@ -174,6 +175,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
     if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
     P.split = 1;                                            // transition -> trace -> emit kernels
+    P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     if (const char* sp = getenv("IRBPP_SPLIT")) P.split = atoi(sp) != 0;    // 0: the fused single-kernel path (A/B tool)
     if (const char* bw = getenv("IRBPP_TRACE_BPW")) { const int v = atoi(bw); env->trace_bpw = v == 1 || v == 2 || v == 4 ? v : 2; }
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
@@ -301,6 +303,19 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             }
             s.nb = (int32_t)bcell.size() - s.ob;
             s.nt = (int32_t)tcell.size() - s.ot;
+            {   // centre of mass of the solid between bottom and top table (columns hit from both sides)
+                double mass = 0.0, mx = 0.0, my = 0.0;
+                for (int ci = 0; ci < s.fx; ++ci)
+                    for (int cj = 0; cj < s.fy; ++cj) {
+                        const int64_t e = off + (int64_t)ci * s.fy + cj;
+                        if (mask_top[e] != 0.0 && mask_bottom[e] != 0.0) {
+                            const double w = height_top[e] - height_bottom[e] > 0.0 ? height_top[e] - height_bottom[e] : 0.0;
+                            mass += w; mx += w * (ci + 0.5); my += w * (cj + 0.5);
+                        }
+                    }
+                s.com_x = mass > 0.0 ? mx / mass : 0.5 * s.fx;
+                s.com_y = mass > 0.0 ? my / mass : 0.5 * s.fy;
+            }
             s.oblk = (int32_t)blkcell.size();
             if (block_b)
                 for (int ti = 0; ti < s.fx / block_b; ++ti)
@@ -446,6 +461,7 @@ int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const
         io.ratio = out->ratio_dev;
         io.ep_reward = out->ep_reward_dev;
         io.ep_len = out->ep_len_dev;
+        io.stable = out->stable_dev;
     }
     const int rc = launch_env(env, io, MODE_STEP, stream);
     if (rc == IRBPP_OK && out && out->err_dev)
@@ -548,6 +564,34 @@ int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, i
     env->S.log_z = z_dev;
     env->S.log_cap = meta_dev ? capacity : 0;
     return IRBPP_OK;
+}
+
+int irbpp_sumtree_find(const float* tree_dev, int32_t n_env, int32_t capacity, const float* values_dev, int32_t draws,
+                       float* prob_dev, int64_t* data_idx_dev, int64_t* tree_idx_dev, void* stream) {
+    if (!tree_dev || !values_dev || !prob_dev || !data_idx_dev || !tree_idx_dev || n_env < 1 || capacity < 1 || draws < 1)
+        return IRBPP_ERR_ARG;
+    const int n = n_env * draws;
+    hipLaunchKernelGGL(irbpp_sumtree_find_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tree_dev, n_env,
+                       capacity, values_dev, draws, prob_dev, data_idx_dev, tree_idx_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_sumtree_update(float* tree_dev, float* max_dev, int32_t n_env, int32_t capacity, const int64_t* tree_idx_dev,
+                         const float* priority_dev, int32_t leaves, const uint8_t* env_mask_dev, void* stream) {
+    if (!tree_dev || !max_dev || !tree_idx_dev || !priority_dev || n_env < 1 || capacity < 1 || leaves < 1) return IRBPP_ERR_ARG;
+    if (2 * capacity - 1 > SUMTREE_LDS) return IRBPP_ERR_ARG;        // caller keeps its host-side path for longer rows
+    hipLaunchKernelGGL(irbpp_sumtree_update_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, tree_dev, max_dev, capacity,
+                       tree_idx_dev, priority_dev, leaves, env_mask_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_masked_argmax(const float* q_dev, int32_t q_stride, const float* obs_dev, int32_t obs_stride, int32_t selected,
+                        int32_t n_env, int64_t* action_dev, void* stream) {
+    if (!q_dev || !obs_dev || !action_dev || n_env < 1 || selected < 1 || q_stride < selected || obs_stride < 5 * selected)
+        return IRBPP_ERR_ARG;
+    hipLaunchKernelGGL(irbpp_masked_argmax_kernel, dim3((n_env + 3) / 4), dim3(256), 0, (hipStream_t)stream, q_dev, q_stride,
+                       obs_dev, obs_stride, selected, n_env, action_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {

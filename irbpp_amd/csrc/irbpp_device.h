@@ -35,6 +35,8 @@ struct ShapeRot {
     int32_t nblk, oblk;    // block list (Params.block_b > 0): uniform-bottom b x b tiles of the footprint
     double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
     double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
+    double com_x, com_y;          // centre of mass of the column solid between the two tables, in heightmap cells from the
+                                  // footprint's corner (stability proxy only)
 };
 
 // Footprint tables are stored as compact lists of the masked-in cells only.  A masked-out cell
@@ -121,6 +123,7 @@ struct Params {
     // 16 whole contour stage.
     int32_t dbg_repeat;
     int32_t split;         // 1: transition kernel -> trace kernel -> emit kernel; 0: everything in the transition kernel
+    int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
 };
 
 enum Mode : int32_t {
@@ -140,6 +143,7 @@ struct StepIO {
     double* ratio;
     double* ep_reward;
     int32_t* ep_len;
+    uint8_t* stable;            // stability proxy verdict of this step's placement
     double* posz_out;           // MODE_POSSIBLE
     uint8_t* mask_out;
     long long* phase_cycles;    // optional [N][8] shader-clock stamps per phase (tooling)

@@ -140,6 +140,8 @@ __device__ __forceinline__ KernArgsPtr cold_args() {
     return p;
 }
 
+__device__ __forceinline__ uint32_t div_magic_dev(int d) { return d >= 2 ? (uint32_t)(0x100000000ull / (uint64_t)d + 1ull) : 0u; }
+
 // linear heightmap index (row*Hy + col) <-> LDS tile index in the phase-plane layout
 __device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
     const int row = fdiv(g, P.Hy, P.mg_hy), col = g - row * P.Hy;
@@ -1259,6 +1261,38 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             const double top = z * P.scale_z + sr.ext_z * P.scale_z;
             if (round6_scaled(top - P.ibin_z) > 0.0) ok = false;
         }
+        // Stability proxy (irbpp_config::stability; not part of the reference's no-physics path): the item rests on
+        // the bottom cells whose gap to the heightmap is within half a height level of the drop height; it is rated
+        // stable iff its centre of mass lies inside the octagonal hull (8 support directions) of those cells.
+        bool stable = false;
+        if (P.stability != 0 && ok) {
+            int* sup = L.redi + 20;                                   // support function of the contact cells, 8 directions
+            if (tid < 8) sup[tid] = -0x40000000;
+            __syncthreads();
+            const Cell* cells = T.bcell + sr.ob;
+            const double* h0 = L.hm + lx * P.Ay + ly;
+            const double tol = 0.5 * P.res_z;
+            int m8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) m8[k] = -0x40000000;
+            for (int e = tid; e < sr.nb; e += BLOCK) {
+                if (h0[cells[e].off] - cells[e].v >= z - tol) {
+                    const int ci = fdiv(cells[e].pad, sr.fy, div_magic_dev(sr.fy)), cj = cells[e].pad - ci * sr.fy;
+                    m8[0] = max(m8[0], ci + 1); m8[1] = max(m8[1], -ci); m8[2] = max(m8[2], cj + 1); m8[3] = max(m8[3], -cj);
+                    m8[4] = max(m8[4], ci + cj + 2); m8[5] = max(m8[5], -(ci + cj));
+                    m8[6] = max(m8[6], ci + 1 - cj); m8[7] = max(m8[7], cj + 1 - ci);
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (m8[k] > -0x40000000) atomicMax(&sup[k], m8[k]);
+            __syncthreads();
+            const double cx = sr.com_x, cy = sr.com_y;
+            stable = cx <= sup[0] && -cx <= sup[1] && cy <= sup[2] && -cy <= sup[3] && cx + cy <= sup[4] &&
+                     -(cx + cy) <= sup[5] && cx - cy <= sup[6] && cy - cx <= sup[7];
+            __syncthreads();
+            if (P.stability == 2 && !stable) ok = false;
+        }
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
             const Cell* cells = T.tcell + sr.ot;
@@ -1300,11 +1334,13 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 if (ka->io.ratio) ka->io.ratio[b] = -1.0;
                 if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
                 if (ka->io.ep_len) ka->io.ep_len[b] = epl;
+                if (ka->io.stable) ka->io.stable[b] = stable ? 1 : 0;
             } else {
                 const int counter = ps->item_idx;                    // info (binPhy.py:306-309)
                 const double ratio = ps->ratio_acc / P.bin_vol;      // get_ratio (:149-153)
                 const double epr = ps->ep_reward + 0.0;
                 const int epl = ps->ep_len + 1;
+                if (ka->io.stable) ka->io.stable[b] = 0;
                 if (ka->io.reward) ka->io.reward[b] = 0.0;
                 if (ka->io.done) ka->io.done[b] = 1;
                 if (ka->io.counter) ka->io.counter[b] = counter;

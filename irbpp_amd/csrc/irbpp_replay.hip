@@ -1,0 +1,95 @@
+// irbpp_replay.hip -- caller-side kernels: the sum trees of the N per-env prioritised replay
+// memories (memory.py:15-93) and the masked greedy action of Agent.act (agent.py:51-58) for all envs at once.
+// The reference walks one recursive Python tree per env on the CPU; replay.py already holds the N trees as one
+// [N][2*cap-1] float32 tensor -- these kernels replace its chains of small torch kernels (~80 launches for a
+// sample) by one launch each.  float32 arithmetic in the reference's order: node = left + right, descent by
+// `value <= left ? left : (value - left, right)`.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+
+namespace irbpp {
+
+// SegmentTree.find / _retrieve (memory.py:72-86): one thread per (env, draw).
+extern "C" __global__ void __launch_bounds__(256)
+irbpp_sumtree_find_kernel(const float* __restrict__ tree, int n_env, int cap, const float* __restrict__ values, int b,
+                          float* __restrict__ prob, int64_t* __restrict__ data_idx, int64_t* __restrict__ tree_idx) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_env * b) return;
+    const float* row = tree + (size_t)(t / b) * (2 * cap - 1);
+    const int len = 2 * cap - 1;
+    int idx = 0;
+    float v = values[t];
+    for (;;) {
+        const int left = 2 * idx + 1;
+        if (left >= len) break;                          // a leaf
+        const float lv = row[left];
+        if (v <= lv) idx = left;
+        else { v = v - lv; idx = left + 1; }
+    }
+    prob[t] = row[idx];
+    data_idx[t] = idx - (cap - 1);
+    tree_idx[t] = idx;
+}
+
+// SegmentTree.update (memory.py:55-58) for b leaves per env, applied in list order (a leaf listed twice keeps its
+// last value, as in the reference's sequential loop), then every ancestor recomputed as left + right from its
+// final children -- which is what the sequence of _propagate calls leaves behind.  One wave per env, the tree
+// row staged in LDS; rows longer than the LDS buffer take the host-side path.
+constexpr int SUMTREE_LDS = 16384;                       // floats: capacities up to 8192 transitions per env
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_sumtree_update_kernel(float* __restrict__ tree, float* __restrict__ maxp, int cap, const int64_t* __restrict__ tree_idx,
+                            const float* __restrict__ prio, int b, const uint8_t* __restrict__ row_mask) {
+    __shared__ float row[SUMTREE_LDS];
+    const int env = blockIdx.x, lane = threadIdx.x;
+    if (row_mask && !row_mask[env]) return;              // append() of a subset of the envs
+    const int len = 2 * cap - 1;
+    float* g = tree + (size_t)env * len;
+    for (int i = lane; i < len; i += 64) row[i] = g[i];
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+        float m = maxp[env];
+        for (int j = 0; j < b; ++j) {
+            const float v = prio[(size_t)env * b + j];
+            row[tree_idx[(size_t)env * b + j]] = v;
+            m = fmaxf(m, v);                             // self.max = max(value, self.max)
+        }
+        maxp[env] = m;
+    }
+    __builtin_amdgcn_wave_barrier();
+    // internal nodes are 0 .. cap-2; depth d occupies [2^d - 1, 2^(d+1) - 1): bottom-up, one depth at a time
+    int depth = 0;
+    while ((2 << depth) - 1 <= cap - 2) ++depth;
+    for (int d = depth; d >= 0; --d) {
+        const int lo = (1 << d) - 1, hi = (2 << d) - 1 < cap - 1 ? (2 << d) - 1 : cap - 1;
+        for (int i = lo + lane; i < hi; i += 64) row[i] = row[2 * i + 1] + row[2 * i + 2];
+        __builtin_amdgcn_wave_barrier();
+    }
+    for (int i = lane; i < len; i += 64) g[i] = row[i];
+}
+
+// Agent.act (agent.py:51-58) after the network: sum_q[(1 - mask).bool()] = -inf; argmax(1), with the mask read
+// straight from the observation (get_mask_from_state, tools.py:298-299: column 4 of the [S][5] candidate block).
+// One wave per env; the first maximum wins.
+extern "C" __global__ void __launch_bounds__(256)
+irbpp_masked_argmax_kernel(const float* __restrict__ q, int q_stride, const float* __restrict__ obs, int obs_stride, int s_rows,
+                           int n_env, int64_t* __restrict__ action) {
+    const int env = (blockIdx.x * 256 + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (env >= n_env) return;
+    const float* qr = q + (size_t)env * q_stride;
+    const float* c = obs + (size_t)env * obs_stride;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = lane; i < s_rows; i += 64) {
+        const float v = c[i * 5 + 4] != 0.0f ? qr[i] : -INFINITY;
+        if (v > best || (v == best && i < bi)) { best = v; bi = i; }       // all -inf: the lowest index, like torch.argmax
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oi = __shfl_xor(bi, o);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) action[env] = bi;
+}
+
+}  // namespace irbpp

@@ -12,20 +12,39 @@ device tensors and every operation handles all environments at once:
 Semantics follow memory.py line by line (cited below): cyclic buffer + sum tree per env with
 float32 node sums, new transitions enter with the env's maximum priority, stratified sampling
 with the reference's validity test, n-step returns that blank everything after a terminal
-transition, importance weights normalised per env.  Nothing here needs the HIP library; tensors
-live wherever ``device`` says, so the CPU tests run the same code.
+transition, importance weights normalised per env.  On a HIP device the three sequential pieces -- the tree
+descent of ``find``, the leaf-to-root update, and the masked greedy action of ``Agent.act`` -- are one kernel
+launch each (csrc/irbpp_replay.hip through the C ABI); on the CPU (the CPU tests) the same results come from
+the torch formulation kept below, which is also the fallback for capacities beyond the kernel's LDS row.
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Optional, Tuple
 
 import torch
 
 
+def _hip_lib(device: torch.device):
+    """The HIP library if ``device`` is a HIP device (raises like every product path if it is missing)."""
+    if device.type != "cuda":
+        return None
+    from . import _lib
+    return _lib.load()
+
+
+def _p(t: Optional[torch.Tensor]):
+    return C.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
 class VectorReplayMemory(object):
     def __init__(self, num_envs: int, capacity: int, obs_len: int, *, discount: float = 0.99, multi_step: int = 3,
                  priority_weight: float = 0.4, priority_exponent: float = 0.5, device="cpu",
-                 state_dtype=torch.float32):
+                 state_dtype=torch.float32, use_hip: Optional[bool] = None):
         """``capacity`` is per environment (main.py:62: memory_capacity / num_processes)."""
         self.N, self.capacity, self.obs_len = int(num_envs), int(capacity), int(obs_len)
         self.device = torch.device(device)
@@ -47,11 +66,33 @@ class VectorReplayMemory(object):
         self.n_step_scaling = torch.tensor([self.discount ** i for i in range(self.n)], dtype=torch.float32, device=d)
         self._rows = torch.arange(N, device=d)
         self._depth = max(1, (2 * cap - 1).bit_length())                 # >= height of the implicit tree
+        # HIP kernels for find / update (one launch each) where the tree row fits their LDS buffer
+        self._lib = _hip_lib(self.device) if use_hip in (None, True) else None
+        if use_hip and self._lib is None:
+            raise RuntimeError("use_hip=True needs a HIP device")
+        if self._lib is not None and 2 * cap - 1 > 16384:
+            self._lib = None
 
     # ------------------------------------------------------------------ sum tree ------------
     def _set_leaves(self, rows: torch.Tensor, tree_idx: torch.Tensor, value: torch.Tensor) -> None:
         """SegmentTree.update (memory.py:55-58) for one leaf per listed env: set, then recompute
         every ancestor as left + right in float32 (``_propagate``, :47-52)."""
+        if self._lib is not None:
+            from . import _lib
+            N = self.N
+            mask = None
+            if rows.numel() != N:                                  # a subset of the envs: full-length arguments + mask
+                mask = torch.zeros((N,), dtype=torch.uint8, device=self.device)
+                mask[rows] = 1
+                ti = torch.zeros((N,), dtype=torch.int64, device=self.device)
+                ti[rows] = tree_idx
+                va = torch.zeros((N,), dtype=torch.float32, device=self.device)
+                va[rows] = value
+                tree_idx, value = ti, va
+            _lib.check(self._lib.irbpp_sumtree_update(_p(self.sum_tree), _p(self.max), N, self.capacity,
+                                                      _p(tree_idx.contiguous()), _p(value.to(torch.float32).contiguous()), 1,
+                                                      _p(mask), _stream(self.device)), "irbpp_sumtree_update")
+            return
         self.sum_tree[rows, tree_idx] = value
         self.max[rows] = torch.maximum(self.max[rows], value)
         cap = self.capacity
@@ -78,6 +119,15 @@ class VectorReplayMemory(object):
         """SegmentTree.find / _retrieve (memory.py:72-86) for ``values[N, B]``:
         -> (priority, data index, tree index), each [N, B]."""
         N, B = values.shape
+        if self._lib is not None:
+            from . import _lib
+            v = values.to(device=self.device, dtype=torch.float32).contiguous()
+            prob = torch.empty((N, B), dtype=torch.float32, device=self.device)
+            data_idx = torch.empty((N, B), dtype=torch.int64, device=self.device)
+            tree_idx = torch.empty((N, B), dtype=torch.int64, device=self.device)
+            _lib.check(self._lib.irbpp_sumtree_find(_p(self.sum_tree), N, self.capacity, _p(v), B, _p(prob), _p(data_idx),
+                                                    _p(tree_idx), _stream(self.device)), "irbpp_sumtree_find")
+            return prob, data_idx, tree_idx
         rows = self._rows[:, None].expand(N, B)
         idx = torch.zeros((N, B), dtype=torch.int64, device=self.device)
         v = values.to(torch.float32).clone()
@@ -191,6 +241,12 @@ class VectorReplayMemory(object):
         pr = priorities.to(self.device, torch.float32).reshape(N, B)
         if not powered:
             pr = torch.pow(pr, self.priority_exponent)
+        if self._lib is not None:                                  # all B leaves of every env in one launch
+            from . import _lib
+            _lib.check(self._lib.irbpp_sumtree_update(_p(self.sum_tree), _p(self.max), N, self.capacity,
+                                                      _p(tree_idxs.to(self.device).contiguous()), _p(pr.contiguous()), B, _p(None),
+                                                      _stream(self.device)), "irbpp_sumtree_update")
+            return
         for j in range(B):
             self._set_leaves(self._rows, tree_idxs[:, j].to(self.device), pr[:, j])
 
@@ -206,6 +262,22 @@ def mask_from_state(state: torch.Tensor, selected_action: int) -> torch.Tensor:
     """get_mask_from_state (tools.py:283-300) for the candidate-selection layout: column 4 of the
     [S, 5] block is the validity flag of each candidate."""
     return state[:, :selected_action * 5].reshape(state.shape[0], selected_action, 5)[:, :, -1]
+
+
+def masked_greedy_action(q: torch.Tensor, state: torch.Tensor, selected_action: int) -> torch.Tensor:
+    """The tail of Agent.act (agent.py:55-58): ``q[(1 - mask).bool()] = -inf; q.argmax(1)`` with the mask taken from
+    the observation (get_mask_from_state).  On a HIP device one kernel reads the flags straight from ``state``."""
+    lib = _hip_lib(q.device)
+    if lib is None:
+        masked = q.masked_fill(mask_from_state(state, selected_action) == 0, float("-inf"))
+        return masked.argmax(1)
+    from . import _lib
+    q = q.to(torch.float32).contiguous()
+    state = state.contiguous()
+    out = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)
+    _lib.check(lib.irbpp_masked_argmax(_p(q), q.stride(0), _p(state), state.stride(0), int(selected_action), q.shape[0],
+                                       _p(out), _stream(q.device)), "irbpp_masked_argmax")
+    return out
 
 
 def actor_step(envs, policy, memory: VectorReplayMemory, state: torch.Tensor, reward_clip: float = 0.0):

@@ -51,7 +51,7 @@ class GpuPackingEnv(object):
                  resolutionA: float = 0.02, resolutionH: float = 0.01, resolutionZ: float = 0.01,
                  bin_dimension=BIN_DIMENSION, selectedAction: int = 500, bufferSize: int = 1,
                  scale_z: float = 100.0, traj_start: int = 1, global_offset: int = 0,
-                 global_bins: Optional[int] = None, device="cuda:0"):
+                 global_bins: Optional[int] = None, device="cuda:0", stability: int = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("GpuPackingEnv needs a HIP device; irbpp_amd has no CPU fallback")
@@ -70,7 +70,7 @@ class GpuPackingEnv(object):
             resolution_a=resolutionA, resolution_h=resolutionH, resolution_z=resolutionZ,
             bin=(C.c_double * 3)(*bin_r), scale_z=scale_z, traj_start=traj_start,
             global_offset=global_offset, global_bins=self.num_bins if global_bins is None else global_bins,
-            device=dev_index, reserved=0)
+            device=dev_index, stability=int(stability))
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _lib.check(self.lib.irbpp_create(C.byref(cfg), C.byref(self._h)), "irbpp_create")
@@ -87,17 +87,19 @@ class GpuPackingEnv(object):
                    "irbpp_load_sequences")
         # ONE contiguous block for the small per-step outputs and the error word -> one pinned D2H copy
         n = self.num_bins
-        off_err = (33 * n + 3) & ~3
+        off_err = (34 * n + 3) & ~3
         self._out = torch.zeros((off_err + 4,), dtype=torch.uint8, device=self.device)
         self._out_host = torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True)
         self._out_f64 = self._out[:24 * n].view(torch.float64).view(3, n)           # reward, ratio, ep_reward
         self._out_i32 = self._out[24 * n:32 * n].view(torch.int32).view(2, n)       # counter, ep_len
         self._out_done = self._out[32 * n:33 * n]
+        self._out_stable = self._out[33 * n:34 * n]           # stability proxy verdict (stability >= 1)
         self._out_err = self._out[off_err:off_err + 4].view(torch.int32)
         self._step_out = _lib.IrbppStepOut(
             reward_dev=self._out_f64[0].data_ptr(), ratio_dev=self._out_f64[1].data_ptr(),
             ep_reward_dev=self._out_f64[2].data_ptr(), counter_dev=self._out_i32[0].data_ptr(),
-            ep_len_dev=self._out_i32[1].data_ptr(), done_dev=self._out_done.data_ptr(), err_dev=self._out_err.data_ptr())
+            ep_len_dev=self._out_i32[1].data_ptr(), done_dev=self._out_done.data_ptr(), stable_dev=self._out_stable.data_ptr(),
+            err_dev=self._out_err.data_ptr())
 
     # -- set-up ------------------------------------------------------------------------------
     def _load_shapes(self, shapes: ShapeSet):
@@ -261,7 +263,7 @@ class GpuPackingEnv(object):
         f64 = h[:24 * n].view(np.float64).reshape(3, n)
         i32 = h[24 * n:32 * n].view(np.int32).reshape(2, n)
         return dict(reward=f64[0].copy(), ratio=f64[1].copy(), ep_reward=f64[2].copy(), counter=i32[0].copy(),
-                    ep_len=i32[1].copy(), done=h[32 * n:33 * n].astype(bool))
+                    ep_len=i32[1].copy(), done=h[32 * n:33 * n].astype(bool), stable=h[33 * n:34 * n].astype(bool))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:

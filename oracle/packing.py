@@ -97,7 +97,9 @@ class PackingGame(object):
 
     def __init__(self, shapes, sequences, resolutionA=0.02, resolutionH=0.01, resolutionZ=0.01,
                  bin_dimension=(0.32, 0.32, 0.30), selectedAction=500, bufferSize=1,
-                 scale=(100, 100, 100), first_traj=1, traj_stride=1):
+                 scale=(100, 100, 100), first_traj=1, traj_stride=1, stability=0):
+        self.stability = stability           # the stability proxy (oracle/stability.py); 0 = the reference's no-physics path
+        self.last_stable = False
         self.resolutionAct = resolutionA
         self.resolutionH = resolutionH
         self.bin_dimension = np.round(np.asarray(bin_dimension, dtype=np.float64), decimals=6)  # arguments.py:115
@@ -226,6 +228,15 @@ class PackingGame(object):
         height = self.space.posZmap[rotIdx, coordinate[0], coordinate[1]]
         if success:
             success, sim_suc = self.simulateHeight(rotIdx, height)
+        self.last_stable = False
+        if success and self.stability:
+            from .stability import placement_is_stable
+            T, B, maskH, maskB = self.shapes.tables[self.next_item_ID][rotIdx]
+            X, Y = coordinate[0] * self.space.stepSize, coordinate[1] * self.space.stepSize
+            window = self.space.heightmapC[X:X + T.shape[0], Y:Y + T.shape[1]]
+            self.last_stable = placement_is_stable(window, T, B, maskH, maskB, height, self.heightResolution)
+            if self.stability == 2 and not self.last_stable:
+                success = False
         self.packed.append([self.next_item_ID, int(rotIdx), int(coordinate[0]), int(coordinate[1]), float(height)])
 
         if not success:

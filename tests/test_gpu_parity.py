@@ -572,7 +572,7 @@ def test_abi_rejects_calls_out_of_order():
     lib = _lib.load()
     cfg = _lib.IrbppConfig(num_bins=2, n_rot=2, selected=500, buffer_size=1, resolution_a=0.02, resolution_h=0.01,
                            resolution_z=0.01, bin=(C.c_double * 3)(0.32, 0.32, 0.3), scale_z=100.0, traj_start=1,
-                           global_offset=0, global_bins=2, device=0, reserved=0)
+                           global_offset=0, global_bins=2, device=0, stability=0)
     h = C.c_void_p()
     assert lib.irbpp_create(C.byref(cfg), C.byref(h)) == 0
     obs = torch.zeros((2, 3533), dtype=torch.float32, device=DEV)
@@ -688,3 +688,39 @@ def test_bench_gpus2_spawns_two_real_ranks():
         obs, _, _ = one.step(one.policy_minz(obs))
     assert float(one.episode_totals()[0].item()) == out["episodes"]["finished_since_reset"]
     one.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_stability_proxy_matches_its_specification(mode):
+    """irbpp_config::stability -- the static support test that stands in for the rigid-body settling the path
+    leaves out (Interface.py:271-310).  Not reference behaviour: its specification is oracle/stability.py.  Mode 1
+    only reports a verdict per accepted placement (observations identical to the plain path), mode 2 also refuses an
+    unstable placement, which ends the episode."""
+    checked = unstable = 0
+    for sh, seqs in ((synthetic.general_shapes(n_shapes=24, n_rot=8, seed=1), synthetic.make_sequences(24, 64, 60, seed=9)),
+                     (synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0), synthetic.make_sequences(24, 64, 150, seed=5))):
+        n = 6
+        genv = GpuVecEnv(sh, seqs, n, device=DEV, stability=mode)
+        oenv = OracleVecEnv(n, sh, seqs, stability=mode)
+        plain = OracleVecEnv(n, sh, seqs) if mode == 1 else None
+        gobs = genv.reset()
+        np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oenv.reset()))
+        if plain:
+            plain.reset()
+        for t in range(40):
+            act = genv.env.policy_minz(gobs).cpu().numpy()
+            gobs, grew, gdone, ginfo = genv.step(act)
+            oobs, orew, odone, _ = oenv.step(act)
+            np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs), err_msg=f"step {t}")
+            np.testing.assert_array_equal(gdone, odone)
+            stable = genv.env.step_info_host()["stable"]
+            for i in range(n):
+                want = oenv.envs[i].last_stable and not odone[i]
+                assert bool(stable[i]) == bool(want), (t, i)
+                checked += 1
+                unstable += int(not odone[i] and not want)
+            if plain:                                         # mode 1 changes nothing but the extra output
+                pobs, _, pdone, _ = plain.step(act)
+                np.testing.assert_array_equal(_f32(oobs), _f32(pobs))
+        genv.close()
+    assert checked > 300 and (mode == 2 or unstable > 5)      # the irregular solids do produce unstable placements

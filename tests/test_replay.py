@@ -178,3 +178,60 @@ def test_actor_step_fills_the_memory_from_the_device_env():
     assert tuple(batch[1].shape) == (128, env.obs_len) and bool(torch.isfinite(batch[6]).all())
     mem.update_priorities(batch[0], torch.rand(128, device="cuda:0") + 0.1)
     env.check_device_error()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capacity,n_step,seed", [(8, 1, 0), (13, 2, 1), (64, 3, 2)])
+def test_hip_sum_tree_kernels_equal_the_torch_formulation(capacity, n_step, seed):
+    """csrc/irbpp_replay.hip (one launch per find / update) against the torch formulation of the same memory on the
+    same device, random streams with partial appends, duplicate leaves in update_priorities and self-drawn samples:
+    trees, maxima, sampled indices and batches bit-identical."""
+    rng = np.random.RandomState(seed)
+    n_envs, obs_len, B = 33, 5, 4
+    hip = VectorReplayMemory(n_envs, capacity, obs_len, multi_step=n_step, device="cuda:0")
+    ref = VectorReplayMemory(n_envs, capacity, obs_len, multi_step=n_step, device="cuda:0", use_hip=False)
+    assert hip._lib is not None and ref._lib is None
+    for t in range(4 * capacity):
+        state = torch.from_numpy(rng.uniform(0, 0.3, size=(n_envs, obs_len)).astype(np.float32)).cuda()
+        action = torch.from_numpy(rng.randint(0, 500, size=n_envs)).cuda()
+        reward = torch.from_numpy(rng.uniform(0, 1, size=n_envs).astype(np.float32)).cuda()
+        terminal = torch.from_numpy(rng.rand(n_envs) < 0.2).cuda()
+        valid = torch.from_numpy(rng.rand(n_envs) < (1.0 if t % 3 else 0.7)).cuda()
+        for m in (hip, ref):
+            m.append(state, action, reward, terminal, valid)
+        assert torch.equal(hip.sum_tree, ref.sum_tree) and torch.equal(hip.max, ref.max)
+        if t % 5 == 4 and bool(ref.full.all()):
+            vals = (torch.rand((n_envs, B), device="cuda:0") * ref.total()[:, None]).clamp(min=1e-6)
+            for a, b in zip(hip.find(vals), ref.find(vals)):
+                assert torch.equal(a, b)
+            idx = ref.find(vals)[2]
+            idx[:, 1] = idx[:, 0]                                        # a leaf listed twice: the last value wins
+            pr = torch.from_numpy(rng.uniform(0.2, 2.0, size=(n_envs, B)).astype(np.float32)).cuda()
+            for m in (hip, ref):
+                m.update_priorities(idx, pr, powered=True)
+            assert torch.equal(hip.sum_tree, ref.sum_tree) and torch.equal(hip.max, ref.max)
+
+
+@pytest.mark.gpu
+def test_masked_greedy_action_is_agent_act():
+    """agent.py:55-58 with get_mask_from_state (tools.py:298-299): -inf where the candidate flag is 0, argmax."""
+    from irbpp_amd.replay import masked_greedy_action
+    rng = np.random.RandomState(3)
+    n, S = 257, 500
+    state = np.zeros((n, 5 * S + 9 + 1024), dtype=np.float32)
+    flags = rng.rand(n, S) < 0.3
+    flags[5] = False                                                  # no valid candidate at all
+    flags[6] = True
+    state[:, :5 * S].reshape(n, S, 5)[:, :, 4] = flags
+    q = rng.randn(n, S).astype(np.float32)
+    q[7, 10] = q[7, 400] = 9.0                                        # a tie: the first maximum
+    flags[7, [10, 400]] = True
+    state[7, :5 * S].reshape(S, 5)[:, 4] = flags[7]
+    got = masked_greedy_action(torch.from_numpy(q).cuda(), torch.from_numpy(state).cuda(), S).cpu().numpy()
+    sum_q = torch.from_numpy(q).clone()
+    sum_q[(1 - mask_from_state(torch.from_numpy(state), S)).bool()] = -float("inf")       # the reference's two lines
+    want = sum_q.argmax(1).numpy()
+    np.testing.assert_array_equal(got, want)
+    assert got[5] == 0 and got[7] == 10
+    cpu = masked_greedy_action(torch.from_numpy(q), torch.from_numpy(state), S).numpy()   # torch formulation (CPU)
+    np.testing.assert_array_equal(cpu, want)
