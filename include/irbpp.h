@@ -202,6 +202,21 @@ int irbpp_sumtree_find(const float* tree_dev, int32_t n_env, int32_t capacity, c
  * caller then keeps its own path). */
 int irbpp_sumtree_update(float* tree_dev, float* max_dev, int32_t n_env, int32_t capacity, const int64_t* tree_idx_dev,
                          const float* priority_dev, int32_t leaves, const uint8_t* env_mask_dev, void* stream);
+/* The replay tensors of all envs (memory.py:28-36 per env): float32 states [n_env][capacity][obs_len], int64 actions,
+ * float32 rewards, uint8 nonterminals [n_env][capacity], float32 tree [n_env][2*capacity-1], int64 index and uint8 full
+ * [n_env], float32 scaling [n_step] = discount^k. */
+typedef struct {
+    const float* states_dev; const int64_t* actions_dev; const float* rewards_dev; const uint8_t* nonterminals_dev;
+    const float* tree_dev; const int64_t* index_dev; const uint8_t* full_dev; const float* scaling_dev;
+    int32_t n_env, capacity, obs_len, n_step;
+} irbpp_replay_view;
+/* replaces: ReplayMemory._get_transition_new and the batch assembly of ReplayMemory.sample (memory.py:123-139,178-204)
+ * for `draws` (<= 256) positions per env found by irbpp_sumtree_find: outputs env-major rows [n_env*draws]:
+ * state and next state float32 [..][obs_len], action int64, n-step return, non-terminal flag, importance weight
+ * (priority_weight = beta) float32. */
+int irbpp_replay_gather(const irbpp_replay_view* view, int32_t draws, float beta, const int64_t* data_idx_dev,
+                        const float* prob_dev, float* state_dev, int64_t* action_dev, float* return_dev,
+                        float* next_state_dev, float* nonterminal_dev, float* weight_dev, void* stream);
 /* replaces: the tail of Agent.act (agent.py:55-58) with get_mask_from_state (tools.py:298-299) fused in:
  * action[e] = argmax_i q[e][i] over the candidates i whose validity flag obs[e][5*i+4] is non-zero (first maximum;
  * 0x7fffffff never occurs: with no valid candidate every q is -inf and index 0 wins, like torch.argmax). */

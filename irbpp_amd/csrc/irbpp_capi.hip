@@ -594,6 +594,21 @@ int irbpp_masked_argmax(const float* q_dev, int32_t q_stride, const float* obs_d
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
+int irbpp_replay_gather(const irbpp_replay_view* v, int32_t draws, float beta, const int64_t* data_idx_dev, const float* prob_dev,
+                        float* state_dev, int64_t* action_dev, float* return_dev, float* next_state_dev, float* nonterminal_dev,
+                        float* weight_dev, void* stream) {
+    if (!v || !v->states_dev || !v->actions_dev || !v->rewards_dev || !v->nonterminals_dev || !v->tree_dev || !v->index_dev ||
+        !v->full_dev || !v->scaling_dev || v->n_env < 1 || v->capacity < 1 || v->obs_len < 1 || v->n_step < 1 || draws < 1 ||
+        draws > 256 || !data_idx_dev || !prob_dev || !state_dev || !action_dev || !return_dev || !next_state_dev ||
+        !nonterminal_dev || !weight_dev)
+        return IRBPP_ERR_ARG;
+    hipLaunchKernelGGL(irbpp_replay_gather_kernel, dim3(v->n_env), dim3(256), 0, (hipStream_t)stream, v->states_dev, v->actions_dev,
+                       v->rewards_dev, v->nonterminals_dev, v->tree_dev, v->index_dev, v->full_dev, v->scaling_dev, v->capacity,
+                       v->obs_len, v->n_step, draws, beta, data_idx_dev, prob_dev, state_dev, action_dev, return_dev,
+                       next_state_dev, nonterminal_dev, weight_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
     env->phase_cycles = (long long*)cycles_dev;

@@ -92,4 +92,64 @@ irbpp_masked_argmax_kernel(const float* __restrict__ q, int q_stride, const floa
     if (lane == 0) action[env] = bi;
 }
 
+// ReplayMemory._get_transition_new + the batch assembly of ReplayMemory.sample (memory.py:123-139,178-204) for the
+// `b` sampled positions of every env: the n+1 consecutive transitions from data_idx (ring order), blanked from the
+// first one that follows a terminal transition; state at t, state at t+n (zeros if blanked), action at t, the n-step
+// return sum_k gamma^k r_{t+k+1}, the non-terminal flag at t+n, and the importance weights
+// (filled * prob / p_total)^-beta normalised by their maximum per env.  One workgroup per env; rows are written
+// env-major ([env * b + j]) exactly as Agent.learn concatenates the per-env batches (agent.py:69-84).
+extern "C" __global__ void __launch_bounds__(256)
+irbpp_replay_gather_kernel(const float* __restrict__ states, const int64_t* __restrict__ actions, const float* __restrict__ rewards,
+                           const uint8_t* __restrict__ nonterminals, const float* __restrict__ tree, const int64_t* __restrict__ index,
+                           const uint8_t* __restrict__ full, const float* __restrict__ scaling, int cap, int obs_len, int n_step,
+                           int b, float beta, const int64_t* __restrict__ data_idx, const float* __restrict__ prob,
+                           float* __restrict__ out_state, int64_t* __restrict__ out_action, float* __restrict__ out_return,
+                           float* __restrict__ out_next, float* __restrict__ out_nonterminal, float* __restrict__ out_weight) {
+    __shared__ float wmax[4];
+    __shared__ float wbuf[256];
+    const int env = blockIdx.x, tid = threadIdx.x;
+    const float p_total = tree[(size_t)env * (2 * cap - 1)];
+    const float filled = full[env] ? (float)cap : (float)index[env];
+    // weights: thread j < b owns sample j (b <= 256)
+    float w = 0.0f;
+    if (tid < b) {
+        const float probs = prob[(size_t)env * b + tid] / p_total;
+        w = powf(filled * probs, -beta);
+    }
+    float m = w;
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((tid & 63) == 0) wmax[tid >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+    if (tid < b) out_weight[(size_t)env * b + tid] = w / m;
+    for (int j = 0; j < b; ++j) {
+        const size_t row = (size_t)env * b + j;
+        const int d0 = (int)(data_idx[row] % cap);
+        // alive chain (wave-uniform scalar work, repeated by every thread: n_step is tiny)
+        bool alive = true;
+        float ret = 0.0f;
+        int pos = d0;
+        for (int t = 0; t < n_step; ++t) {
+            const float r = alive ? rewards[(size_t)env * cap + pos] : 0.0f;
+            ret = ret + r * scaling[t];
+            alive = alive && nonterminals[(size_t)env * cap + pos] != 0;
+            pos = pos + 1 == cap ? 0 : pos + 1;
+        }
+        const int dn = pos;                                       // (d0 + n_step) % cap
+        const float* s0 = states + ((size_t)env * cap + d0) * obs_len;
+        const float* sn = states + ((size_t)env * cap + dn) * obs_len;
+        float* o0 = out_state + row * obs_len;
+        float* o1 = out_next + row * obs_len;
+        for (int i = tid; i < obs_len; i += 256) {
+            o0[i] = s0[i];
+            o1[i] = alive ? sn[i] : 0.0f;
+        }
+        if (tid == 0) {
+            out_action[row] = actions[(size_t)env * cap + d0];
+            out_return[row] = ret;
+            out_nonterminal[row] = (alive && nonterminals[(size_t)env * cap + dn] != 0) ? 1.0f : 0.0f;
+        }
+    }
+}
+
 }  // namespace irbpp

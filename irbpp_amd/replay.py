@@ -220,6 +220,25 @@ class VectorReplayMemory(object):
                 prob, data_idx, tree_idx = torch.where(bad, p2, prob), torch.where(bad, d2, data_idx), torch.where(bad, t2, tree_idx)
             else:
                 raise RuntimeError("could not draw a valid sample from every segment; append more transitions first")
+        if self._lib is not None and self.states.dtype == torch.float32 and B <= 256:
+            # one launch: transitions, n-step returns, next states, weights -- env-major rows as below
+            from . import _lib
+            dev, NB = self.device, N * B
+            view = _lib.IrbppReplayView(
+                states_dev=self.states.data_ptr(), actions_dev=self.actions.data_ptr(), rewards_dev=self.rewards.data_ptr(),
+                nonterminals_dev=self.nonterminals.data_ptr(), tree_dev=self.sum_tree.data_ptr(), index_dev=self.index.data_ptr(),
+                full_dev=self.full.data_ptr(), scaling_dev=self.n_step_scaling.data_ptr(), n_env=N, capacity=self.capacity,
+                obs_len=self.obs_len, n_step=self.n)
+            st = torch.empty((NB, self.obs_len), dtype=torch.float32, device=dev)
+            nx = torch.empty((NB, self.obs_len), dtype=torch.float32, device=dev)
+            ac = torch.empty((NB,), dtype=torch.int64, device=dev)
+            re = torch.empty((NB,), dtype=torch.float32, device=dev)
+            nt = torch.empty((NB, 1), dtype=torch.float32, device=dev)
+            we = torch.empty((NB,), dtype=torch.float32, device=dev)
+            _lib.check(self._lib.irbpp_replay_gather(C.byref(view), B, float(self.priority_weight), _p(data_idx.contiguous()),
+                                                     _p(prob.contiguous()), _p(st), _p(ac), _p(re), _p(nx), _p(nt), _p(we),
+                                                     _stream(dev)), "irbpp_replay_gather")
+            return tree_idx, st, ac, re, nx, nt, we
         state, action, returns, next_state, nonterminal = self._transitions(data_idx)
         probs = prob / p_total[:, None]                                           # (:199)
         filled = torch.where(self.full, torch.full_like(self.index, self.capacity), self.index).to(torch.float32)

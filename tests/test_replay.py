@@ -191,6 +191,7 @@ def test_hip_sum_tree_kernels_equal_the_torch_formulation(capacity, n_step, seed
     hip = VectorReplayMemory(n_envs, capacity, obs_len, multi_step=n_step, device="cuda:0")
     ref = VectorReplayMemory(n_envs, capacity, obs_len, multi_step=n_step, device="cuda:0", use_hip=False)
     assert hip._lib is not None and ref._lib is None
+    sampled = [0]
     for t in range(4 * capacity):
         state = torch.from_numpy(rng.uniform(0, 0.3, size=(n_envs, obs_len)).astype(np.float32)).cuda()
         action = torch.from_numpy(rng.randint(0, 500, size=n_envs)).cuda()
@@ -204,12 +205,25 @@ def test_hip_sum_tree_kernels_equal_the_torch_formulation(capacity, n_step, seed
             vals = (torch.rand((n_envs, B), device="cuda:0") * ref.total()[:, None]).clamp(min=1e-6)
             for a, b in zip(hip.find(vals), ref.find(vals)):
                 assert torch.equal(a, b)
+            pr0, di0, _ = ref.find(vals)
+            ok = ref._valid(pr0, di0)
+            if bool(ok.any(dim=1).all()):                                # every env has a drawable position: use it for
+                first = ok.float().argmax(dim=1)                         # the draws the reference would reject
+                vals = torch.where(ok, vals, vals[torch.arange(n_envs, device="cuda:0"), first][:, None])
+                pr0, di0, _ = ref.find(vals)
+            if bool(ref._valid(pr0, di0).all()):                         # a drawable batch: the fused gather kernel too
+                a, b = hip.sample(B, values=vals), ref.sample(B, values=vals)
+                for k in (0, 1, 2, 4, 5):                                # tree idx, states, actions, next states, non-terminal
+                    assert torch.equal(a[k], b[k]), k
+                assert torch.allclose(a[3], b[3], rtol=0, atol=1e-6) and torch.allclose(a[6], b[6], rtol=0, atol=1e-6)
+                sampled[0] += 1
             idx = ref.find(vals)[2]
             idx[:, 1] = idx[:, 0]                                        # a leaf listed twice: the last value wins
             pr = torch.from_numpy(rng.uniform(0.2, 2.0, size=(n_envs, B)).astype(np.float32)).cuda()
             for m in (hip, ref):
                 m.update_priorities(idx, pr, powered=True)
             assert torch.equal(hip.sum_tree, ref.sum_tree) and torch.equal(hip.max, ref.max)
+    assert sampled[0] >= 1 or capacity <= 8
 
 
 @pytest.mark.gpu
