@@ -444,27 +444,28 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     int px[P], py[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) { px[u] = IRBPP_PX(pv[u]); py[u] = IRBPP_PY(pv[u]); }
-    // 1. three farthest-point hops
-    int pos[P], right_start[P];
+    // 1. three farthest-point hops.  The arg-max key carries the winner's coordinates in its low byte
+    // (dist << 16 | 255 - t << 8 | x | y << 4: t is unique inside a segment, so the byte never decides), which
+    // makes the winner's point known to every lane without another read: the next hop starts there.
+    int pos[P], right_start[P], sxy[P], fxy[P];
     bool le_eps[P];
 #pragma unroll
-    for (int u = 0; u < P; ++u) { pos[u] = 0; right_start[u] = 0; le_eps[u] = false; }
+    for (int u = 0; u < P; ++u) {
+        pos[u] = 0; right_start[u] = 0; le_eps[u] = false;
+        sxy[u] = live[u] ? (int)pts[u][0] : 0;
+        fxy[u] = sxy[u];
+    }
     for (int it = 0; it < 3; ++it) {
 #pragma unroll
-        for (int u = 0; u < P; ++u) {
-            pos[u] += right_start[u];
-            if (pos[u] >= n[u]) pos[u] -= n[u];
-            slots[u * 64 + lane] = 0u;
-        }
+        for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             if (live[u]) {
-                const int sp = pts[u][pos[u]];
                 int t = j[u] - pos[u];
                 if (t < 0) t += n[u];
-                const int dx = px[u] - IRBPP_PX(sp), dy = py[u] - IRBPP_PY(sp);
-                if (t >= 1) atomicMax(&slots[sb[u]], ((uint32_t)(dx * dx + dy * dy) << 8) | (uint32_t)(255 - t));
+                const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
+                if (t >= 1) atomicMax(&slots[sb[u]], ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]);
             }
         }
         IRBPP_WAVE_SYNC();
@@ -474,14 +475,20 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         IRBPP_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-            const int max_dist = (int)(best[u] >> 8);
-            if (max_dist > 0) right_start[u] = 255 - (int)(best[u] & 255u);
+            const int max_dist = (int)(best[u] >> 16);
+            if (max_dist > 0) { right_start[u] = 255 - (int)((best[u] >> 8) & 255u); fxy[u] = (int)(best[u] & 255u); }
             le_eps[u] = max_dist <= 1;
+            if (it < 2 && max_dist > 0) {                    // the next hop starts at the farthest point found
+                pos[u] += right_start[u];
+                if (pos[u] >= n[u]) pos[u] -= n[u];
+                sxy[u] = fxy[u];
+            }
         }
     }
-    // 2. Douglas-Peucker, all slices of one recursion level per round
+    // 2. Douglas-Peucker, all slices of one recursion level per round; every lane keeps the end points of its
+    // slice in registers, the split point's coordinates arrive with the arg-max
     bool keep[P], active[P];
-    int ss[P], se[P], s0[P];
+    int ss[P], se[P], s0[P], axy[P], bxy[P];
     bool any_active = false;
 #pragma unroll
     for (int u = 0; u < P; ++u) {
@@ -493,7 +500,8 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         if (len_a < 0) len_a += n[u];
         keep[u] = live[u] && (le_eps[u] ? j[u] == s0[u] : (j[u] == s0[u] || j[u] == far));
         active[u] = live[u] && !le_eps[u] && !keep[u];
-        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; } else { ss[u] = far; se[u] = s0[u]; }
+        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; axy[u] = sxy[u]; bxy[u] = fxy[u]; }
+        else { ss[u] = far; se[u] = s0[u]; axy[u] = fxy[u]; bxy[u] = sxy[u]; }
         any_active |= active[u];
     }
     while (__ballot(any_active) != 0ull) {
@@ -505,14 +513,13 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         for (int u = 0; u < P; ++u) {
             t[u] = dx[u] = dy[u] = 0;
             if (active[u]) {
-                const int a = pts[u][ss[u]], b = pts[u][se[u]];
-                dx[u] = IRBPP_PX(b) - IRBPP_PX(a);
-                dy[u] = IRBPP_PY(b) - IRBPP_PY(a);
+                dx[u] = IRBPP_PX(bxy[u]) - IRBPP_PX(axy[u]);
+                dy[u] = IRBPP_PY(bxy[u]) - IRBPP_PY(axy[u]);
                 t[u] = j[u] - ss[u];
                 if (t[u] < 0) t[u] += n[u];
-                int dist = (py[u] - IRBPP_PY(a)) * dx[u] - (px[u] - IRBPP_PX(a)) * dy[u];
+                int dist = (py[u] - IRBPP_PY(axy[u])) * dx[u] - (px[u] - IRBPP_PX(axy[u])) * dy[u];
                 dist = dist < 0 ? -dist : dist;
-                atomicMax(&slots[sb[u] + ss[u]], ((uint32_t)dist << 8) | (uint32_t)(255 - t[u]));
+                atomicMax(&slots[sb[u] + ss[u]], ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u]);
             }
         }
         IRBPP_WAVE_SYNC();
@@ -524,15 +531,15 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             if (active[u]) {
-                const int md = (int)(best[u] >> 8), ts = 255 - (int)(best[u] & 255u);
+                const int md = (int)(best[u] >> 16), ts = 255 - (int)((best[u] >> 8) & 255u);
                 if (md * md <= dx[u] * dx[u] + dy[u] * dy[u]) {
                     active[u] = false;                   // slice accepted: its interior points are dropped
                 } else {
                     int sp = ss[u] + ts;
                     if (sp >= n[u]) sp -= n[u];
                     if (t[u] == ts) { keep[u] = true; active[u] = false; }
-                    else if (t[u] < ts) se[u] = sp;
-                    else ss[u] = sp;
+                    else if (t[u] < ts) { se[u] = sp; bxy[u] = (int)(best[u] & 255u); }
+                    else { ss[u] = sp; axy[u] = (int)(best[u] & 255u); }
                 }
             }
             any_active |= active[u];
@@ -564,15 +571,15 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     }
 #pragma unroll
     for (int u = 0; u < P; ++u)
-        if (keep[u]) slots[sb[u] + rank[u]] = (uint32_t)j[u];
+        if (keep[u]) slots[sb[u] + rank[u]] = (uint32_t)j[u] | ((uint32_t)pv[u] << 16);   // index and point
     IRBPP_WAVE_SYNC();
-    int ja[P], jc[P];
+    int ea[P], ec[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-        ja[u] = jc[u] = 0;
+        ea[u] = ec[u] = 0;
         if (keep[u]) {
-            ja[u] = (int)slots[sb[u] + (rank[u] == 0 ? m[u] - 1 : rank[u] - 1)];
-            jc[u] = (int)slots[sb[u] + (rank[u] == m[u] - 1 ? 0 : rank[u] + 1)];
+            ea[u] = (int)slots[sb[u] + (rank[u] == 0 ? m[u] - 1 : rank[u] - 1)];
+            ec[u] = (int)slots[sb[u] + (rank[u] == m[u] - 1 ? 0 : rank[u] + 1)];
         }
     }
     bool redo[P], mark[P];
@@ -581,7 +588,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     for (int u = 0; u < P; ++u) {
         redo[u] = mark[u] = false;
         if (keep[u]) {
-            const int pa = pts[u][ja[u]], pc = pts[u][jc[u]];
+            const int pa = ea[u] >> 16, pc = ec[u] >> 16;
             const int ax = IRBPP_PX(pa), ay = IRBPP_PY(pa), cx = IRBPP_PX(pc), cy = IRBPP_PY(pc);
             if (m[u] > 2) {                              // removal test of the clean-up pass (start = A, pt = me, end = C)
                 const int ddx = cx - ax, ddy = cy - ay, ux = px[u] - ax, uy = py[u] - ay;
@@ -626,22 +633,19 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
             pending &= pending - 1ull;
             const int sb0 = __builtin_amdgcn_readlane(sb[u], l0), cnt = __builtin_amdgcn_readlane(m[u], l0);
             const int s00 = __builtin_amdgcn_readlane(s0[u], l0), rot0 = __builtin_amdgcn_readlane(rot[u], l0);
-            const unsigned long long ptr_lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned long long)pts[u], l0);
-            const unsigned long long ptr_hi = (unsigned)__builtin_amdgcn_readlane((int)((unsigned long long)pts[u] >> 32), l0);
-            const uint8_t* pts0 = (const uint8_t*)(ptr_lo | (ptr_hi << 32));
             // rank of the start point s0 in the polygon list: the list is sorted by index
             int r0 = 0;
-            for (int i = 0; i < cnt; ++i) r0 += (int)slots[sb0 + i] < s00 ? 1 : 0;
+            for (int i = 0; i < cnt; ++i) r0 += (int)(slots[sb0 + i] & 0xFFFFu) < s00 ? 1 : 0;
             if (cnt <= 64) {
                 int k = lane + r0;
                 if (k >= cnt) k -= cnt;
-                const int dv = lane < cnt ? (int)pts0[slots[sb0 + k]] : 0;
+                const int dv = lane < cnt ? (int)(slots[sb0 + k] >> 16) : 0;
                 cleanup_convex_wave(lane, dv, cnt, vmask + rot0 * 16);
             } else {
                 for (int i = lane; i < cnt; i += 64) {
                     int k = i + r0;
                     if (k >= cnt) k -= cnt;
-                    scratch[i] = pts0[slots[sb0 + k]];
+                    scratch[i] = (uint8_t)(slots[sb0 + k] >> 16);
                 }
                 IRBPP_WAVE_SYNC();
                 if (lane == 0) cleanup_convex_serial(scratch, cnt, vmask + rot0 * 16);

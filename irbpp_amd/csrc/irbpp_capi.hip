@@ -25,7 +25,7 @@ struct irbpp_env {
     Tables T;
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
-    int trace_bpw = 2;                     // bins per wave of the trace kernel: 1, 2 or 4
+    bool reorder = true;                   // launch the bins most-expensive-first (IRBPP_NO_ORDER=1: identity order, A/B tool)
     long long* phase_cycles = nullptr;
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
@@ -44,7 +44,7 @@ template <typename T>
 int dev_alloc(irbpp_env* env, T** out, size_t count) {
     void* p = nullptr;
     if (hipMalloc(&p, count * sizeof(T) > 0 ? count * sizeof(T) : sizeof(T)) != hipSuccess) return IRBPP_ERR_NOMEM;
-    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) return IRBPP_ERR_HIP;
+    if (hipMemset(p, 0, count * sizeof(T)) != hipSuccess) { hipFree(p); return IRBPP_ERR_HIP; }
     env->allocs.push_back(p);
     *out = (T*)p;
     return IRBPP_OK;
@@ -111,6 +111,16 @@ void layout_lds(Params& P) {
     P.lds_bytes = off;
 }
 
+// The dynamic-LDS limit is an attribute of the kernel on the device, not of an environment: always raise it to the
+// CU's 160 KiB, so that a later, smaller environment cannot lower it under one that is still alive.
+int raise_lds_limits() {
+    const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_hull_kernel,
+                             (const void*)irbpp_emit_kernel, (const void*)irbpp_heuristic_kernel};
+    for (const void* k : kernels)
+        if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return IRBPP_ERR_HIP;
+    return IRBPP_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -131,6 +141,7 @@ int irbpp_version(void) { return 100; }
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
+    if (cfg->num_bins > SCAN_MAX_BINS) return IRBPP_ERR_ARG;
     if (cfg->num_bins < 1 || cfg->n_rot < 1 || cfg->n_rot > 8 || cfg->selected < 1 || cfg->selected > 1024 ||
         cfg->buffer_size < 1 || cfg->buffer_size > 16)
         return IRBPP_ERR_ARG;
@@ -168,6 +179,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.AC = P.Ax * P.Ay;
     if (P.Ax > 16 || P.Ay > 16 || P.Ax < 1 || P.Ay < 1 || P.Hc > 128 * 128) { delete env; return IRBPP_ERR_ARG; }
     if (P.Hx != P.Ax * P.step || P.Hy != P.Ay * P.step) { delete env; return IRBPP_ERR_ARG; }   // phase-plane tile layout
+    // height levels are coded in 6 bits (level + 32): a placement height never exceeds bin_z, so 31 levels must cover it
+    if (floor(cfg->bin[2] / cfg->resolution_z + 1e-9) > 31.0) { delete env; return IRBPP_ERR_ARG; }
     P.traj_start = cfg->traj_start;
     P.goff = cfg->global_offset;
     P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
@@ -177,24 +190,11 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     if (const char* sp = getenv("IRBPP_SPLIT")) P.split = atoi(sp) != 0;    // 0: the fused single-kernel path (A/B tool)
-    if (const char* bw = getenv("IRBPP_TRACE_BPW")) { const int v = atoi(bw); env->trace_bpw = v == 1 || v == 2 || v == 4 ? v : 2; }
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
-    if (hipFuncSetAttribute((const void*)irbpp_env_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)irbpp_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess) {
-        delete env;
-        return IRBPP_ERR_HIP;
-    }
+    if (raise_lds_limits() != IRBPP_OK) { delete env; return IRBPP_ERR_HIP; }
     State& S = env->S;
     const size_t N = (size_t)P.N;
     int rc = IRBPP_OK;
@@ -213,9 +213,20 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_img, N * WIMG * 32);
     ALLOC(w_imgrot, N * WIMG);
     ALLOC(w_cand, N * WCAND);
-    ALLOC(w_big, N * 6 * TRACE_BIG);
+    ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)
+    ALLOC(w_cprefix, N + 1);
+    ALLOC(w_chunk, N * WCAND / TRACE_CPW + 1);
+    ALLOC(w_total, 1);
+    ALLOC(w_ncand, N);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
+    env->reorder = !P.split;               // the split pipeline's transition kernel is uniform enough: ordering buys nothing (measured)
+    if (const char* no = getenv("IRBPP_NO_ORDER")) env->reorder = atoi(no) == 0;
+    {   // identity launch order until the first ordering pass (and for good with IRBPP_NO_ORDER)
+        std::vector<int32_t> ident(N);
+        for (size_t i = 0; i < N; ++i) ident[i] = (int32_t)i;
+        if (hipMemcpy(S.order, ident.data(), N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { irbpp_destroy(env); return IRBPP_ERR_HIP; }
+    }
     *out = env;
     return IRBPP_OK;
 }
@@ -242,6 +253,10 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     const int R = P.R;
     std::vector<ShapeRot> sr((size_t)n_shapes * R);
     std::vector<Cell> bcell, tcell, blkcell;
+    for (int64_t i = 0; i < (int64_t)n_shapes * R; ++i) {               // table shapes and offsets first: the scans below trust them
+        const int64_t fx = dims[i * 2], fy = dims[i * 2 + 1];
+        if (fx < 1 || fy < 1 || fx > 4096 || fy > 4096 || offsets[i] < 0 || offsets[i] + fx * fy > pool_len) return IRBPP_ERR_ARG;
+    }
     // Block path: the largest b (multiple of step, <= 8) such that every footprint of the dataset is a
     // union of b x b tiles that are fully masked out or fully masked in with one bottom height.
     int block_b = 0;
@@ -346,13 +361,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         env->P.mb_w = mb_w;
         layout_lds(env->P);
         if (env->P.lds_bytes > 160 * 1024) return IRBPP_ERR_ARG;
-        if (hipFuncSetAttribute((const void*)irbpp_env_kernel_wide, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            P.lds_bytes) != hipSuccess ||
-        hipFuncSetAttribute((const void*)irbpp_env_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)irbpp_hull_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)irbpp_emit_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess ||
-            hipFuncSetAttribute((const void*)irbpp_heuristic_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, env->P.lds_bytes) != hipSuccess)
-            return IRBPP_ERR_HIP;
+        if (raise_lds_limits() != IRBPP_OK) return IRBPP_ERR_HIP;
     }
     env->shapes_loaded = true;
     return IRBPP_OK;
@@ -376,13 +385,17 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 }
 
 // six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
-static bool use_wide_kernel(const Params& P) { return 6 * P.lds_bytes > 150 * 1024; }
+static bool use_wide_kernel(const Params& P) {
+    static const char* force = getenv("IRBPP_WIDE");            // A/B tool: 0 / 1 forces the build
+    if (force) return atoi(force) != 0;
+    return 6 * P.lds_bytes > 150 * 1024;
+}
 
 // One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the
 // transition kernel and, in the split pipeline, trace and emit -- on one stream.
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
-    if (mode == MODE_STEP || mode == MODE_CANDS)      // most expensive bins first (see irbpp_env_kernel)
+    if ((mode == MODE_STEP || mode == MODE_CANDS) && env->reorder)      // most expensive bins first (see irbpp_env_kernel)
         hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, st, env->S.cost, env->S.order, first, n);
     if (!use_wide_kernel(env->P))
         hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
@@ -393,11 +406,12 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
     if (env->P.split && observes) {
         const int32_t* map = (mode == MODE_STEP || mode == MODE_CANDS) ? env->S.order : io.bin_list;
-        const int bpw = env->trace_bpw;
-        const dim3 tg((n + bpw - 1) / bpw);
-        if (bpw == 1) hipLaunchKernelGGL(irbpp_trace_kernel_1, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
-        else if (bpw == 2) hipLaunchKernelGGL(irbpp_trace_kernel_2, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
-        else hipLaunchKernelGGL(irbpp_trace_kernel_4, tg, dim3(64), 0, st, env->P, env->S, map, first, n, env->phase_cycles);
+        hipLaunchKernelGGL(irbpp_cand_scan_kernel, dim3(1), dim3(1024), 0, st, env->S.w_ncand, first, n, env->S.w_cprefix,
+                           env->S.w_chunk, env->S.w_total);
+        // one wave per chunk of 64 candidates; the grid covers an average of up to 64 candidates per bin and
+        // strides over the chunks beyond that
+        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, map, first, n, env->S.w_cprefix,
+                           env->S.w_chunk, env->S.w_total, env->phase_cycles);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }
@@ -429,6 +443,7 @@ int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream) {
     memset(&io, 0, sizeof(io));
     io.obs = obs_dev;
     io.obs_stride = env->P.obs_len0;
+    io.reset_next = env->was_reset ? 1 : 0;       // a later reset() moves every bin on to its next trajectory (IRcreator.py:86-92)
     const int rc = launch_env(env, io, MODE_RESET, stream);
     if (rc == IRBPP_OK) env->was_reset = true;
     return rc;

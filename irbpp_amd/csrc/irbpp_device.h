@@ -16,14 +16,18 @@ namespace irbpp {
 
 // Contour stage: every thread of the 256-thread workgroup owns CONTOUR_IPT (image, row) pairs, i.e. a
 // batch holds CONTOUR_IPT * 16 level images of 16x16 pixels (row words + column words, 16 bit each).
-constexpr int CONTOUR_IPT = 2;
+#ifndef IRBPP_CONTOUR_IPT
+#define IRBPP_CONTOUR_IPT 2
+#endif
+constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 
 // Split pipeline (Params.split): the transition kernel stops after the overlap test and hands the contour
 // work of a bin to the trace kernel through global memory -- up to WIMG level images (16 row + 16 column
-// words each) and WCAND candidate start pixels per bin; a bin that exceeds either resolves its contours
-// inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
+// words each; R * 64 are possible in theory) and WCAND candidate start pixels per bin; a bin that exceeds
+// either resolves its contours inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
 // several bins per wave, which is what keeps its lanes busy: one bin alone has ~25 borders to follow.
-constexpr int WIMG = 16 * CONTOUR_IPT, WCAND = 256, WMETA = 8;
+constexpr int WIMG = 256, WCAND = 1024, WMETA = 8;
+constexpr int SCAN_MAX_BINS = 32768;              // bins per device the one-workgroup candidate scan covers (irbpp_create refuses more)
 
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
@@ -94,8 +98,12 @@ struct State {
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
     uint16_t* w_img;       // [N][WIMG][32] level images: 16 row words then 16 column words
     uint8_t* w_imgrot;     // [N][WIMG] rotation of each level image
-    uint16_t* w_cand;      // [N][WCAND] candidate starts: image | x0<<6 | y0<<10
-    uint8_t* w_big;        // [trace waves][6 * 768] scratch of the sequential redo of a border with more than 64 points
+    uint32_t* w_cand;      // [N][WCAND] candidate starts: image | x0<<9 | y0<<13
+    uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
+    int32_t* w_cprefix;    // [N + 1] exclusive prefix of the bins' candidate counts in launch order
+    int32_t* w_chunk;      // [N * WCAND / 64 + 1] launch slot of the bin in which each chunk of 64 candidates starts
+    int32_t* w_total;      // [1] candidates of the launch
+    int32_t* w_ncand;      // [N] candidates handed over, by LAUNCH SLOT (what the scan reads, contiguously)
 };
 
 struct Params {
@@ -151,6 +159,7 @@ struct StepIO {
     int32_t heur_method;        // 1 MINZ, 2 DBLF, 3 FIRSTFIT, 4 HM (space.py:168-218)
     int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
     const int32_t* bin_list;    // MODE_RESET on a subset (reset_specific): workgroup i resets bin bin_list[i]
+    int32_t reset_next;         // MODE_RESET of all bins: 0 = episode 0 (first reset), 1 = every bin moves on to its next episode
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
 };
 

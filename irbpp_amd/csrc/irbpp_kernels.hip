@@ -687,7 +687,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
 
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
                                         int nvalid, float* obs);
-__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int item, int nvalid);
+__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid);
 
 // ---------------------------------------------------------------------------------------
 // Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
@@ -711,7 +711,9 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
     if (P.split) {                       // the trace and emit kernels take it from here
-        split_handover(P, S, L, b, item, nvalid);
+        split_handover(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
+        if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
+            io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
         return;
     }
     for (int rep = 0; rep < IRBPP_REPS(4); ++rep)
@@ -831,23 +833,40 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
 // the trace and emit kernels.  A bin with more level images or candidates than the hand-over holds
 // (speckled height fields) resolves its contours right here instead and hands over nothing to trace.
 // ---------------------------------------------------------------------------------------
-__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int item, int nvalid) {
+__device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid) {
     const int tid = threadIdx.x;
     const KernArgsPtr ka = cold_args();
     const int ntasks = contour_tasks(P, L);
     int nimg = 0, ncand = 0;
     bool here = ntasks > WIMG;
-    if (!here && ntasks > 0) {
-        contour_images(P, L, 0);
+    uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * WIMG * 32);
+    uint8_t* gr = ka->S.w_imgrot + (size_t)b * WIMG;
+    uint32_t* gc = ka->S.w_cand + (size_t)b * WCAND;
+    for (int base = 0; base < ntasks && !here; base += CONTOUR_IMGS) {       // one batch of level images at a time
+        contour_images(P, L, base);
         uint32_t my_cand[CONTOUR_IPT];
-        const int batch_total = contour_candidates(P, L, 0, ntasks, my_cand);
-        if (batch_total > WCAND) here = true;
-        else {
-            nimg = ntasks;
-            ncand = contour_list(L, my_cand, 1, 0);
+        const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
+        if (batch_total > CONTOUR_CLIST || ncand + batch_total > WCAND) { here = true; break; }
+        const int total = contour_list(L, my_cand, 1, 0);
+        const int nb = ntasks - base < CONTOUR_IMGS ? ntasks - base : CONTOUR_IMGS;
+        // rows [IMGS][16] and columns [IMGS][16] in LDS -> [image][16 rows | 16 columns] in global, as dwords
+        const uint32_t* lr = (const uint32_t*)L.img;
+        const uint32_t* lc = (const uint32_t*)(L.img + CONTOUR_IMGS * 16);
+        for (int i = tid; i < nb * 16; i += BLOCK) {
+            const int t = i >> 4, w = i & 15;
+            gi[(size_t)base * 16 + i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
         }
+        for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
+        for (int i = tid; i < total; i += BLOCK) {
+            const uint32_t e = L.clist[i];
+            gc[ncand + i] = (uint32_t)(base + (e & 63u)) | (((e >> 6) & 15u) << 9) | (((e >> 10) & 15u) << 13);
+        }
+        ncand += total;
+        nimg = base + nb;
+        __syncthreads();                             // the next batch rebuilds the images and the list
     }
     if (here) {
+        nimg = ncand = 0;
         __syncthreads();
         contour_stage(P, S, L, nullptr);             // vertex bits of isolated pixels set above are simply set again
         __syncthreads();
@@ -856,26 +875,13 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     for (int i = tid; i < P.R * P.AC; i += BLOCK) gz[i] = L.posz[i];
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
     for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
-    if (nimg > 0) {
-        // rows [IMGS][16] and columns [IMGS][16] in LDS -> [image][16 rows | 16 columns] in global, as dwords
-        uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * WIMG * 32);
-        const uint32_t* lr = (const uint32_t*)L.img;
-        const uint32_t* lc = (const uint32_t*)(L.img + CONTOUR_IMGS * 16);
-        for (int i = tid; i < nimg * 16; i += BLOCK) {
-            const int t = i >> 4, w = i & 15;
-            gi[i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
-        }
-        uint8_t* gr = ka->S.w_imgrot + (size_t)b * WIMG;
-        for (int i = tid; i < nimg; i += BLOCK) gr[i] = (uint8_t)(L.tasklist[i] >> 8);
-        uint16_t* gc = ka->S.w_cand + (size_t)b * WCAND;
-        for (int i = tid; i < ncand; i += BLOCK) gc[i] = L.clist[i];
-    }
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
         m[0] = nimg;
         m[1] = ncand;
         m[2] = nvalid;
         m[3] = item;
+        ka->S.w_ncand[slot] = ncand;
     }
 }
 
@@ -903,16 +909,14 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
 }
 
 // ---------------------------------------------------------------------------------------
-// Split pipeline, middle kernel: border following + approxPolyDP + convexity.  One bin has ~25 borders to
-// follow, a handful of them long: traced one lane each inside the bin's own workgroup, a wave spends most
-// of its instructions with a few lanes alive.  Here a workgroup is ONE wave that owns `bpw` consecutive
-// bins and treats their candidate starts as a queue:
-//   * a lane whose border is closed takes the next candidate from the queue (trace_init / trace_step are
-//     resumable), so the lanes stay busy whatever the mix of short and long borders;
-//   * closed borders wait in their lane's slot until 64 contour points are ready, then one round of
-//     approx_convex_segmented (one lane per POINT) serves them all;
-//   * no block barriers, no staging: level images are read where the transition kernel left them (L2), the
-//     vertex bits go straight to the bins' rows in global memory (one atomic OR per vertex).
+// Split pipeline, middle kernels: border following + approxPolyDP + convexity over the candidate starts of ALL
+// bins of the launch as one flat list.  One bin has ~25 borders to follow, a handful of them long: traced inside
+// the bin's own workgroup, most lanes idle, and the bins with many or long borders set the duration of the
+// launch.  Here the candidates are numbered through across the bins (irbpp_cand_scan_kernel: exclusive prefix of
+// the per-bin counts) and cut into chunks of 64: one wave per chunk, one candidate per lane, whichever bins they
+// come from -- every wave has the same amount of work.  A lane copies its level image (64 bytes) into LDS,
+// follows its border (trace_border), and the wave then runs approx_convex_segmented on all the closed borders,
+// 128 contour points per round; vertex bits go to the bins' rows in global memory with one atomic OR each.
 // ---------------------------------------------------------------------------------------
 // wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
 // row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
@@ -941,148 +945,142 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
 
 constexpr int TRACE_P = 2;                                            // contour points per lane and polygon round
 constexpr int TRACE_CAP = 64 * TRACE_P, TRACE_SLOT = TRACE_CAP + 4;   // points per border slot; 33 dwords: odd stride
+constexpr int TRACE_SHORT = 8;                                        // borders of up to this many points are approximated first
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
-constexpr int TRACE_BPW = 4;                                         // bins per wave the LDS staging is sized for
 constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
+#ifndef IRBPP_TRACE_CPW
+#define IRBPP_TRACE_CPW 64
+#endif
+constexpr int TRACE_CPW = IRBPP_TRACE_CPW;                            // candidates per wave (chunk), <= 64
 
-template <int G>                                 // bins per wave: sizes the LDS staging (images, queue)
-__device__ __forceinline__ void trace_wave(const Params& P, const State& S, const int32_t* __restrict__ map, const int first,
-                                           const int count, long long* prof) {
-    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, KSTEPS = 4, PP = TRACE_P, DP_TRIGGER = 64 * PP - 24, bpw = G;
+// Exclusive prefix of the bins' candidate counts in launch order, the total, and for every chunk of TRACE_CPW
+// candidates the launch slot of the bin its first candidate belongs to.  One workgroup; a few microseconds.
+extern "C" __global__ void __launch_bounds__(1024)
+irbpp_cand_scan_kernel(const int32_t* __restrict__ ncand, int first, int n, int32_t* __restrict__ cprefix,
+                       int32_t* __restrict__ chunk_slot, int32_t* __restrict__ total_out) {
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int MAXPER = SCAN_MAX_BINS / 1024;                     // bins per thread
+    const int per = (n + 1023) / 1024;
+    const int lo = tid * per;
+    int c[MAXPER];
+    int mine = 0;
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {                               // all loads in flight at once: one round trip
+        const int i = lo + k;
+        c[k] = (k < per && i < n) ? ncand[first + i] : 0;
+        mine += c[k];
+    }
+    const int incl = wave_inclusive_sum(mine);
+    if (lane == 63) wsum[wv] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wv; ++w) base += wsum[w];
+    int run = base + incl - mine;                                     // exclusive prefix of this thread's first bin
+#pragma unroll
+    for (int k = 0; k < MAXPER; ++k) {
+        const int i = lo + k;
+        if (k < per && i < n) {
+            cprefix[i] = run;
+            // chunks whose first candidate lies in [run, run + c)
+            for (int q = (run + TRACE_CPW - 1) / TRACE_CPW; q * TRACE_CPW < run + c[k]; ++q) chunk_slot[q] = i;
+            run += c[k];
+        }
+    }
+    if (tid == 1023) { cprefix[n] = run; *total_out = run; }          // (idle threads carry the running total through)
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count,
+                   const int32_t* __restrict__ cprefix, const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ total_ptr,
+                   long long* prof) {
+    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
     __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];            // one border per lane
-    __shared__ __attribute__((aligned(16))) uint16_t simg[G * WIMG * TRACE_ISTRIDE];   // this wave's level images
-    __shared__ uint16_t scand[G * WCAND];                                        // the queue: image (7 bit) | x0<<8 | y0<<12
-    __shared__ uint8_t srot[G * WIMG];
+    __shared__ __attribute__((aligned(16))) uint16_t simg[64 * TRACE_ISTRIDE];   // one level image per lane
+    __shared__ int spre[65];
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
     const int lane = threadIdx.x;
-    const long long t_start = prof ? (long long)clock64() : 0;
-    long long c_trace = 0, c_dp = 0, n_outer = 0, n_dp = 0;
-    // ---- the wave's bins and everything they handed over, staged in two rounds of loads
-    int bins[G], nts[G], ncs[G];
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-        const int qk = first + (int)blockIdx.x * bpw + k;
-        int b = -1;
-        if (k < bpw && qk < first + count) {
-            b = map ? map[qk] : qk;
-            if (b < 0 || b >= P.N) b = -1;
-        }
-        bins[k] = b;
-    }
-#pragma unroll
-    for (int k = 0; k < G; ++k) {
-        nts[k] = bins[k] >= 0 ? S.w_meta[(size_t)bins[k] * WMETA] : 0;
-        ncs[k] = bins[k] >= 0 ? S.w_meta[(size_t)bins[k] * WMETA + 1] : 0;
-    }
-    int total = 0;
-    {
-        uint32_t iv[G][8];                       // WIMG images x 16 dwords = 8 dwords per lane and bin
-        uint32_t cv[G][WCAND / 64];
-        uint8_t rv[G];
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            const uint32_t* gi = (const uint32_t*)(S.w_img + (size_t)(bins[k] < 0 ? 0 : bins[k]) * WIMG * 32);
-            const uint16_t* gc = S.w_cand + (size_t)(bins[k] < 0 ? 0 : bins[k]) * WCAND;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) iv[k][u] = lane + 64 * u < nts[k] * 16 ? gi[lane + 64 * u] : 0u;
-#pragma unroll
-            for (int u = 0; u < WCAND / 64; ++u) cv[k][u] = lane + 64 * u < ncs[k] ? gc[lane + 64 * u] : 0u;
-            rv[k] = lane < nts[k] ? S.w_imgrot[(size_t)bins[k] * WIMG + lane] : 0;
-        }
-#pragma unroll
-        for (int k = 0; k < G; ++k) {
-            uint32_t* li = (uint32_t*)simg;
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int i = lane + 64 * u;
-                if (i < nts[k] * 16) li[(k * WIMG + (i >> 4)) * (TRACE_ISTRIDE / 2) + (i & 15)] = iv[k][u];
-            }
-#pragma unroll
-            for (int u = 0; u < WCAND / 64; ++u) {
-                const int i = lane + 64 * u;
-                if (i < ncs[k]) {
-                    const uint32_t e = cv[k][u];
-                    scand[total + i] = (uint16_t)((k * WIMG + (e & 63u)) | (((e >> 6) & 15u) << 8) | (((e >> 10) & 15u) << 12));
+    const int total = *total_ptr;
+    for (int chunk = blockIdx.x; chunk * TRACE_CPW < total; chunk += gridDim.x) {
+        const long long t_start = prof ? (long long)clock64() : 0;
+        const int g = chunk * TRACE_CPW + lane;                       // my candidate in the flat list
+        const bool have = lane < TRACE_CPW && g < total;
+        // ---- which bin: the prefixes of the launch slots from the chunk's first one on, 64 at a time
+        int slot0 = chunk_slot[chunk], my_slot_idx = -1, my_off = 0;
+        for (int guard = 0; guard < 4096; ++guard) {
+            const int i = slot0 + lane;
+            spre[lane] = i <= count ? cprefix[i] : 0x7fffffff;
+            if (lane == 0) spre[64] = slot0 + 64 <= count ? cprefix[slot0 + 64] : 0x7fffffff;
+            IRBPP_WAVE_SYNC();
+            if (have && my_slot_idx < 0 && g < spre[64]) {            // my bin is among these 64: last prefix <= g
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (spre[mid] <= g) lo = mid; else hi = mid - 1;
                 }
+                my_slot_idx = slot0 + lo;
+                my_off = g - spre[lo];
             }
-            if (lane < nts[k]) srot[k * WIMG + lane] = rv[k];
-            total += ncs[k];
+            IRBPP_WAVE_SYNC();
+            if (__ballot(have && my_slot_idx < 0) == 0ull) break;
+            slot0 += 64;
         }
-    }
-    if (total == 0) return;
-    const long long t_staged = prof ? (long long)clock64() : 0;
-    IRBPP_WAVE_SYNC();
-    __builtin_amdgcn_s_waitcnt(0xc07f);          // lgkmcnt(0): the staging stores have landed before any lane reads them
-    int qi = 0;                                  // queue head
-    TraceState t = {};
-    bool active = false;
-    int wn = 0;                                  // points of the closed border waiting in my slot
-    int rk = 0, steps = 0;
-    const uint16_t* im = simg;
-    uint8_t* const my_slot = slots + lane * SLOT;
-    for (;;) {
-        // ---- idle lanes take the next candidates
-        {
-            const unsigned long long idle = __ballot(!active && wn == 0);
-            const int rank = __popcll(idle & ((1ull << lane) - 1ull));
-            if (((idle >> lane) & 1ull) != 0ull && qi + rank < total) {
-                const uint32_t e = scand[qi + rank];
-                const int gimg = (int)(e & 127u);
-                im = simg + gimg * TRACE_ISTRIDE;
-                int b = bins[0];
+        // ---- my candidate, its level image into LDS
+        int my_n = 0, rk = 0, x0 = 0, y0 = 0;
+        uint16_t* const im = simg + lane * TRACE_ISTRIDE;
+        uint8_t* const my_slot = slots + lane * SLOT;
+        if (have) {
+            const int b = map ? map[first + my_slot_idx] : first + my_slot_idx;
+            const uint32_t e = S.w_cand[(size_t)b * WCAND + my_off];
+            const int img = (int)(e & 511u);
+            x0 = (e >> 9) & 15u;
+            y0 = (e >> 13) & 15u;
+            rk = b * P.R + (int)S.w_imgrot[(size_t)b * WIMG + img];
+            const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * WIMG + img) * 32);
+            uint32_t* li = (uint32_t*)im;
 #pragma unroll
-                for (int k = 1; k < G; ++k) b = (gimg >> 5) == k ? bins[k] : b;
-                rk = b * P.R + (int)srot[gimg];
-                steps = 0;
-                const int r = trace_init(t, im, (e >> 8) & 15u, (e >> 12) & 15u, my_slot, CAP);
-                if (r == TRACE_RUNNING) active = true;
-                else wn = r;
-            }
-            const int nidle = __popcll(idle);
-            qi = qi + nidle < total ? qi + nidle : total;
-        }
-        if (__ballot(active || wn > 0) == 0ull) break;           // queue drained, nothing in flight
-        const long long t_a = prof ? (long long)clock64() : 0;
-        ++n_outer;
-        // ---- a few steps of every open border
-        for (int k = 0; k < KSTEPS; ++k) {
-            if (active) {
-                const int r = trace_step(t, im, im + 16, my_slot, CAP);
-                if (++steps > 4096) { atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD); active = false; }
-                else if (r != TRACE_RUNNING) {
-                    active = false;
-                    wn = r;                                       // 0: not the first pixel of its component
-                }
+            for (int q = 0; q < 4; ++q) {
+                const uint4 v = gi[q];
+                li[4 * q] = v.x; li[4 * q + 1] = v.y; li[4 * q + 2] = v.z; li[4 * q + 3] = v.w;
             }
         }
-        // ---- a border of more than 64 points (speckle): redone sequentially in this wave's global scratch
+        const long long t_staged = prof ? (long long)clock64() : 0;
+        // ---- follow the borders, all lanes in lockstep
+        if (have) {
+            const int n = trace_border(im, im + 16, x0, y0, my_slot, CAP);
+            if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+            else my_n = n;                                            // 0: not the first pixel of its component
+        }
+        // ---- a border of more than 128 points (not seen in any workload): sequential, in global scratch
         {
-            unsigned long long big = __ballot(wn > CAP);
+            unsigned long long big = __ballot(my_n > CAP);
             while (big != 0ull) {
                 const int l0 = __ffsll((long long)big) - 1;
                 big &= big - 1ull;
                 if (lane == l0) {
-                    // more than 128 points: not seen in any workload; sequential, in this wave's global scratch
-                    uint8_t* g = S.w_big + ((size_t)first / bpw + blockIdx.x) * (6 * TRACE_BIG);
+                    uint8_t* gsc = S.w_big + (size_t)blockIdx.x * (6 * TRACE_BIG);        // one scratch per wave of the grid
                     SlotMem m;
-                    m.pts = g; m.dst = g + TRACE_BIG; m.stk = (uint32_t*)(g + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
-                    const int rc = contour_vertices(im, im + 16, t.x0, t.y0, m, S.w_vmask + (size_t)rk * 16);
-                    if (rc != 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
-                    wn = 0;
+                    m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
+                    if (contour_vertices(im, im + 16, x0, y0, m, S.w_vmask + (size_t)rk * 16) != 0)
+                        atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                    my_n = 0;
                 }
             }
         }
-        const long long t_b = prof ? (long long)clock64() : 0;
-        c_trace += t_b - t_a;
-        // ---- polygon approximation: when a wave-full of points waits, or when nobody is tracing any more
+        const long long t_traced = prof ? (long long)clock64() : 0;
+        // ---- polygon approximation of the closed borders, 64 * PP contour points per round
+        // (two classes: a round lasts as many recursion levels as its deepest border needs, so the short borders
+        // -- the majority, done after two or three levels -- go first and the long ones share the later rounds)
+        int left = my_n, n_dp = 0;
+        for (int cls = 0; cls < 2; ++cls)
         for (;;) {
+            int wn = (cls == 0 ? left <= TRACE_SHORT : true) ? left : 0;
             const int incl = wave_inclusive_sum(wn), excl = incl - wn;
-            const int waiting = __builtin_amdgcn_readlane(incl, 63);
-            if (waiting == 0 || (waiting < DP_TRIGGER && __ballot(active) != 0ull)) break;
+            if (__builtin_amdgcn_readlane(incl, 63) == 0) break;
             const unsigned long long todo = __ballot(wn > 0);
-            const int first = __ffsll((long long)todo) - 1;
-            const int base = __builtin_amdgcn_readlane(excl, first);
+            const int firstl = __ffsll((long long)todo) - 1;
+            const int base = __builtin_amdgcn_readlane(excl, firstl);
             const unsigned long long sel = __ballot(wn > 0 && incl - base <= 64 * PP);
             // which border does the point at position q = u * 64 + lane belong to: border lanes drop their id at
             // the position of their first point, a running maximum over the positions spreads it
@@ -1115,32 +1113,21 @@ __device__ __forceinline__ void trace_wave(const Params& P, const State& S, cons
                 pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
             }
             approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
-            if ((sel >> lane) & 1ull) wn = 0;
+            if ((sel >> lane) & 1ull) left = 0;
             ++n_dp;
         }
-        if (prof) c_dp += (long long)clock64() - t_b;
+        if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
+            const int b0 = map ? map[first + chunk_slot[chunk]] : first + chunk_slot[chunk];
+            long long* row = prof + (size_t)b0 * PHASE_ROW;
+            const long long t_end = (long long)clock64();
+            row[11] = t_end - t_start;
+            row[12] = t_staged - t_start;
+            row[13] = t_traced - t_staged;
+            row[14] = t_end - t_traced;
+            row[15] = 1 | ((long long)n_dp << 20) | ((long long)(total - chunk * TRACE_CPW < TRACE_CPW ? total - chunk * TRACE_CPW : TRACE_CPW) << 40);
+        }
+        IRBPP_WAVE_SYNC();
     }
-    if (prof && lane == 0) {                     // tooling: this wave's account, in the row of its first bin
-        long long* row = prof + (size_t)bins[0] * PHASE_ROW;
-        row[11] = (long long)clock64() - t_start;
-        row[12] = t_staged - t_start;
-        row[13] = c_trace;
-        row[14] = c_dp;
-        row[15] = n_outer | (n_dp << 20) | ((long long)total << 40);
-    }
-}
-
-extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel_1(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
-    trace_wave<1>(P, S, map, first, count, prof);
-}
-extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel_2(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
-    trace_wave<2>(P, S, map, first, count, prof);
-}
-extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel_4(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count, long long* prof) {
-    trace_wave<4>(P, S, map, first, count, prof);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1176,7 +1163,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
-        if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
+        if (tid == 0) { atomicOr(S.err, IRBPP_DEVERR_BAD_BIN); if (P.split) cold_args()->S.w_ncand[slot] = 0; }
         return;
     }
     const long long t_begin = (long long)clock64();
@@ -1210,10 +1197,10 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
         if (tid == 0) {
             BinState* ps = S.bs + b;
-            // reset(): start over at episode 0.  reset_specific(): the env's own reset, i.e. the
-            // item creator moves on to its next trajectory (IRcreator.py:86-92) and the running
+            // The first reset() starts episode 0.  Every later reset() and reset_specific() is the env's own
+            // reset: the item creator moves on to its next trajectory (IRcreator.py:86-92) and the running
             // episode is dropped without statistics (monitor.py reset)
-            const int ep = some ? ps->episode + 1 : 0;
+            const int ep = (some || io.reset_next) ? ps->episode + 1 : 0;
             const int trow = trajectory_row(P, T, b, ep);
             for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, i);
             ps->episode = ep;

@@ -724,3 +724,24 @@ def test_stability_proxy_matches_its_specification(mode):
                 np.testing.assert_array_equal(_f32(oobs), _f32(pobs))
         genv.close()
     assert checked > 300 and (mode == 2 or unstable > 5)      # the irregular solids do produce unstable placements
+
+
+def test_second_reset_moves_on_to_the_next_trajectories():
+    """VecEnv.reset() mid-run (shmem_vec_env.py:61-68 -> PackingGame.reset -> LoadItemCreator.reset, IRcreator.py:86-92):
+    every env drops its running episode and starts its NEXT trajectory, it does not rewind to the first one."""
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    n = 5
+    genv, oenv = GpuVecEnv(sh, seqs, n, device=DEV), OracleVecEnv(n, sh, seqs)
+    gobs, oobs = genv.reset(), _f32(oenv.reset())
+    for rnd in range(3):
+        for t in range(7):
+            act = genv.env.policy_minz(gobs).cpu().numpy()
+            gobs, _, gdone, _ = genv.step(act)
+            oobs, _, odone, _ = oenv.step(act)
+            np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs))
+        first_items = gobs.cpu().numpy()[:, 5 * S].copy()
+        gobs, oobs = genv.reset(), _f32(oenv.reset())
+        np.testing.assert_array_equal(gobs.cpu().numpy(), oobs, err_msg=f"reset number {rnd + 2}")
+        assert not gobs.cpu().numpy()[:, 5 * S + 9:].any()                       # empty bins
+    genv.close()

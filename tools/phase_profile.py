@@ -48,6 +48,9 @@ out = {"workload": a.workload, "bins": a.bins,
        "total_pct": {str(q): float(np.percentile(d.sum(1), q)) for q in (50, 90, 99, 99.9, 100)},
        "mean_candidates": float(ncand.mean())}
 ex = np.concatenate(extra)
+out["split_pipeline"] = {"transition_kernel_apply": float(d[:, 0].mean()), "transition_kernel_overlap": float(d[:, 1].mean()),
+                         "transition_kernel_handover": float(np.concatenate(extra)[:, 0].mean()),
+                         "emit_kernel": float(d[:, 3].mean())}
 out["contour_detail"] = {"extract_mean": float(ex[:, 0].mean()), "extract_max": float(ex[:, 0].max()),
                          "process_mean": float(ex[:, 1].mean()), "process_max": float(ex[:, 1].max()),
                          "borders_mean": float(ex[:, 2].mean()), "borders_max": float(ex[:, 2].max()),

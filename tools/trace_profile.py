@@ -27,7 +27,7 @@ for _ in range(a.steps):
     c = c[c[:, 11] > 0]
     rows.append(c[:, 11:16].copy())
 r = np.concatenate(rows)
-outer, dp, cand = r[:, 4] & 0xFFFFF, (r[:, 4] >> 20) & 0xFFFFF, r[:, 4] >> 40
+outer, dp, cand = np.maximum(r[:, 4] & 0xFFFFF, 1), (r[:, 4] >> 20) & 0xFFFFF, r[:, 4] >> 40
 q = lambda v: {"mean": float(v.mean()), "p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": float(v.max())}
 top = np.argsort(-r[:, 0])[:6]
 print(json.dumps({"slowest_waves": [{"cycles": int(r[i, 0]), "staging": int(r[i, 1]), "trace": int(r[i, 2]), "dp": int(r[i, 3]),
