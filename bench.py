@@ -1,9 +1,9 @@
 #!/usr/bin/env python
 """bench.py -- placement-steps/s of the batched packing environment on N MI355X.
 
-One "step" = one batched transition of every bin on this rank: the scripted MINZ policy kernel
-picks an action from the device-resident observation, then the fused transition kernel applies
-it (placement, reward, termination, auto-reset) and produces the next observation.  Inputs
+One "step" = one batched transition of every bin on this rank: the transition kernel applies the
+actions (placement, reward, termination, auto-reset), the trace and emit kernels produce the next
+observation and, fused into the emit kernel, the scripted MINZ policy's action on it.  Inputs
 (shape tables, trajectories, heightmaps, observations) are resident in HBM before the timed
 region; nothing crosses PCIe inside it.
 
@@ -265,13 +265,19 @@ def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
         loc = [torch.empty((per, env.loc_obs_len), dtype=torch.float32, device=dev) for _ in range(G)]
     torch.cuda.synchronize(dev)
 
+    # The scripted MINZ policy runs fused into the emit kernel (irbpp_set_auto_policy): every observation comes
+    # with the action the policy picks on it, in act[g], which the next step() consumes.  The first actions come
+    # from the stand-alone policy kernel on the reset observation (same function, tests/test_gpu_parity.py).
+    for g in range(G):
+        if k == 1:
+            env.policy_minz_group(g, cur[g], actions_out=act[g])
+        env.groups[g].set_auto_policy(act[g])
+    torch.cuda.synchronize(dev)
+
     def one_step():
         for g in range(G):
-            src = cur[g]
             if k > 1:                          # one hierarchical placement: candidates of the
                 env.get_action_candidates_group(g, slot0, obs_out=loc[g])    # chosen buffer slot, then the placement
-                src = loc[g]
-            env.policy_minz_group(g, src, actions_out=act[g])
             env.step_group(g, act[g], obs_out=nxt[g])
             cur[g], nxt[g] = nxt[g], cur[g]
 

@@ -138,6 +138,13 @@ int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev
 int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stride,
                       int32_t* actions_dev, void* stream);
 
+/* The same policy fused into the observation: while actions_dev is set (int32[num_bins] on the device; NULL
+ * switches it off), every call that emits a location observation -- irbpp_reset, irbpp_reset_bins (listed bins
+ * only), irbpp_step of an online environment, irbpp_get_action_candidates -- also writes the action
+ * irbpp_policy_minz would pick on it, so that a scripted roll-out (tools.test with a heuristic, the benchmark)
+ * needs no policy kernel between two steps.  The buffer may be the one the next irbpp_step reads its actions from. */
+int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev);
+
 /* -- stage-level entry points (parity tests and tooling) ------------------------------- */
 
 /* Space.get_possible_position (space.py:98-129) for item_ids_dev[b] on bin b's current

@@ -98,20 +98,22 @@ __device__ inline int trace_init(TraceState& t, const uint16_t* img, int x0, int
     t.nb = nb_mask(ra, rb, rc, x0);
     // clockwise search 3,2,1,0,7,6,5 (s_end = 4: the west pixel is background) for the first neighbour
     const uint32_t rot = ((t.nb << 4) | (t.nb >> 4)) & 0xFFu;     // direction 3 -> bit 7
-    t.x0 = t.x3 = x0;
-    t.y0 = t.y3 = y0;
+    // (every field is assigned exactly once, outside any branch: stores under diverging branches end up as one
+    // store through a selected address, which keeps the whole state in scratch memory)
+    const bool iso = rot == 0u;                                    // isolated pixel
+    const int s = iso ? 0 : (3 - (7 - (31 - __clz((int)rot)))) & 7;
+    t.x0 = x0;
+    t.y0 = y0;
+    t.x3 = x0;
+    t.y3 = y0;
     t.n = 0;
-    if (rot == 0u) {                                              // isolated pixel
-        if (cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
-        t.s = t.x1 = t.y1 = t.cur_s = t.prev_s = 0;
-        return 1;
-    }
-    t.s = (3 - (7 - (31 - __clz((int)rot)))) & 7;
-    t.x1 = x0 + dir_dx(t.s);
-    t.y1 = y0 + dir_dy(t.s);
-    t.prev_s = t.s ^ 4;
-    t.cur_s = t.s;
-    return TRACE_RUNNING;
+    t.s = s;
+    t.x1 = iso ? 0 : x0 + dir_dx(s);
+    t.y1 = iso ? 0 : y0 + dir_dy(s);
+    t.prev_s = iso ? 0 : s ^ 4;
+    t.cur_s = s;
+    if (iso && cap > 0) pts[0] = (uint8_t)(x0 | (y0 << 4));
+    return iso ? 1 : TRACE_RUNNING;
 }
 
 // One step of the walk.  Returns TRACE_RUNNING, or the final number of points: 0 if the walk met a pixel

@@ -27,6 +27,7 @@ struct irbpp_env {
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
     bool reorder = true;                   // launch the bins most-expensive-first (IRBPP_NO_ORDER=1: identity order, A/B tool)
     long long* phase_cycles = nullptr;
+    int32_t* auto_actions = nullptr;       // irbpp_set_auto_policy
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
     std::vector<void*> allocs;
@@ -141,7 +142,7 @@ int irbpp_version(void) { return 100; }
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
-    if (cfg->num_bins > SCAN_MAX_BINS) return IRBPP_ERR_ARG;
+    if (cfg->num_bins > MAX_BINS) return IRBPP_ERR_ARG;
     if (cfg->num_bins < 1 || cfg->n_rot < 1 || cfg->n_rot > 8 || cfg->selected < 1 || cfg->selected > 1024 ||
         cfg->buffer_size < 1 || cfg->buffer_size > 16)
         return IRBPP_ERR_ARG;
@@ -189,7 +190,6 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
-    if (const char* sp = getenv("IRBPP_SPLIT")) P.split = atoi(sp) != 0;    // 0: the fused single-kernel path (A/B tool)
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
@@ -212,12 +212,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_meta, N * WMETA);
     ALLOC(w_img, N * WIMG * 32);
     ALLOC(w_imgrot, N * WIMG);
-    ALLOC(w_cand, N * WCAND);
+    ALLOC(w_cand, (size_t)NXCD * flat_segment_capacity(P.N));
     ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)
-    ALLOC(w_cprefix, N + 1);
-    ALLOC(w_chunk, N * WCAND / TRACE_CPW + 1);
-    ALLOC(w_total, 1);
-    ALLOC(w_ncand, N);
+    ALLOC(w_total, NXCD * XCD_STRIDE);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     env->reorder = !P.split;               // the split pipeline's transition kernel is uniform enough: ordering buys nothing (measured)
@@ -395,23 +392,21 @@ static bool use_wide_kernel(const Params& P) {
 // transition kernel and, in the split pipeline, trace and emit -- on one stream.
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
+    io.auto_action = env->auto_actions;
     if ((mode == MODE_STEP || mode == MODE_CANDS) && env->reorder)      // most expensive bins first (see irbpp_env_kernel)
         hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, st, env->S.cost, env->S.order, first, n);
-    if (!use_wide_kernel(env->P))
-        hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
-    else
-        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
-    // split pipeline: a location observation is finished by the trace kernel (one wave per `bpw` bins) and the
-    // emit kernel (one workgroup per bin), on the same stream
+    // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
+    // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
     const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
-    if (env->P.split && observes) {
-        const int32_t* map = (mode == MODE_STEP || mode == MODE_CANDS) ? env->S.order : io.bin_list;
-        hipLaunchKernelGGL(irbpp_cand_scan_kernel, dim3(1), dim3(1024), 0, st, env->S.w_ncand, first, n, env->S.w_cprefix,
-                           env->S.w_chunk, env->S.w_total);
-        // one wave per chunk of 64 candidates; the grid covers an average of up to 64 candidates per bin and
-        // strides over the chunks beyond that
-        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, map, first, n, env->S.w_cprefix,
-                           env->S.w_chunk, env->S.w_total, env->phase_cycles);
+    const bool split = env->P.split && observes;
+    StepIO io_env = io;
+    if (!use_wide_kernel(env->P))
+        hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
+    else
+        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
+    if (split) {
+        // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
+        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }
@@ -477,9 +472,10 @@ int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const
         io.ep_reward = out->ep_reward_dev;
         io.ep_len = out->ep_len_dev;
         io.stable = out->stable_dev;
+        if (env->P.K == 1) io.err_out = out->err_dev;      // online: written by the emit kernel, the step's last one
     }
     const int rc = launch_env(env, io, MODE_STEP, stream);
-    if (rc == IRBPP_OK && out && out->err_dev)
+    if (rc == IRBPP_OK && env->P.K > 1 && out && out->err_dev)      // buffered: the transition kernel is the last one and may raise bits itself
         HIP_TRY(hipMemcpyAsync(out->err_dev, env->S.err, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return rc;
 }
@@ -503,6 +499,12 @@ int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stri
     hipLaunchKernelGGL(irbpp_policy_minz_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, loc_obs_dev,
                        obs_stride, env->P.S, env->P.N, actions_dev);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev) {
+    if (!env) return IRBPP_ERR_ARG;
+    env->auto_actions = actions_dev;
+    return IRBPP_OK;
 }
 
 int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double* posz_dev, uint8_t* mask_dev, void* stream) {

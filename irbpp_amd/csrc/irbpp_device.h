@@ -27,7 +27,12 @@ constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 // either resolves its contours inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
 // several bins per wave, which is what keeps its lanes busy: one bin alone has ~25 borders to follow.
 constexpr int WIMG = 256, WCAND = 1024, WMETA = 8;
-constexpr int SCAN_MAX_BINS = 32768;              // bins per device the one-workgroup candidate scan covers (irbpp_create refuses more)
+constexpr int NXCD = 8;                            // accelerator dies of the MI355X: one flat candidate list each
+constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each
+// Capacity of one XCD's flat candidate list: a fair share of the bins' worst case plus room for an uneven share.  A
+// bin whose batch does not fit resolves its contours inside the transition kernel, so the capacity never changes results.
+__host__ __device__ constexpr int flat_segment_capacity(int n_bins) { return (n_bins / NXCD + 64) * 128; }
+constexpr int MAX_BINS = 32768;                   // bins per device: a flat-list entry has 15 bits for the bin (irbpp_create refuses more)
 
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
@@ -98,12 +103,10 @@ struct State {
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
     uint16_t* w_img;       // [N][WIMG][32] level images: 16 row words then 16 column words
     uint8_t* w_imgrot;     // [N][WIMG] rotation of each level image
-    uint32_t* w_cand;      // [N][WCAND] candidate starts: image | x0<<9 | y0<<13
+    uint32_t* w_cand;      // [NXCD][flat_segment_capacity(N)] flat lists of the launch's candidate starts, in arrival order:
+                           // bin<<16 | image<<8 | y0<<4 | x0
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
-    int32_t* w_cprefix;    // [N + 1] exclusive prefix of the bins' candidate counts in launch order
-    int32_t* w_chunk;      // [N * WCAND / 64 + 1] launch slot of the bin in which each chunk of 64 candidates starts
-    int32_t* w_total;      // [1] candidates of the launch
-    int32_t* w_ncand;      // [N] candidates handed over, by LAUNCH SLOT (what the scan reads, contiguously)
+    int32_t* w_total;      // [NXCD * XCD_STRIDE] candidates in each XCD's list (XCD-local atomicAdd in the transition kernel, zeroed by the emit kernel)
 };
 
 struct Params {
@@ -160,6 +163,9 @@ struct StepIO {
     int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
     const int32_t* bin_list;    // MODE_RESET on a subset (reset_specific): workgroup i resets bin bin_list[i]
     int32_t reset_next;         // MODE_RESET of all bins: 0 = episode 0 (first reset), 1 = every bin moves on to its next episode
+    int32_t* auto_action;       // optional [N]: the scripted MINZ policy's choice for the observation just emitted (row with the
+                                // lowest H among V == 1, first on ties; 0 if none) -- irbpp_set_auto_policy
+    int32_t* err_out;           // optional [1]: copy of the device error word, written by the emit kernel (split pipeline)
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
 };
 

@@ -710,16 +710,121 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     if (io.phase_cycles && tid == 0)
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
-    if (P.split) {                       // the trace and emit kernels take it from here
-        split_handover(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
-        if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
-            io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
-        return;
+    // the trace and emit kernels take it from here
+    split_handover(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
+    if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
+        io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
+}
+
+// ---------------------------------------------------------------------------------------
+// The `want` smallest of n <= R*AC values in (value, position) order -- np.argsort(...)[:S] with ties by
+// ascending position (binPhy.py:209-212, 217-225) -- without the n^2 ranking of everything against
+// everything: (1) radix select on the order-preserving 64-bit image of the float64 values finds the
+// want-th smallest value T in eight histogram rounds, (2) the elements below T plus the first few equal to
+// T are compacted in position order, (3) only those `want` elements are ranked against each other.
+// Element e is the candidate key(e) = rot<<16 | lx<<8 | ly with value posZValid[rot, lx, ly]; out[rank] = its key.
+// `sel` ([n] words, may be the array key() reads) and `hist` ([256] words) are LDS.  All threads call it.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long sortable_f64(double v) {
+    const unsigned long long b = (unsigned long long)__double_as_longlong(v);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+constexpr int SEL_PER_THREAD = (8 * 256 + BLOCK - 1) / BLOCK;           // R*AC <= 2048 elements
+
+template <typename KEY>
+__device__ inline void select_smallest(const Params& P, const Lds& L, int n, int want, const KEY& key, uint32_t* out,
+                                       uint32_t* sel, uint32_t* hist) {
+    const int tid = threadIdx.x;
+    auto value = [&](uint32_t k) { return L.posz[(k >> 16) * P.AC + ((k >> 8) & 255u) * P.Ay + (k & 255u)]; };
+    unsigned long long sk[SEL_PER_THREAD];
+    uint32_t ky[SEL_PER_THREAD];
+#pragma unroll
+    for (int k = 0; k < SEL_PER_THREAD; ++k) {
+        const int e = tid + k * BLOCK;
+        ky[k] = e < n ? key(e) : 0u;
+        sk[k] = e < n ? sortable_f64(value(ky[k])) : ~0ull;
     }
-    for (int rep = 0; rep < IRBPP_REPS(4); ++rep)
-    contour_stage(P, S, L, io.phase_cycles ? io.phase_cycles + (size_t)b * PHASE_ROW : nullptr);
-    stamp(io, b, 3);
-    emit_observation(P, S, io, L, b, item, nvalid, obs);
+    // (1) the want-th smallest value, one byte per round from the top
+    unsigned long long prefix = 0ull;
+    int remaining = want;
+    for (int d = 7; d >= 0; --d) {
+        hist[tid] = 0u;                                                  // BLOCK == 256 bins
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SEL_PER_THREAD; ++k) {
+            const int e = tid + k * BLOCK;
+            const bool in = e < n && (d == 7 || (sk[k] >> (8 * (d + 1))) == prefix);
+            if (in) atomicAdd(&hist[(uint32_t)(sk[k] >> (8 * d)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {                                                   // one wave scans the 256 counts
+            int c[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i] = (int)hist[tid * 4 + i]; sum += c[i]; }
+            int incl = sum;
+            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            int run = incl - sum;                                        // elements in the bins below this lane's four
+            if (run < remaining && remaining <= incl) {                  // the want-th element falls into one of my bins
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (run < remaining && remaining <= run + c[i]) { L.redi[32] = tid * 4 + i; L.redi[33] = remaining - run; }
+                    run += c[i];
+                }
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned long long)(uint32_t)L.redi[32];
+        remaining = L.redi[33];
+    }
+    // (2) compaction in position order: everything below T, and the first `remaining` elements equal to T.
+    // `sel` may be the array key() reads: chunk k only writes below the positions it has read.
+    int nsel = 0, neq = 0;
+#pragma unroll
+    for (int k = 0; k < SEL_PER_THREAD; ++k) {
+        if (k * BLOCK < n) {
+            const int e = tid + k * BLOCK;
+            const bool eq = e < n && sk[k] == prefix;
+            int teq;
+            const int eqb = block_scan_flag(eq, L.redi, teq);
+            const bool take = e < n && (sk[k] < prefix || (eq && neq + eqb < remaining));
+            int tsel;
+            const int pos = block_scan_flag(take, L.redi, tsel);
+            if (take) sel[nsel + pos] = ky[k];
+            nsel += tsel;
+            neq += teq;
+        }
+    }
+    __syncthreads();
+    // (3) rank the selected elements among themselves; the list is in position order, so ties go to the lower index.
+    // Every wave walks the whole list 64 entries at a time: lane t fetches the value of entry base + t once, the
+    // wave then broadcasts them with v_readlane -- no LDS access and no dependent loads in the counting loop.
+    constexpr int MINE = (1024 + BLOCK - 1) / BLOCK;                 // selected <= 1024 rows (irbpp_create)
+    const int lane = tid & 63;
+    double vi[MINE];
+    uint32_t si[MINE];
+    int rank[MINE];
+#pragma unroll
+    for (int m = 0; m < MINE; ++m) {
+        const int i = tid + m * BLOCK;
+        si[m] = i < want ? sel[i] : 0u;
+        vi[m] = i < want ? value(si[m]) : 0.0;
+        rank[m] = 0;
+    }
+    for (int base = 0; base < want; base += 64) {
+        const double jv = base + lane < want ? value(sel[base + lane]) : 0.0;
+        const int jlo = (int)__double2loint(jv), jhi = (int)__double2hiint(jv);
+        const int cnt = want - base < 64 ? want - base : 64;
+        for (int t = 0; t < cnt; ++t) {
+            const double vj = __hiloint2double(__builtin_amdgcn_readlane(jhi, t), __builtin_amdgcn_readlane(jlo, t));
+            const int j = base + t;
+#pragma unroll
+            for (int m = 0; m < MINE; ++m) rank[m] += (vj < vi[m] || (vj == vi[m] && j < tid + m * BLOCK)) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < MINE; ++m)
+        if (tid + m * BLOCK < want) out[rank[m]] = si[m];
+    __syncthreads();
 }
 
 // ---------------------------------------------------------------------------------------
@@ -734,6 +839,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
     uint32_t* okey = keys + R * AC;                 // [S]
+    uint32_t* hist = (uint32_t*)L.img;              // [256] counters of the radix select: the level images are done with
     int n = 0;
     {
         const int cx = fdiv(tid, Ax, P.mg_ax), cy = tid - cx * Ax;     // col-major walk: x = column (ly), y = row (lx)
@@ -754,17 +860,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         rows = keys;
     } else if (n > P.S) {
         // np.argsort(candidates[:,3])[:S] (binPhy.py:209-212), ties by ascending index
-        for (int i = tid; i < n; i += BLOCK) {
-            const uint32_t ki = keys[i];
-            const double hi = L.posz[(ki >> 16) * AC + ((ki >> 8) & 255u) * Ay + (ki & 255u)];
-            int rank = 0;
-            for (int j = 0; j < n; ++j) {
-                const uint32_t kj = keys[j];
-                const double hj = L.posz[(kj >> 16) * AC + ((kj >> 8) & 255u) * Ay + (kj & 255u)];
-                rank += (hj < hi || (hj == hi && j < i)) ? 1 : 0;
-            }
-            if (rank < P.S) okey[rank] = ki;
-        }
+        select_smallest(P, L, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist);
         nrows = P.S;
         rows = okey;
         __syncthreads();
@@ -772,28 +868,16 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         // no candidate at all: the S smallest of posZValid.reshape(-1) (binPhy.py:217-225)
         fallback = true;
         const int total_cells = R * AC;
-        int valid_before_r = 0;              // valid cells of earlier rotations
-        for (int r = 0; r < R; ++r) {
-            const int c = r * AC + tid;
-            const bool in = tid < AC;
-            const double zc = in ? L.posz[c] : 1e3;
-            const bool v = in && zc < 1e3;
-            int tot;
-            const int vbefore = block_scan_flag(v, L.redi, tot);
-            if (in) {
-                int rank;
-                if (v) {
-                    rank = 0;
-                    for (int j = 0; j < total_cells; ++j) {
-                        const double zj = L.posz[j];
-                        rank += (zj < 1e3 && (zj < zc || (zj == zc && j < c))) ? 1 : 0;
-                    }
-                } else {
-                    rank = nvalid + (c - (valid_before_r + vbefore));
-                }
-                if (rank < P.S) okey[rank] = ((uint32_t)r << 16) | ((uint32_t)X << 8) | (uint32_t)Y;
-            }
-            valid_before_r += tot;
+        const int want = total_cells < P.S ? total_cells : P.S;
+        auto cell_key = [&](int e) {
+            const int r = fdiv(e, AC, P.mg_ac), c = e - r * AC, x = fdiv(c, Ay, P.mg_ay);
+            return ((uint32_t)r << 16) | ((uint32_t)x << 8) | (uint32_t)(c - x * Ay);
+        };
+        if (nvalid == 0) {                   // nothing fits (the usual end of an episode): every value is 1e3, position order
+            for (int e = tid; e < want; e += BLOCK) okey[e] = cell_key(e);
+            __syncthreads();
+        } else {
+            select_smallest(P, L, total_cells, want, cell_key, okey, keys, hist);
         }
         nrows = total_cells < P.S ? total_cells : P.S;
         rows = okey;
@@ -824,6 +908,35 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         S.bs[b].cur_item = item;
         S.bs[b].nvalid = nvalid;
     }
+    // The scripted MINZ policy on the rows just written (irbpp_policy_minz on this observation gives the same):
+    // the row with the lowest float32 H among V == 1, first on ties.  Fallback rows all carry H = bin_z and are
+    // sorted valid-first, so the answer there is row 0 (or "none" = 0).
+    if (io.auto_action != nullptr) {
+        float best = INFINITY;
+        int bi = 0x7fffffff;
+        if (!fallback)
+            for (int i = tid; i < nrows; i += BLOCK) {
+                const uint32_t k = rows[i];
+                const float h = (float)L.posz[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];
+                if (h < best) { best = h; bi = i; }              // ascending i per thread: the first of equals stays
+            }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        __syncthreads();
+        if ((tid & 63) == 0) { ((float*)L.redi)[4 + (tid >> 6)] = best; L.redi[8 + (tid >> 6)] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < WAVES; ++w) {
+                const float ob = ((float*)L.redi)[4 + w];
+                const int oi = L.redi[8 + w];
+                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            io.auto_action[b] = bi == 0x7fffffff ? 0 : bi;
+        }
+    }
     stamp(io, b, 4);
 }
 
@@ -841,7 +954,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     bool here = ntasks > WIMG;
     uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * WIMG * 32);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * WIMG;
-    uint32_t* gc = ka->S.w_cand + (size_t)b * WCAND;
+    const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
+    const int seg_cap = flat_segment_capacity(P.N);
     for (int base = 0; base < ntasks && !here; base += CONTOUR_IMGS) {       // one batch of level images at a time
         contour_images(P, L, base);
         uint32_t my_cand[CONTOUR_IPT];
@@ -857,9 +971,26 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
             gi[(size_t)base * 16 + i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
         }
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
-        for (int i = tid; i < total; i += BLOCK) {
-            const uint32_t e = L.clist[i];
-            gc[ncand + i] = (uint32_t)(base + (e & 63u)) | (((e >> 6) & 15u) << 9) | (((e >> 10) & 15u) << 13);
+        // The candidates join a flat list (bin<<16 | image<<8 | y0<<4 | x0), one allocation per batch, in whatever
+        // order the bins arrive -- the trace kernel's results do not depend on it.  One list per XCD: the line of a
+        // counter that only the workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide
+        // counter travels between the eight L2s with every allocation (measured: +22 us per launch).
+        if (tid == 0) {
+            int at = 0;
+            if (total > 0) {
+                at = atomicAdd(ka->S.w_total + xcd * XCD_STRIDE, total);
+                if (at + total > seg_cap) at = -1;                 // this XCD's list is full: resolve the contours here
+            }
+            L.redi[11] = at;
+        }
+        __syncthreads();
+        if (L.redi[11] < 0) { here = true; break; }
+        {
+            uint32_t* flat = ka->S.w_cand + (size_t)xcd * seg_cap + L.redi[11];
+            for (int i = tid; i < total; i += BLOCK) {
+                const uint32_t e = L.clist[i];
+                flat[i] = ((uint32_t)b << 16) | ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u);
+            }
         }
         ncand += total;
         nimg = base + nb;
@@ -881,7 +1012,6 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         m[1] = ncand;
         m[2] = nvalid;
         m[3] = item;
-        ka->S.w_ncand[slot] = ncand;
     }
 }
 
@@ -896,6 +1026,11 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     const int slot = (int)blockIdx.x + io.block_off;
     const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
+    // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
+    // device error word to the step outputs: every bit of this step was raised by the transition or the trace
+    // kernel, which have completed (the emit kernel raises none).
+    if (blockIdx.x == 0 && tid < NXCD) S.w_total[tid * XCD_STRIDE] = 0;
+    if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
     const double* gz = S.w_posz + (size_t)b * P.R * P.AC;
@@ -912,8 +1047,8 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
 // Split pipeline, middle kernels: border following + approxPolyDP + convexity over the candidate starts of ALL
 // bins of the launch as one flat list.  One bin has ~25 borders to follow, a handful of them long: traced inside
 // the bin's own workgroup, most lanes idle, and the bins with many or long borders set the duration of the
-// launch.  Here the candidates are numbered through across the bins (irbpp_cand_scan_kernel: exclusive prefix of
-// the per-bin counts) and cut into chunks of 64: one wave per chunk, one candidate per lane, whichever bins they
+// launch.  Here the candidates of all bins form one flat list (every bin appends its batch with one atomicAdd on
+// the list's counter while it hands over) that is cut into chunks of 64: one wave per chunk, one candidate per lane, whichever bins they
 // come from -- every wave has the same amount of work.  A lane copies its level image (64 bytes) into LDS,
 // follows its border (trace_border), and the wave then runs approx_convex_segmented on all the closed borders,
 // 128 contour points per round; vertex bits go to the bins' rows in global memory with one atomic OR each.
@@ -953,89 +1088,44 @@ constexpr int TRACE_ISTRIDE = 34;                                    // u16 per 
 #endif
 constexpr int TRACE_CPW = IRBPP_TRACE_CPW;                            // candidates per wave (chunk), <= 64
 
-// Exclusive prefix of the bins' candidate counts in launch order, the total, and for every chunk of TRACE_CPW
-// candidates the launch slot of the bin its first candidate belongs to.  One workgroup; a few microseconds.
-extern "C" __global__ void __launch_bounds__(1024)
-irbpp_cand_scan_kernel(const int32_t* __restrict__ ncand, int first, int n, int32_t* __restrict__ cprefix,
-                       int32_t* __restrict__ chunk_slot, int32_t* __restrict__ total_out) {
-    __shared__ int wsum[16];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    constexpr int MAXPER = SCAN_MAX_BINS / 1024;                     // bins per thread
-    const int per = (n + 1023) / 1024;
-    const int lo = tid * per;
-    int c[MAXPER];
-    int mine = 0;
-#pragma unroll
-    for (int k = 0; k < MAXPER; ++k) {                               // all loads in flight at once: one round trip
-        const int i = lo + k;
-        c[k] = (k < per && i < n) ? ncand[first + i] : 0;
-        mine += c[k];
-    }
-    const int incl = wave_inclusive_sum(mine);
-    if (lane == 63) wsum[wv] = incl;
-    __syncthreads();
-    int base = 0;
-    for (int w = 0; w < wv; ++w) base += wsum[w];
-    int run = base + incl - mine;                                     // exclusive prefix of this thread's first bin
-#pragma unroll
-    for (int k = 0; k < MAXPER; ++k) {
-        const int i = lo + k;
-        if (k < per && i < n) {
-            cprefix[i] = run;
-            // chunks whose first candidate lies in [run, run + c)
-            for (int q = (run + TRACE_CPW - 1) / TRACE_CPW; q * TRACE_CPW < run + c[k]; ++q) chunk_slot[q] = i;
-            run += c[k];
-        }
-    }
-    if (tid == 1023) { cprefix[n] = run; *total_out = run; }          // (idle threads carry the running total through)
-}
-
 extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ map, const int first, const int count,
-                   const int32_t* __restrict__ cprefix, const int32_t* __restrict__ chunk_slot, const int32_t* __restrict__ total_ptr,
-                   long long* prof) {
+irbpp_trace_kernel(const Params P, const State S, long long* prof) {
     constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
     __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];            // one border per lane
     __shared__ __attribute__((aligned(16))) uint16_t simg[64 * TRACE_ISTRIDE];   // one level image per lane
-    __shared__ int spre[65];
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
     const int lane = threadIdx.x;
-    const int total = *total_ptr;
-    for (int chunk = blockIdx.x; chunk * TRACE_CPW < total; chunk += gridDim.x) {
+    // the eight lists, one after the other, cut into chunks of TRACE_CPW candidates (a list's last chunk may be short)
+    const int seg_cap = flat_segment_capacity(P.N);
+    int seg_n[NXCD], seg_first[NXCD + 1];                                    // candidates of list s, its first chunk
+    seg_first[0] = 0;
+#pragma unroll
+    for (int s = 0; s < NXCD; ++s) {
+        const int n = S.w_total[s * XCD_STRIDE];
+        seg_n[s] = n < seg_cap ? n : seg_cap;
+        seg_first[s + 1] = seg_first[s] + (seg_n[s] + TRACE_CPW - 1) / TRACE_CPW;
+    }
+    for (int chunk = blockIdx.x; chunk < seg_first[NXCD]; chunk += gridDim.x) {
         const long long t_start = prof ? (long long)clock64() : 0;
-        const int g = chunk * TRACE_CPW + lane;                       // my candidate in the flat list
-        const bool have = lane < TRACE_CPW && g < total;
-        // ---- which bin: the prefixes of the launch slots from the chunk's first one on, 64 at a time
-        int slot0 = chunk_slot[chunk], my_slot_idx = -1, my_off = 0;
-        for (int guard = 0; guard < 4096; ++guard) {
-            const int i = slot0 + lane;
-            spre[lane] = i <= count ? cprefix[i] : 0x7fffffff;
-            if (lane == 0) spre[64] = slot0 + 64 <= count ? cprefix[slot0 + 64] : 0x7fffffff;
-            IRBPP_WAVE_SYNC();
-            if (have && my_slot_idx < 0 && g < spre[64]) {            // my bin is among these 64: last prefix <= g
-                int lo = 0, hi = 63;
-                while (lo < hi) {
-                    const int mid = (lo + hi + 1) >> 1;
-                    if (spre[mid] <= g) lo = mid; else hi = mid - 1;
-                }
-                my_slot_idx = slot0 + lo;
-                my_off = g - spre[lo];
-            }
-            IRBPP_WAVE_SYNC();
-            if (__ballot(have && my_slot_idx < 0) == 0ull) break;
-            slot0 += 64;
-        }
+        int seg = 0;
+#pragma unroll
+        for (int s = 1; s < NXCD; ++s) seg += chunk >= seg_first[s] ? 1 : 0;
+        int first_chunk = 0, count = 0;
+#pragma unroll
+        for (int s = 0; s < NXCD; ++s) if (s == seg) { first_chunk = seg_first[s]; count = seg_n[s]; }
+        const int gi = (chunk - first_chunk) * TRACE_CPW + lane;              // my candidate in list `seg`
+        const bool have = lane < TRACE_CPW && gi < count;
+        const size_t g = (size_t)seg * seg_cap + gi;
         // ---- my candidate, its level image into LDS
         int my_n = 0, rk = 0, x0 = 0, y0 = 0;
         uint16_t* const im = simg + lane * TRACE_ISTRIDE;
         uint8_t* const my_slot = slots + lane * SLOT;
         if (have) {
-            const int b = map ? map[first + my_slot_idx] : first + my_slot_idx;
-            const uint32_t e = S.w_cand[(size_t)b * WCAND + my_off];
-            const int img = (int)(e & 511u);
-            x0 = (e >> 9) & 15u;
-            y0 = (e >> 13) & 15u;
+            const uint32_t e = S.w_cand[g];
+            const int b = (int)(e >> 16), img = (int)((e >> 8) & 255u);
+            x0 = e & 15u;
+            y0 = (e >> 4) & 15u;
             rk = b * P.R + (int)S.w_imgrot[(size_t)b * WIMG + img];
             const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * WIMG + img) * 32);
             uint32_t* li = (uint32_t*)im;
@@ -1117,14 +1207,14 @@ irbpp_trace_kernel(const Params P, const State S, const int32_t* __restrict__ ma
             ++n_dp;
         }
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
-            const int b0 = map ? map[first + chunk_slot[chunk]] : first + chunk_slot[chunk];
+            const int b0 = (int)(S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW] >> 16);
             long long* row = prof + (size_t)b0 * PHASE_ROW;
             const long long t_end = (long long)clock64();
             row[11] = t_end - t_start;
             row[12] = t_staged - t_start;
             row[13] = t_traced - t_staged;
             row[14] = t_end - t_traced;
-            row[15] = 1 | ((long long)n_dp << 20) | ((long long)(total - chunk * TRACE_CPW < TRACE_CPW ? total - chunk * TRACE_CPW : TRACE_CPW) << 40);
+            row[15] = 1 | ((long long)n_dp << 20) | ((long long)(count - (chunk - first_chunk) * TRACE_CPW < TRACE_CPW ? count - (chunk - first_chunk) * TRACE_CPW : TRACE_CPW) << 40);
         }
         IRBPP_WAVE_SYNC();
     }
@@ -1163,7 +1253,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
-        if (tid == 0) { atomicOr(S.err, IRBPP_DEVERR_BAD_BIN); if (P.split) cold_args()->S.w_ncand[slot] = 0; }
+        if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
         return;
     }
     const long long t_begin = (long long)clock64();

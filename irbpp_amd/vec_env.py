@@ -167,6 +167,15 @@ class GpuPackingEnv(object):
                    "irbpp_policy_minz")
         return act
 
+    def set_auto_policy(self, actions: Optional[torch.Tensor]) -> None:
+        """Fuse the scripted MINZ policy into the observation: while ``actions`` (int32[N] on the device) is set,
+        reset / reset_bins / step (online) / get_action_candidates also write the action ``policy_minz`` would pick
+        on the observation they emit; ``None`` switches it off.  The buffer may be the one passed to the next step()."""
+        if actions is not None:
+            assert actions.dtype == torch.int32 and actions.is_cuda and actions.numel() == self.num_bins and actions.is_contiguous()
+        self._auto_actions = actions                # keep the buffer alive
+        _lib.check(self.lib.irbpp_set_auto_policy(self._h, _ptr(actions)), "irbpp_set_auto_policy")
+
     # -- stage-level access (tests, tooling) ---------------------------------------------------
     def possible_position(self, item_ids: torch.Tensor):
         posz = torch.empty((self.num_bins, self.n_rot, self.Ax, self.Ay), dtype=torch.float64, device=self.device)

@@ -745,3 +745,43 @@ def test_second_reset_moves_on_to_the_next_trajectories():
         np.testing.assert_array_equal(gobs.cpu().numpy(), oobs, err_msg=f"reset number {rnd + 2}")
         assert not gobs.cpu().numpy()[:, 5 * S + 9:].any()                       # empty bins
     genv.close()
+
+
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 256, 140), ("general", 128, 60), ("blockout_k10", 64, 60)])
+def test_fused_policy_matches_policy_kernel(workload, n, steps):
+    """irbpp_set_auto_policy: the action written next to every emitted observation (reset, online step incl.
+    auto-resets, get_action_candidates; rows selected from more than S candidates and the no-candidate fallback
+    both occur in 'general') equals irbpp_policy_minz on that observation, and the error word published by the
+    step's last workgroup is the device's."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload(workload)
+    k = int(kw.get("bufferSize", 1))
+    env = GpuPackingEnv(shapes, seqs[:500], n, device=DEV, **kw)
+    auto = torch.full((n,), -7, dtype=torch.int32, device=DEV)
+    env.set_auto_policy(auto)
+    obs = env.reset()
+    slot0 = torch.zeros((n,), dtype=torch.int32, device=DEV)
+    seen_fallback = seen_sorted = 0
+    for t in range(steps):
+        if k > 1:
+            loc = env.get_action_candidates(slot0)
+        else:
+            loc = obs
+        ref = env.policy_minz(loc)
+        assert torch.equal(auto, ref), f"step {t}: fused policy differs from the policy kernel"
+        rows = loc[:, :5 * S].reshape(n, S, 5)
+        seen_fallback += int(((rows[:, :, 4] == 0).any(1)).sum())
+        seen_sorted += int((rows[:, S - 1, 4] == 1).sum())
+        obs, _, _ = env.step(ref.clone())
+        torch.cuda.synchronize()
+        assert int(env._out_err.item()) == 0
+    env.check_device_error()
+    env.set_auto_policy(None)
+    auto.fill_(-7)
+    if k == 1:
+        env.step(ref.clone())
+        torch.cuda.synchronize()
+        assert int(auto.min()) == -7 and int(auto.max()) == -7        # switched off: untouched
+    if workload == "general":
+        assert seen_fallback > 0 and seen_sorted > 0
+    env.close()

@@ -1,14 +1,14 @@
-O=gpurun_out/r2a; mkdir -p $O
+O=gpurun_out/r2d; mkdir -p $O
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
-tail -4 $O/pytest_gpu.txt
-timeout 600 python bench.py > $O/bench_default.json 2>$O/bench_default.err; tail -c 2500 $O/bench_default.json
-for wl in general abc_fine blockout_r8 cube blockout_k10; do
-timeout 600 python bench.py --no-cpu-baseline --no-extra --workload $wl > $O/bench_$wl.json 2>/dev/null
+tail -6 $O/pytest_gpu.txt
+for wl in blockout general abc_fine; do
+timeout 600 python bench.py --no-cpu-baseline --workload $wl > $O/bench_$wl.json 2>$O/bench_$wl.err || tail -3 $O/bench_$wl.err
 python -c "
-import json; d=json.load(open('$O/bench_$wl.json')); print('$wl value', round(d['value']), 'ms', round(d['ms_per_step'],4), d.get('roofline'))"
+import json; d=json.load(open('$O/bench_$wl.json')); print('$wl value', round(d['value']), 'ms', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), d.get('grouped_stepping',{}).get('value'), d.get('extra'))"
 done
 R=$PWD
-(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt -o r02 -- python $R/bench.py --no-cpu-baseline --no-extra --steps 200 --warmup 20 > $R/$O/bench_under_rocprof.json 2> $R/$O/kt.err)
-find $O/kt -name '*kernel_stats.csv' | head -1 | xargs head -12
-find $O/kt -name '*kernel_trace.csv' -size +4M -delete
-timeout 300 python tools/vecenv_throughput.py > $O/vecenv.txt 2>&1; tail -3 $O/vecenv.txt
+for wl in blockout general; do
+(cd /tmp && export TMPDIR=/tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/kt_$wl -o r02 -- python $R/bench.py --workload $wl --no-cpu-baseline --no-extra --steps 100 --warmup 10 > $R/$O/bench_rocprof_$wl.json 2> $R/$O/kt_$wl.err)
+find $O/kt_$wl -name '*kernel_stats.csv' | head -1 | xargs head -5 | cut -c1-150
+find $O/kt_$wl -name '*kernel_trace.csv' -delete
+done
