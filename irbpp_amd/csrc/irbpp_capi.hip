@@ -74,11 +74,20 @@ void layout_lds(Params& P) {
     P.mg_ax = div_magic(P.Ax);
     P.mg_ac = div_magic(P.AC);
     P.mg_mbw = div_magic(P.mb_w);
+    // heightmap tile: phase planes of period 2*step, one entry per 2 x 2 block of action cells (= per lane of the
+    // generic overlap test)
+    P.pp = 2 * P.step;
+    P.LX = (P.Ax + 1) / 2;
+    P.LY = (P.Ay + 1) / 2;
+    P.PL = P.LX * P.LY;
+    P.tile_words = P.pp * P.pp * P.PL;
+    P.mg_pp = div_magic(P.pp);
+    P.mg_ly = div_magic(P.LY);
     P.nslot = 64;                                                     // candidate starts traced per pass (16 per wave)
     P.slot_cap = 64;                                                  // points of a border: one lane each in the segmented Douglas-Peucker
     P.slot_bytes = P.slot_cap + 4;                                    // 68 B = 17 dwords: odd stride, lanes hit distinct LDS banks
     int32_t off = 0;
-    P.o_posz = off;      off += align16(P.R * P.AC * 8);
+    P.o_sr = off;        off += align16(P.R * (int32_t)sizeof(ShapeRot));
     P.o_lev = off;       off += align16(P.R * P.AC);
     P.o_present = off;   off += align16(P.R * 8);
     P.o_taskidx = off;   off += align16(P.R * 64 * 2);
@@ -100,7 +109,7 @@ void layout_lds(Params& P) {
     int32_t scratch = slots + dps + 512;
     const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
-    if (scratch < P.Hc * 8) scratch = P.Hc * 8;
+    if (scratch < P.tile_words * 8) scratch = P.tile_words * 8;
     P.scratch_bytes = align16(scratch);
     P.o_hm = off;
     P.o_scratch = off;
@@ -110,6 +119,16 @@ void layout_lds(Params& P) {
     off += P.scratch_bytes;
     if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tuning: caps workgroups per CU
     P.lds_bytes = off;
+    P.o_posz = off;                                    // only the heuristic kernel keeps posZValid in LDS
+    P.lds_bytes_full = off + align16(P.R * P.AC * 8);
+    // emit kernel: posZValid, vertex bits, reductions, the radix-select counters, candidate keys + selected keys
+    int32_t e = 0;
+    P.e_posz = e;   e += align16(P.R * P.AC * 8);
+    P.e_vmask = e;  e += align16(P.R * 16 * 4);
+    P.e_red = e;    e += 256;
+    P.e_hist = e;   e += 1024;
+    P.e_keys = e;   e += align16(keys);
+    P.emit_lds_bytes = e;
 }
 
 // The dynamic-LDS limit is an attribute of the kernel on the device, not of an environment: always raise it to the
@@ -191,7 +210,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
-    if (P.lds_bytes > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
+    if (P.lds_bytes_full > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
     if (raise_lds_limits() != IRBPP_OK) { delete env; return IRBPP_ERR_HIP; }
@@ -250,6 +269,8 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     const int R = P.R;
     std::vector<ShapeRot> sr((size_t)n_shapes * R);
     std::vector<Cell> bcell, tcell, blkcell;
+    std::vector<Pos4> pos_b;
+    std::vector<int32_t> pos_off;
     for (int64_t i = 0; i < (int64_t)n_shapes * R; ++i) {               // table shapes and offsets first: the scans below trust them
         const int64_t fx = dims[i * 2], fy = dims[i * 2 + 1];
         if (fx < 1 || fy < 1 || fx > 4096 || fy > 4096 || offsets[i] < 0 || offsets[i] + fx * fy > pool_len) return IRBPP_ERR_ARG;
@@ -298,7 +319,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             if (s.fx != dims[i * 2] || s.fy != dims[i * 2 + 1]) return IRBPP_ERR_ARG;   // table shape must match
             if (s.fx < 1 || s.fy < 1 || s.fx > s.ax * P.step || s.fy > s.ay * P.step) return IRBPP_ERR_ARG;
             if (off < 0 || off + (int64_t)s.fx * s.fy > pool_len) return IRBPP_ERR_ARG;
-            // compact lists of the masked-in cells, row-major, with phase-plane tile offsets
+            // compact lists of the masked-in cells, row-major
             s.ob = (int32_t)bcell.size();
             s.ot = (int32_t)tcell.size();
             for (int ci = 0; ci < s.fx; ++ci) {
@@ -306,11 +327,10 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                     const int64_t e = off + (int64_t)ci * s.fy + cj;
                     const double mt = mask_top[e], mb = mask_bottom[e];
                     if ((mt != 0.0 && mt != 1.0) || (mb != 0.0 && mb != 1.0)) return IRBPP_ERR_ARG;
-                    const int32_t toff = ((ci % P.step) * P.step + (cj % P.step)) * P.AC + (ci / P.step) * P.Ay +
-                                         (cj / P.step);
-                    if (mb != 0.0) bcell.push_back(Cell{height_bottom[e], toff, ci * s.fy + cj});
+                    const int32_t ij = ci | (cj << 16);
+                    if (mb != 0.0) bcell.push_back(Cell{height_bottom[e], ij, ci * s.fy + cj});
                     else s.has_out = 1;
-                    if (mt != 0.0) tcell.push_back(Cell{height_top[e], toff, ci * s.fy + cj});
+                    if (mt != 0.0) tcell.push_back(Cell{height_top[e], ij, ci * s.fy + cj});
                 }
             }
             s.nb = (int32_t)bcell.size() - s.ob;
@@ -337,17 +357,43 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                             blkcell.push_back(Cell{height_bottom[e0], (ti * block_b / P.step) * mb_w + tj * block_b / P.step, 0});
                     }
             s.nblk = (int32_t)blkcell.size() - s.oblk;
+            // generic path: the positions (u, v) relative to the corner of a 2 x 2 block of action cells at which
+            // at least one of the four cells has a masked-in footprint cell (u - a*step, v - b*step)
+            s.opos = (int32_t)pos_b.size();
+            if (!block_b)
+                for (int u = 0; u < s.fx + P.step; ++u)
+                    for (int v = 0; v < s.fy + P.step; ++v) {
+                        Pos4 q;
+                        bool any = false;
+                        for (int a = 0; a < 2; ++a)
+                            for (int bb = 0; bb < 2; ++bb) {
+                                const int ci = u - a * P.step, cj = v - bb * P.step;
+                                double val = INFINITY;
+                                if (ci >= 0 && ci < s.fx && cj >= 0 && cj < s.fy && mask_bottom[off + (int64_t)ci * s.fy + cj] != 0.0) {
+                                    val = height_bottom[off + (int64_t)ci * s.fy + cj];
+                                    any = true;
+                                }
+                                q.b[a * 2 + bb] = val;
+                            }
+                        if (!any) continue;
+                        pos_b.push_back(q);
+                        pos_off.push_back(((u % P.pp) * P.pp + (v % P.pp)) * P.PL + (u / P.pp) * P.LY + v / P.pp);
+                    }
+            s.npos = (int32_t)pos_b.size() - s.opos;
             if (s.nb == 0 && !s.has_out) return IRBPP_ERR_ARG;
         }
     }
     if (bcell.empty()) bcell.push_back(Cell{0.0, 0, 0});
     if (tcell.empty()) tcell.push_back(Cell{0.0, 0, 0});
     if (blkcell.empty()) blkcell.push_back(Cell{0.0, 0, 0});
+    if (pos_b.empty()) { pos_b.push_back(Pos4{{0.0, 0.0, 0.0, 0.0}}); pos_off.push_back(0); }
     Tables& T = env->T;
     int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.bcell, (const Cell*)bcell.data(), bcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.tcell, (const Cell*)tcell.data(), tcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.blkcell, (const Cell*)blkcell.data(), blkcell.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.pos_b, (const Pos4*)pos_b.data(), pos_b.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.pos_off, (const int32_t*)pos_off.data(), pos_off.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
     if (rc == IRBPP_OK) rc = dev_alloc(env, &env->S.item_cost, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
@@ -357,7 +403,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         env->P.mb_h = mb_h;
         env->P.mb_w = mb_w;
         layout_lds(env->P);
-        if (env->P.lds_bytes > 160 * 1024) return IRBPP_ERR_ARG;
+        if (env->P.lds_bytes_full > 160 * 1024) return IRBPP_ERR_ARG;
         if (raise_lds_limits() != IRBPP_OK) return IRBPP_ERR_HIP;
     }
     env->shapes_loaded = true;
@@ -407,7 +453,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
-        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
+        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }
 
@@ -526,7 +572,7 @@ int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int3
     io.heur_out = out_dev;
     io.heur_method = method;
     io.heur_dir = dir_idx;
-    hipLaunchKernelGGL(irbpp_heuristic_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes, (hipStream_t)stream, env->P,
+    hipLaunchKernelGGL(irbpp_heuristic_kernel, dim3(env->P.N), dim3(256), env->P.lds_bytes_full, (hipStream_t)stream, env->P,
                        env->T, env->S, io);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }

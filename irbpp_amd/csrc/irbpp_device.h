@@ -42,6 +42,7 @@ struct ShapeRot {
     int32_t has_out;       // 1 iff some maskB==0 cell exists: the window max then includes (H-B)*0 = 0
     int32_t pad;
     int32_t nblk, oblk;    // block list (Params.block_b > 0): uniform-bottom b x b tiles of the footprint
+    int32_t npos, opos;    // position list of the generic overlap test (Pos4 / pos_off)
     double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
     double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
     double com_x, com_y;          // centre of mass of the column solid between the two tables, in heightmap cells from the
@@ -51,19 +52,25 @@ struct ShapeRot {
 // Footprint tables are stored as compact lists of the masked-in cells only.  A masked-out cell
 // contributes (H-B)*0 = +-0 to np.max at space.py:118-119, i.e. the constant 0 (has_out), and
 // (T+z)*0 = +-0 to np.maximum at space.py:213, a no-op on a non-negative heightmap.
-// `off` addresses the LDS heightmap tile relative to the action cell's own entry, in the
-// phase-plane layout described in irbpp_kernels.hip.
-struct Cell {              // 16 B: one s_load_dwordx4 per cell when the list index is wave-uniform
+struct Cell {              // 16 B
     double v;              // heightMapB / heightMapT value
-    int32_t off;           // LDS tile offset relative to the action cell's own entry
+    int32_t ij;            // i | j << 16: the cell's row and column in its [fx][fy] table
     int32_t pad;           // row-major index i*fy+j of the cell in its [fx][fy] table
 };
+
+// Generic overlap test, one entry per heightmap position (u, v) relative to the corner of a 2 x 2 block of action
+// cells: the four action cells (a, b) of the block see position (u, v) as their footprint cell (u - a*step,
+// v - b*step); b[a*2+b] is that cell's heightMapB, +inf where the cell is outside the table or masked out.  One
+// LDS read of the heightmap then serves up to four (action cell, footprint cell) pairs.  Read with scalar loads.
+struct alignas(32) Pos4 { double b[4]; };
 
 struct Tables {
     const ShapeRot* sr;    // [n_shapes][R]
     const Cell* bcell;     // bottom cells (maskB == 1)
     const Cell* tcell;     // top cells    (maskH == 1)
-    const Cell* blkcell;   // bottom tiles (block path): v = the tile's heightMapB, off = offset into the block-max grid
+    const Cell* blkcell;   // bottom tiles (block path): v = the tile's heightMapB, ij = offset into the block-max grid
+    const Pos4* pos_b;     // generic path: bottom heights of the four action cells at each listed position
+    const int32_t* pos_off; //              LDS tile offset of the position relative to the lane's own entry
     const double* volume;  // [n_shapes]
     const int32_t* seq;    // [n_traj][seq_len]
     int32_t n_shapes, n_traj, seq_len;
@@ -118,8 +125,14 @@ struct Params {
     int32_t traj_start, goff, gbins;
     int32_t obs_len0, obs_len1;
     // dynamic-LDS carve-up (byte offsets, all multiples of 16)
+    // heightmap tile in LDS ("phase planes" of period pp = 2*step, see irbpp_kernels.hip): LX x LY entries per plane
+    int32_t pp, LX, LY, PL, tile_words;
+    uint32_t mg_pp, mg_ly;
+    int32_t o_sr;             // the R ShapeRots of the observed item
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red, o_dps;
-    int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;
+    int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;   // lds_bytes: transition kernel (no posZValid region)
+    int32_t lds_bytes_full;   // + posZValid at o_posz: heuristic kernel
+    int32_t e_posz, e_vmask, e_red, e_hist, e_keys, emit_lds_bytes;   // the emit kernel's own carve-up
     int32_t big_slot_bytes;   // bytes of the scratch region the serial redo of an oversized border may use
     // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid

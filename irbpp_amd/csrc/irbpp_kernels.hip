@@ -15,11 +15,12 @@
 // order (compile with -ffp-contract=off), so results are bit-identical to the numpy code.
 // No MFMA: this is subtract/max/compare and integer border following, not a contraction.
 //
-// LDS heightmap tile layout ("phase planes"): heightmap cell (row, col) with row = X*step + ri,
-// col = Y*step + rj lives at plane (ri*step + rj), entry X*Ay + Y.  For a fixed footprint cell
-// (i, j) all lanes (X, Y) of a wave read ONE plane at consecutive entries, so the per-lane
-// ds_read_b64 of the overlap test is bank-conflict-free (16 lanes x 8 B = 32 banks, the next
-// X row lands on the other 32), and the footprint cell's tile offset is a wave-uniform scalar.
+// LDS heightmap tile layout ("phase planes" of period pp = 2*step): heightmap cell (row, col) with
+// row = Lx*pp + u, col = Ly*pp + v (u, v < pp) lives at plane (u*pp + v), entry Lx*LY + Ly; a plane has
+// LX x LY = ceil(Ax/2) x ceil(Ay/2) <= 64 entries.  In the overlap test lane l = Lx*LY + Ly owns the 2 x 2 block of
+// action cells whose corner is heightmap cell (Lx*pp, Ly*pp): for a fixed position relative to that corner all lanes
+// of a wave read ONE plane at consecutive entries, so the per-lane ds_read_b64 is bank-conflict-free and the
+// position's tile offset is a wave-uniform scalar; and one value read serves the four action cells of the block.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -142,18 +143,19 @@ __device__ __forceinline__ KernArgsPtr cold_args() {
 
 __device__ __forceinline__ uint32_t div_magic_dev(int d) { return d >= 2 ? (uint32_t)(0x100000000ull / (uint64_t)d + 1ull) : 0u; }
 
-// linear heightmap index (row*Hy + col) <-> LDS tile index in the phase-plane layout
-__device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
-    const int row = fdiv(g, P.Hy, P.mg_hy), col = g - row * P.Hy;
-    const int X = fdiv(row, P.step, P.mg_step), ri = row - X * P.step;
-    const int Y = fdiv(col, P.step, P.mg_step), rj = col - Y * P.step;
-    return (ri * P.step + rj) * P.AC + X * P.Ay + Y;
+// heightmap cell (row, col) / linear heightmap index (row*Hy + col) -> LDS tile index in the phase-plane layout
+__device__ __forceinline__ int tile_rc(const Params& P, int row, int col) {
+    const int qr = fdiv(row, P.pp, P.mg_pp), mr = row - qr * P.pp;
+    const int qc = fdiv(col, P.pp, P.mg_pp), mc = col - qc * P.pp;
+    return (mr * P.pp + mc) * P.PL + qr * P.LY + qc;
 }
-__device__ __forceinline__ int linear_of_tile(const Params& P, int t) {
-    const int plane = fdiv(t, P.AC, P.mg_ac), rem = t - plane * P.AC;
-    const int X = fdiv(rem, P.Ay, P.mg_ay), Y = rem - X * P.Ay;
-    const int ri = fdiv(plane, P.step, P.mg_step), rj = plane - ri * P.step;
-    return (X * P.step + ri) * P.Hy + Y * P.step + rj;
+__device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
+    const int row = fdiv(g, P.Hy, P.mg_hy);
+    return tile_rc(P, row, g - row * P.Hy);
+}
+// footprint cell `ij` (i | j << 16) of an item whose corner sits on action cell (lx, ly)
+__device__ __forceinline__ int tile_of_cell(const Params& P, int lx, int ly, int ij) {
+    return tile_rc(P, lx * P.step + (ij & 0xFFFF), ly * P.step + (ij >> 16));
 }
 
 // Read-only tables are addressed through the constant address space so that wave-uniform
@@ -190,6 +192,7 @@ __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) 
 }
 
 struct Lds {
+    int* sr;                // the R ShapeRots of the observed item, as dwords
     double* hm;
     double* mb;             // block-max grid of the tile (block path of the overlap test)
     double* posz;
@@ -208,6 +211,7 @@ struct Lds {
 
 __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     Lds L;
+    L.sr = (int*)(smem + P.o_sr);
     L.hm = (double*)(smem + P.o_hm);
     L.mb = (double*)(smem + P.o_mb);
     L.posz = (double*)(smem + P.o_posz);
@@ -496,12 +500,10 @@ __device__ inline double heuristic_score(const Params& P, const Tables& T, const
         default: {                                                           // HM
             score = (cx + cy) * P.res_a;
             const Cell* top = T.tcell + sr.ot;
-            const double* h0 = L.hm + X * P.Ay + Y;
             // dense row-major walk over the fx x fy window; the compact top list is in the same order
             auto at = [&](int e) -> double {
                 const int i = e / sr.fy, j = e - i * sr.fy;
-                const int off = ((i % P.step) * P.step + (j % P.step)) * P.AC + (i / P.step) * P.Ay + (j / P.step);
-                const double h = h0[off];
+                const double h = L.hm[tile_rc(P, X * P.step + i, Y * P.step + j)];
                 // binary search of the masked-in list for this offset's row-major rank
                 int lo = 0, hi = sr.nt - 1;
                 double v = 0.0;                                             // (T + z) * 0 for masked-out cells
@@ -521,47 +523,51 @@ __device__ inline double heuristic_score(const Params& P, const Tables& T, const
     return round6(score);
 }
 
+// wave64 OR-reduction on the DPP network; lane 63 ends up with the OR of all lanes (0 shifted in = identity)
+__device__ __forceinline__ uint32_t wave_or_to_lane63(uint32_t x) {
+    int v = (int)x;
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, false);     // row_shr:1
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, false);     // row_shr:2
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, false);     // row_shr:4
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, false);     // row_shr:8
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 into rows 1 and 3
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 into rows 2 and 3
+    return (uint32_t)v;
+}
+
+typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
+typedef const __attribute__((address_space(4))) int32_t* ConstIntPtr;
+
 // Space.get_possible_position (space.py:98-129) for `item` on the tile in LDS: fills L.posz
 // (posZValid), L.lev (height-level codes), L.present and returns np.sum(naiveMask).
+// posZValid goes to `zdst` ([R][AC]): global memory in the transition kernel (the emit kernel reads it from there; the
+// transition kernel's own LDS layout has no room for it, which is worth two more workgroups per CU), LDS elsewhere.
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                   const Lds& L, int b, int item, bool debug_out) {
+                                   const Lds& L, int b, int item, bool debug_out, double* zdst) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
-    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
-    // All R ShapeRots of the item in ONE coalesced load into LDS (the scratch region is free while the
-    // tile is in use only if it does not alias it -- it does, so they go to the front of L.posz's
-    // last rotation slab, which is written only at the very end of this function for r = R-1).
-    int* srw = (int*)(L.lev);                                // R*AC bytes >= R*72: lev is written after the loops read sr
+    int* srw = L.sr;                                         // all R ShapeRots of the item in ONE coalesced load
     if (item >= 0)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
     for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
-    if (P.block_b > 0) {                         // block-max grid of the current tile, plane offsets built incrementally
+    if (P.block_b > 0) {                         // block-max grid of the current tile
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
-            const double* base = L.hm + pi * Ay + pj;
             double m = -1e300;
-            int ri = 0, xi = 0;
-            for (int i = 0; i < P.block_b; ++i) {
-                int rj = 0, yj = 0;
-                for (int j = 0; j < P.block_b; ++j) {
-                    m = fmax(m, base[(ri * P.step + rj) * AC + xi * Ay + yj]);
-                    if (++rj == P.step) { rj = 0; ++yj; }
-                }
-                if (++ri == P.step) { ri = 0; ++xi; }
-            }
+            for (int i = 0; i < P.block_b; ++i)
+                for (int j = 0; j < P.block_b; ++j) m = fmax(m, L.hm[tile_rc(P, pi * P.step + i, pj * P.step + j)]);
             L.mb[t] = m;
         }
     }
     __syncthreads();
 
-    // ---- Space.get_possible_position (space.py:98-129): one action cell per lane -------
-    const bool blocks = P.block_b > 0;
-    const int lane = tid & 63;
+    const int lane = tid & 63, wave = tid >> 6;
     int my_valid = 0;
-    // per-rotation results are kept in registers until all rotations have read their ShapeRot from
-    // the LDS staging area (which shares memory with L.lev)
+    if (P.block_b > 0) {
+    // ---- block path: one action cell per lane, all rotations; footprint = list of uniform b x b blocks ----------
+    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     double zs[8];
     bool vs[8];
     int level_code[8];
@@ -570,9 +576,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
     if (item >= 0) {
         const ShapeRot* s0 = (const ShapeRot*)srw;
-        ncell_next = __builtin_amdgcn_readfirstlane(blocks ? s0->nblk : s0->nb);
-        off_next = __builtin_amdgcn_readfirstlane(blocks ? s0->oblk : s0->ob);
-        const Cell* c0 = (blocks ? T.blkcell : T.bcell) + off_next;
+        ncell_next = __builtin_amdgcn_readfirstlane(s0->nblk);
+        off_next = __builtin_amdgcn_readfirstlane(s0->oblk);
+        const Cell* c0 = T.blkcell + off_next;
         if (ncell_next > 0) pre = c0[lane < ncell_next ? lane : ncell_next - 1];
     }
 #pragma unroll
@@ -589,28 +595,27 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         Cell c = pre;
         if (r + 1 < R) {                                     // issue the next rotation's first chunk now
             const ShapeRot* sn = sp + 1;
-            ncell_next = __builtin_amdgcn_readfirstlane(blocks ? sn->nblk : sn->nb);
-            off_next = __builtin_amdgcn_readfirstlane(blocks ? sn->oblk : sn->ob);
-            const Cell* cn = (blocks ? T.blkcell : T.bcell) + off_next;
+            ncell_next = __builtin_amdgcn_readfirstlane(sn->nblk);
+            off_next = __builtin_amdgcn_readfirstlane(sn->oblk);
+            const Cell* cn = T.blkcell + off_next;
             if (ncell_next > 0) pre = cn[lane < ncell_next ? lane : ncell_next - 1];
         }
         const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
-        const double* h0 = blocks ? L.mb + X * P.mb_w + Y : L.hm + X * Ay + Y;
+        const double* h0 = L.mb + X * P.mb_w + Y;
         double m = has_out ? 0.0 : -1e300;
-        // The footprint list is fetched 64 cells at a time, one 16-byte cell per lane (a coalesced
-        // vector load), and broadcast cell by cell with v_readlane: the loop then has only LDS reads
-        // in flight, which the hardware returns in order and the compiler can pipeline (scalar
-        // loads would share lgkmcnt with the LDS reads and force full drains).
-        const Cell* cells = (blocks ? T.blkcell : T.bcell) + off0;
+        // The block list is fetched 64 entries at a time, one 16-byte entry per lane (a coalesced
+        // vector load), and broadcast entry by entry with v_readlane: the loop then has only LDS reads
+        // in flight, which the hardware returns in order and the compiler can pipeline.
+        const Cell* cells = T.blkcell + off0;
         for (int base = 0; base < ncell; base += 64) {
             if (base > 0) {
                 const int idx = base + lane < ncell ? base + lane : ncell - 1;
                 c = cells[idx];
             }
             const int cnt = ncell - base < 64 ? ncell - base : 64;
-            int c_off = c.off;
+            int c_off = c.ij;
             int c_lo = (int)__double2loint(c.v), c_hi = (int)__double2hiint(c.v);
-            // every lane must really hold its cell (v_readlane reads lanes that are masked off
+            // every lane must really hold its entry (v_readlane reads lanes that are masked off
             // below): keep the compiler from sinking the load into the in_range branch
             asm volatile("" : "+v"(c_off), "+v"(c_lo), "+v"(c_hi));
             if (in_range) {
@@ -641,7 +646,6 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         }
     }
     }
-    __syncthreads();                                         // every ShapeRot has been read: L.lev may be written
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         if (r >= R) continue;
@@ -653,7 +657,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 ka->io.posz_out[((size_t)b * R + r) * AC + tid] = z;
                 ka->io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
             }
-            L.posz[r * AC + tid] = valid ? z : 1e3;
+            zdst[r * AC + tid] = valid ? z : 1e3;
             int code = 255;
             if (valid) {
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
@@ -682,6 +686,98 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         }
         if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
     }
+    } else {
+    // ---- generic path: wave w takes the rotations w, w + 4; lane l = Lx*LY + Ly owns the 2 x 2 block of action
+    // cells (2Lx + a, 2Ly + b).  The footprint is walked position by position (Pos4): one LDS read of the
+    // heightmap per position, four subtract/max pairs with the bottom heights as SCALAR operands (s_load from
+    // the wave-uniform list), no cross-lane traffic at all.  A position outside a lane's part of the heightmap
+    // reads some other float64 of the workgroup's LDS: it can only belong to action cells that are out of
+    // range for this rotation (discarded below), while the in-range cells of the lane see +inf there, i.e.
+    // -inf or NaN, which max() drops.
+    const int Lx = fdiv(lane, P.LY, P.mg_ly), Ly = lane - Lx * P.LY;
+    const double* hbase = L.hm + lane;
+    double zq[2][4];
+    bool vq[2][4];
+    for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = wave + k * WAVES;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { zq[k][q] = 1e3; vq[k][q] = false; }
+        if (r >= R || item < 0) continue;
+        const ShapeRot* sp = (const ShapeRot*)srw + r;
+        const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
+        const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
+        const int npos = __builtin_amdgcn_readfirstlane(sp->npos), opos = __builtin_amdgcn_readfirstlane(sp->opos);
+        const double ext_z_r = sp->ext_z_r;
+        const ConstF64Ptr pb = (ConstF64Ptr)(unsigned long long)(T.pos_b + opos);      // [npos][4]
+        const ConstIntPtr po = (ConstIntPtr)(unsigned long long)(T.pos_off + opos);
+        const double init = has_out ? 0.0 : -1e300;
+        double a0 = init, a1 = init, a2 = init, a3 = init;
+        int p = 0;
+        for (; p + 4 <= npos; p += 4) {                      // four LDS reads in flight per trip
+            const int o0 = po[p], o1 = po[p + 1], o2 = po[p + 2], o3 = po[p + 3];
+            const double h0 = hbase[o0], h1 = hbase[o1], h2 = hbase[o2], h3 = hbase[o3];
+            const ConstF64Ptr q = pb + 4 * p;
+            a0 = fmax(a0, h0 - q[0]);  a1 = fmax(a1, h0 - q[1]);  a2 = fmax(a2, h0 - q[2]);  a3 = fmax(a3, h0 - q[3]);
+            a0 = fmax(a0, h1 - q[4]);  a1 = fmax(a1, h1 - q[5]);  a2 = fmax(a2, h1 - q[6]);  a3 = fmax(a3, h1 - q[7]);
+            a0 = fmax(a0, h2 - q[8]);  a1 = fmax(a1, h2 - q[9]);  a2 = fmax(a2, h2 - q[10]); a3 = fmax(a3, h2 - q[11]);
+            a0 = fmax(a0, h3 - q[12]); a1 = fmax(a1, h3 - q[13]); a2 = fmax(a2, h3 - q[14]); a3 = fmax(a3, h3 - q[15]);
+        }
+        for (; p < npos; ++p) {
+            const double h0 = hbase[po[p]];
+            const ConstF64Ptr q = pb + 4 * p;
+            a0 = fmax(a0, h0 - q[0]); a1 = fmax(a1, h0 - q[1]); a2 = fmax(a2, h0 - q[2]); a3 = fmax(a3, h0 - q[3]);
+        }
+        const double acc[4] = {a0, a1, a2, a3};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = 2 * Lx + (q >> 1), Y = 2 * Ly + (q & 1);
+            if (lane < P.PL && X <= Ax - s_ax && Y <= Ay - s_ay) {
+                zq[k][q] = acc[q];
+                vq[k][q] = round6_scaled(acc[q] + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int r = wave + k * WAVES;
+        if (r >= R) continue;
+        uint32_t bits_lo = 0u, bits_hi = 0u;                 // level codes present among my four cells
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int X = 2 * Lx + (q >> 1), Y = 2 * Ly + (q & 1);
+            if (lane < P.PL && X < Ax && Y < Ay) {
+                const int cell = X * Ay + Y;
+                const double z = zq[k][q];
+                const bool valid = vq[k][q];
+                if (debug_out) {
+                    const KernArgsPtr ka = cold_args();
+                    ka->io.posz_out[((size_t)b * R + r) * AC + cell] = z;
+                    ka->io.mask_out[((size_t)b * R + r) * AC + cell] = valid ? 1 : 0;
+                }
+                zdst[r * AC + cell] = valid ? z : 1e3;
+                int code = 255;
+                if (valid) {
+                    const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
+                    if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
+                        const int idx = li + 32;
+                        if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                        else code = idx;
+                    }
+                    ++my_valid;
+                }
+                L.lev[r * AC + cell] = (uint8_t)code;
+                if (code < 32) bits_lo |= 1u << code;
+                else if (code < 64) bits_hi |= 1u << (code - 32);
+            }
+        }
+        // presence mask of the rotation: OR over the wave on the DPP network, one LDS store by its last lane
+        bits_lo = wave_or_to_lane63(bits_lo);
+        bits_hi = wave_or_to_lane63(bits_hi);
+        if (lane == 63) L.present[r] = ((unsigned long long)bits_hi << 32) | bits_lo;
+    }
+    }
     return block_sum_int(my_valid, L.redi);                  // np.sum(naiveMask) for prejudge
 }
 
@@ -698,7 +794,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
-    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out);
+    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
@@ -1002,8 +1098,6 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         contour_stage(P, S, L, nullptr);             // vertex bits of isolated pixels set above are simply set again
         __syncthreads();
     }
-    double* gz = ka->S.w_posz + (size_t)b * P.R * P.AC;
-    for (int i = tid; i < P.R * P.AC; i += BLOCK) gz[i] = L.posz[i];
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
     for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
     if (tid == 0) {
@@ -1021,7 +1115,13 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 extern "C" __global__ void __launch_bounds__(BLOCK)
 irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const Lds L = carve_lds(smem, P);
+    Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
+    L.posz = (double*)(smem + P.e_posz);
+    L.vmask = (uint32_t*)(smem + P.e_vmask);
+    L.redd = (double*)(smem + P.e_red);
+    L.redi = (int*)(L.redd + 8);
+    L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select
+    L.scratch = smem + P.e_keys;
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;
     const int slot = (int)blockIdx.x + io.block_off;
     const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
@@ -1078,9 +1178,16 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
     return v;
 }
 
-constexpr int TRACE_P = 2;                                            // contour points per lane and polygon round
-constexpr int TRACE_CAP = 64 * TRACE_P, TRACE_SLOT = TRACE_CAP + 4;   // points per border slot; 33 dwords: odd stride
-constexpr int TRACE_SHORT = 8;                                        // borders of up to this many points are approximated first
+#ifndef IRBPP_TRACE_P
+#define IRBPP_TRACE_P 2
+#endif
+#ifndef IRBPP_TRACE_SHORT
+#define IRBPP_TRACE_SHORT 8
+#endif
+constexpr int TRACE_P = IRBPP_TRACE_P;                                // contour points per lane and polygon round
+constexpr int TRACE_CAP = 128, TRACE_SLOT = TRACE_CAP + 4;            // points per border slot; 33 dwords: odd stride
+constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points are approximated first
+static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
 constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
 #ifndef IRBPP_TRACE_CPW
@@ -1264,8 +1371,13 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     stamp(io, b, 0);
     // stage the heightmap tile
     if (mode == MODE_RESET) {
-        for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }
+        for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;
+        for (int i = tid; i < P.Hc; i += BLOCK) ghm[i] = 0.0;
     } else {
+        if (P.tile_words > P.Hc) {                       // odd action grid: the planes have padding entries
+            for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;
+            __syncthreads();
+        }
         for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     }
     __syncthreads();
@@ -1328,9 +1440,8 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         const bool in_grid = item0 >= 0 && rot < P.R && lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay;
         if (in_grid && (ok || cold_args()->S.log_meta != nullptr)) {
             const Cell* cells = T.bcell + sr.ob;
-            const double* h0 = L.hm + lx * P.Ay + ly;
             double m = sr.has_out ? 0.0 : -1e300;
-            for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, h0[cells[e].off] - cells[e].v);
+            for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v);
             z = block_max_f64(m, L.redd);
         }
         if (ok) {
@@ -1347,13 +1458,12 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             if (tid < 8) sup[tid] = -0x40000000;
             __syncthreads();
             const Cell* cells = T.bcell + sr.ob;
-            const double* h0 = L.hm + lx * P.Ay + ly;
             const double tol = 0.5 * P.res_z;
             int m8[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k) m8[k] = -0x40000000;
             for (int e = tid; e < sr.nb; e += BLOCK) {
-                if (h0[cells[e].off] - cells[e].v >= z - tol) {
+                if (L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v >= z - tol) {
                     const int ci = fdiv(cells[e].pad, sr.fy, div_magic_dev(sr.fy)), cj = cells[e].pad - ci * sr.fy;
                     m8[0] = max(m8[0], ci + 1); m8[1] = max(m8[1], -ci); m8[2] = max(m8[2], cj + 1); m8[3] = max(m8[3], -cj);
                     m8[4] = max(m8[4], ci + cj + 2); m8[5] = max(m8[5], -(ci + cj));
@@ -1373,15 +1483,17 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
             const Cell* cells = T.tcell + sr.ot;
-            const int base = lx * P.Ay + ly;
             for (int e = tid; e < sr.nt; e += BLOCK) {
-                const int c = base + cells[e].off;
+                const int ij = cells[e].ij;
+                const int row = lx * P.step + (ij & 0xFFFF), col = ly * P.step + (ij >> 16);
+                const int c = tile_rc(P, row, col);
                 const double h = fmax(L.hm[c], cells[e].v + z);
                 L.hm[c] = h;
-                ghm[linear_of_tile(P, c)] = h;
+                ghm[row * P.Hy + col] = h;
             }
         } else {
-            for (int i = tid; i < P.Hc; i += BLOCK) { L.hm[i] = 0.0; ghm[i] = 0.0; }   // Space.reset (space.py:49-52)
+            for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;                 // Space.reset (space.py:49-52)
+            for (int i = tid; i < P.Hc; i += BLOCK) ghm[i] = 0.0;
         }
         if (tid == 0) {
             BinState* ps = S.bs + b;                                 // field-wise: no struct copy (keeps scratch at 0)
@@ -1537,7 +1649,7 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(S.bs[b].cur_item);
-    overlap_test(P, T, S, io, L, b, item, false);
+    overlap_test(P, T, S, io, L, b, item, false, L.posz);
     __syncthreads();
     double best = 1e300;
     int best_i = 0x7fffffff;
@@ -1631,7 +1743,6 @@ irbpp_hull_kernel(const Params P, const State S, const double* posz_valid, const
             const size_t gi = ((size_t)g * R + r) * AC + tid;
             const double z = posz_valid[gi];
             const bool valid = mask[gi] != 0;
-            L.posz[r * AC + tid] = z;
             int code = 255;
             if (valid) {
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);

@@ -57,4 +57,13 @@ out["contour_detail"] = {"extract_mean": float(ex[:, 0].mean()), "extract_max": 
                          "wave0_trace_mean": float(ex[:, 3].mean()), "wave0_dp_mean": float(ex[:, 4].mean()),
                          "wave0_barrier_wait_mean": float(ex[:, 5].mean()), "redo_mean": float(ex[:, 6].mean()),
                          "redo_borders_mean": float(ex[:, 7].mean())}
+# the slowest bins of the emit kernel in the last step: how many candidate rows, which path (tooling)
+last = np.diff(c[:, :5], axis=1)[:, 3]
+rows = obs[:, :2500].reshape(a.bins, 500, 5)
+nrow = (rows[:, :, 4] == 1).sum(1).cpu().numpy()
+fb = (rows[:, :, 3] == rows[:, :1, 3]).all(1).cpu().numpy() & (rows[:, 0, 3] > 0.29).cpu().numpy()
+top = np.argsort(-last)[:8]
+out["slowest_emit_bins"] = [{"cycles": int(last[i]), "rows_V1": int(nrow[i]), "fallback_rows": bool(fb[i])} for i in top]
+out["emit_cycles_by_rows"] = {"rows<500": float(last[nrow < 500].mean()), "rows==500": float(last[nrow == 500].mean()) if (nrow == 500).any() else None,
+                              "share_rows==500": float((nrow == 500).mean()), "share_fallback": float(fb.mean())}
 print(json.dumps(out))
