@@ -126,7 +126,11 @@ void layout_lds(Params& P) {
     P.e_posz = e;   e += align16(P.R * P.AC * 8);
     P.e_vmask = e;  e += align16(P.R * 16 * 4);
     P.e_red = e;    e += 256;
-    P.e_hist = e;   e += 1024;
+    {   // 256 radix counters, later the sort keys of the selected rows: 10 bytes per entry of the next power of two
+        int32_t npad = 64;
+        while (npad < P.S) npad <<= 1;
+        P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);
+    }
     P.e_keys = e;   e += align16(keys);
     P.emit_lds_bytes = e;
 }
@@ -427,11 +431,14 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
     return which == 0 ? env->P.obs_len0 : env->P.obs_len1;
 }
 
-// six workgroups of this layout fit a CU's LDS (150 KiB usable, measured): take the 80-VGPR build
+// Two register budgets of the transition kernel.  The block path (lattice data) is short on work per bin and wants
+// residency: 80 VGPRs, six workgroups per CU.  The generic path keeps eight float64 accumulators and a chunk of
+// scalar operands live in its inner loop: unconstrained (108 VGPRs, four workgroups per CU) it is 8 % faster than
+// squeezed into 80 (measured on "general": 8.5 vs 7.9 M steps/s), and its larger LDS layouts cap residency anyway.
 static bool use_wide_kernel(const Params& P) {
     static const char* force = getenv("IRBPP_WIDE");            // A/B tool: 0 / 1 forces the build
     if (force) return atoi(force) != 0;
-    return 6 * P.lds_bytes > 150 * 1024;
+    return P.block_b == 0 || 6 * P.lds_bytes > 150 * 1024;
 }
 
 // One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the

@@ -698,6 +698,24 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     const double* hbase = L.hm + lane;
     double zq[2][4];
     bool vq[2][4];
+    // The position lists (a few KB per rotation, tens of MB per dataset: beyond L2) are consumed by scalar loads, of
+    // which a wave has only one chunk in flight.  One vector load per 128-byte line, issued up front for both of this
+    // wave's rotations, brings the lists into this XCD's L2, so that the scalar loads wait for L2 instead of HBM.
+    int pref = 0;
+    if (item >= 0) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = wave + k * WAVES;
+            if (r < R) {
+                const ShapeRot* sp = (const ShapeRot*)srw + r;
+                const int npos = __builtin_amdgcn_readfirstlane(sp->npos), opos = __builtin_amdgcn_readfirstlane(sp->opos);
+                const char* pbv = (const char*)(T.pos_b + opos);
+                const char* pov = (const char*)(T.pos_off + opos);
+                for (int o = lane * 128; o < npos * 32; o += 64 * 128) pref |= *(const int*)(pbv + o);
+                for (int o = lane * 128; o < npos * 4; o += 64 * 128) pref |= *(const int*)(pov + o);
+            }
+        }
+    }
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -739,6 +757,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             }
         }
     }
+    asm volatile("" :: "v"(pref));                           // the prefetch loads are complete by now; nothing uses their data
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
         const int r = wave + k * WAVES;
@@ -817,7 +836,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
 // ascending position (binPhy.py:209-212, 217-225) -- without the n^2 ranking of everything against
 // everything: (1) radix select on the order-preserving 64-bit image of the float64 values finds the
 // want-th smallest value T in eight histogram rounds, (2) the elements below T plus the first few equal to
-// T are compacted in position order, (3) only those `want` elements are ranked against each other.
+// T are compacted in position order, (3) only those `want` elements are sorted.
 // Element e is the candidate key(e) = rot<<16 | lx<<8 | ly with value posZValid[rot, lx, ly]; out[rank] = its key.
 // `sel` ([n] words, may be the array key() reads) and `hist` ([256] words) are LDS.  All threads call it.
 // ---------------------------------------------------------------------------------------
@@ -891,35 +910,38 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, int n, int
         }
     }
     __syncthreads();
-    // (3) rank the selected elements among themselves; the list is in position order, so ties go to the lower index.
-    // Every wave walks the whole list 64 entries at a time: lane t fetches the value of entry base + t once, the
-    // wave then broadcasts them with v_readlane -- no LDS access and no dependent loads in the counting loop.
-    constexpr int MINE = (1024 + BLOCK - 1) / BLOCK;                 // selected <= 1024 rows (irbpp_create)
-    const int lane = tid & 63;
-    double vi[MINE];
-    uint32_t si[MINE];
-    int rank[MINE];
-#pragma unroll
-    for (int m = 0; m < MINE; ++m) {
-        const int i = tid + m * BLOCK;
-        si[m] = i < want ? sel[i] : 0u;
-        vi[m] = i < want ? value(si[m]) : 0.0;
-        rank[m] = 0;
+    // (3) sort the selected elements by (value, position in the list): bitonic network over the next power of two
+    // (entries beyond `want` are +infinity), keys as three LDS arrays (high word, low word, list position) in the
+    // region the radix counters used.  log2(n)(log2(n)+1)/2 rounds of one compare-exchange per thread.
+    int npad = 64;
+    while (npad < want) npad <<= 1;
+    uint32_t* const khi = hist;                                      // [npad]
+    uint32_t* const klo = hist + npad;                               // [npad]
+    uint16_t* const kps = (uint16_t*)(hist + 2 * npad);              // [npad]
+    for (int i = tid; i < npad; i += BLOCK) {
+        unsigned long long v = ~0ull;
+        if (i < want) v = sortable_f64(value(sel[i]));
+        khi[i] = (uint32_t)(v >> 32);
+        klo[i] = (uint32_t)v;
+        kps[i] = (uint16_t)(i < want ? i : 0xFFFF);
     }
-    for (int base = 0; base < want; base += 64) {
-        const double jv = base + lane < want ? value(sel[base + lane]) : 0.0;
-        const int jlo = (int)__double2loint(jv), jhi = (int)__double2hiint(jv);
-        const int cnt = want - base < 64 ? want - base : 64;
-        for (int t = 0; t < cnt; ++t) {
-            const double vj = __hiloint2double(__builtin_amdgcn_readlane(jhi, t), __builtin_amdgcn_readlane(jlo, t));
-            const int j = base + t;
-#pragma unroll
-            for (int m = 0; m < MINE; ++m) rank[m] += (vj < vi[m] || (vj == vi[m] && j < tid + m * BLOCK)) ? 1 : 0;
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int sh = __ffs(j) - 1;
+            for (int t = tid; t < (npad >> 1); t += BLOCK) {
+                const int i = ((t >> sh) << (sh + 1)) | (t & (j - 1)), l = i | j;
+                const uint32_t ah = khi[i], al = klo[i], bh = khi[l], bl = klo[l];
+                const uint32_t ap = kps[i], bp = kps[l];
+                const bool a_gt_b = ah > bh || (ah == bh && (al > bl || (al == bl && ap > bp)));
+                if (a_gt_b == ((i & k) == 0)) {
+                    khi[i] = bh; klo[i] = bl; kps[i] = (uint16_t)bp;
+                    khi[l] = ah; klo[l] = al; kps[l] = (uint16_t)ap;
+                }
+            }
+            __syncthreads();
         }
-    }
-#pragma unroll
-    for (int m = 0; m < MINE; ++m)
-        if (tid + m * BLOCK < want) out[rank[m]] = si[m];
+    for (int r = tid; r < want; r += BLOCK) out[r] = sel[kps[r]];
     __syncthreads();
 }
 
