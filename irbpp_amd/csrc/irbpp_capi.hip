@@ -238,6 +238,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_cand, (size_t)NXCD * flat_segment_capacity(P.N));
     ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)
     ALLOC(w_total, NXCD * XCD_STRIDE);
+    ALLOC(w_nround, NXCD * XCD_STRIDE);
+    ALLOC(w_round, (size_t)NXCD * round_segment_capacity(P.N) * ROUND_BYTES);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     env->reorder = !P.split;               // the split pipeline's transition kernel is uniform enough: ordering buys nothing (measured)
@@ -460,6 +462,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
+        hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(2 * n), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }

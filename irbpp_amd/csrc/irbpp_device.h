@@ -32,6 +32,10 @@ constexpr int XCD_STRIDE = 64;                     // ints between the lists' co
 // Capacity of one XCD's flat candidate list: a fair share of the bins' worst case plus room for an uneven share.  A
 // bin whose batch does not fit resolves its contours inside the transition kernel, so the capacity never changes results.
 __host__ __device__ constexpr int flat_segment_capacity(int n_bins) { return (n_bins / NXCD + 64) * 128; }
+// Round records of the polygon kernel (one per 128 contour points): capacity of one XCD's list, bytes of a record
+// ([points | border length | border start] per position, then the vertex-row index of the position's border).
+__host__ __device__ constexpr int round_segment_capacity(int n_bins) { return flat_segment_capacity(n_bins) / 8; }
+constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;
 constexpr int MAX_BINS = 32768;                   // bins per device: a flat-list entry has 15 bits for the bin (irbpp_create refuses more)
 
 struct ShapeRot {
@@ -113,6 +117,8 @@ struct State {
     uint32_t* w_cand;      // [NXCD][flat_segment_capacity(N)] flat lists of the launch's candidate starts, in arrival order:
                            // bin<<16 | image<<8 | y0<<4 | x0
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
+    uint8_t* w_round;      // [NXCD][round_segment_capacity(N)][ROUND_BYTES] round records, trace kernel -> polygon kernel
+    int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list
     int32_t* w_total;      // [NXCD * XCD_STRIDE] candidates in each XCD's list (XCD-local atomicAdd in the transition kernel, zeroed by the emit kernel)
 };
 

@@ -1151,7 +1151,7 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
     // device error word to the step outputs: every bit of this step was raised by the transition or the trace
     // kernel, which have completed (the emit kernel raises none).
-    if (blockIdx.x == 0 && tid < NXCD) S.w_total[tid * XCD_STRIDE] = 0;
+    if (blockIdx.x == 0 && tid < NXCD) { S.w_total[tid * XCD_STRIDE] = 0; S.w_nround[tid * XCD_STRIDE] = 0; }
     if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
@@ -1210,6 +1210,7 @@ constexpr int TRACE_P = IRBPP_TRACE_P;                                // contour
 constexpr int TRACE_CAP = 128, TRACE_SLOT = TRACE_CAP + 4;            // points per border slot; 33 dwords: odd stride
 constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points are approximated first
 static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
+static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
 constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
 #ifndef IRBPP_TRACE_CPW
@@ -1288,19 +1289,49 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
             }
         }
         const long long t_traced = prof ? (long long)clock64() : 0;
-        // ---- polygon approximation of the closed borders, 64 * PP contour points per round
-        // (two classes: a round lasts as many recursion levels as its deepest border needs, so the short borders
-        // -- the majority, done after two or three levels -- go first and the long ones share the later rounds)
+        // ---- the closed borders go to the polygon kernel in rounds of 64 * PP contour points, borders packed back
+        // to back (two classes: a round lasts as many recursion levels as its deepest border needs, so the short
+        // borders -- the majority, done after two or three levels -- share rounds, and so do the long ones).  A wave
+        // traces for as long as its longest border takes and has 2 to 6 rounds' worth of points: approximating them
+        // here would stretch the slowest waves, which set the kernel's duration; as records in global memory every
+        // round is one evenly sized work item of irbpp_polygon_kernel.
+        auto next_round = [&](int cls, int left, int& wn, int& excl, int& base) -> unsigned long long {
+            wn = (cls == 0 ? left <= TRACE_SHORT : true) ? left : 0;
+            const int incl = wave_inclusive_sum(wn);
+            excl = incl - wn;
+            if (__builtin_amdgcn_readlane(incl, 63) == 0) return 0ull;
+            const unsigned long long todo = __ballot(wn > 0);
+            base = __builtin_amdgcn_readlane(excl, __ffsll((long long)todo) - 1);
+            return __ballot(wn > 0 && incl - base <= 64 * PP);
+        };
+        int n_rounds = 0;                                             // first pass: how many rounds
+        {
+            int left = my_n;
+            for (int cls = 0; cls < 2; ++cls)
+                for (;;) {
+                    int wn, excl, base = 0;
+                    const unsigned long long sel = next_round(cls, left, wn, excl, base);
+                    if (sel == 0ull) break;
+                    if ((sel >> lane) & 1ull) left = 0;
+                    ++n_rounds;
+                }
+        }
+        // their records: one allocation in this XCD's list (L2-local atomic, like the candidate lists)
+        const int round_cap = round_segment_capacity(P.N);
+        const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));
+        int at = 0;
+        if (n_rounds > 0) {
+            if (lane == 0) at = atomicAdd(S.w_nround + xcd * XCD_STRIDE, n_rounds);
+            at = __builtin_amdgcn_readfirstlane(at);
+        }
+        const bool inline_dp = at + n_rounds > round_cap;             // list full: approximate here (never changes results)
+        uint8_t* const rec0 = S.w_round + ((size_t)xcd * round_cap + at) * ROUND_BYTES;
         int left = my_n, n_dp = 0;
         for (int cls = 0; cls < 2; ++cls)
         for (;;) {
-            int wn = (cls == 0 ? left <= TRACE_SHORT : true) ? left : 0;
-            const int incl = wave_inclusive_sum(wn), excl = incl - wn;
-            if (__builtin_amdgcn_readlane(incl, 63) == 0) break;
-            const unsigned long long todo = __ballot(wn > 0);
-            const int firstl = __ffsll((long long)todo) - 1;
-            const int base = __builtin_amdgcn_readlane(excl, firstl);
-            const unsigned long long sel = __ballot(wn > 0 && incl - base <= 64 * PP);
+            int wn, excl, base = 0;
+            const unsigned long long sel = next_round(cls, left, wn, excl, base);
+            if (sel == 0ull) break;
             // which border does the point at position q = u * 64 + lane belong to: border lanes drop their id at
             // the position of their first point, a running maximum over the positions spreads it
 #pragma unroll
@@ -1331,9 +1362,27 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
                 if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
                 pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
             }
-            approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+            if (inline_dp) {
+                approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+            } else {
+                uint8_t* const rec = rec0 + (size_t)n_dp * ROUND_BYTES;       // [pts | n | sb][64 * PP] bytes, then rk words
+#pragma unroll
+                for (int u = 0; u < PP; ++u) {
+                    const int q = u * 64 + lane;
+                    rec[q] = (uint8_t)pv[u];
+                    rec[64 * PP + q] = (uint8_t)(live[u] ? nn[u] : 0);         // 0: no point at this position
+                    rec[2 * 64 * PP + q] = (uint8_t)sbq[u];
+                    ((uint32_t*)(rec + 3 * 64 * PP))[q] = (uint32_t)prk[u];
+                }
+            }
             if ((sel >> lane) & 1ull) left = 0;
             ++n_dp;
+        }
+        if (inline_dp && n_rounds > 0 && at < round_cap) {            // reserved but unused slots of a full list: no points
+            const int lim = at + n_rounds < round_cap ? n_rounds : round_cap - at;
+            for (int i = 0; i < lim; ++i)
+#pragma unroll
+                for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
         }
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
             const int b0 = (int)(S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW] >> 16);
@@ -1345,6 +1394,59 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
             row[14] = t_end - t_traced;
             row[15] = 1 | ((long long)n_dp << 20) | ((long long)(count - (chunk - first_chunk) * TRACE_CPW < TRACE_CPW ? count - (chunk - first_chunk) * TRACE_CPW : TRACE_CPW) << 40);
         }
+        IRBPP_WAVE_SYNC();
+    }
+}
+
+// Split pipeline, after the trace kernel: approxPolyDP + find_convex_vetex of one round of borders per wave
+// (approx_convex_segmented on the 64 * TRACE_P contour points of a record); vertex bits go to the bins' rows in
+// global memory with one atomic OR each.  The rounds of the eight lists are numbered through like the chunks of
+// the trace kernel; every round is the same amount of work, so the waves finish together.
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_polygon_kernel(const Params P, const State S) {
+    constexpr int PP = TRACE_P;
+    __shared__ uint32_t dps[64 * PP];
+    __shared__ uint8_t dpscratch[64 * PP];
+    __shared__ __attribute__((aligned(16))) uint8_t lpts[64 * PP];
+    const int lane = threadIdx.x;
+    const int round_cap = round_segment_capacity(P.N);
+    int seg_n[NXCD], seg_first[NXCD + 1];
+    seg_first[0] = 0;
+#pragma unroll
+    for (int s = 0; s < NXCD; ++s) {
+        const int n = S.w_nround[s * XCD_STRIDE];
+        seg_n[s] = n < round_cap ? n : round_cap;
+        seg_first[s + 1] = seg_first[s] + seg_n[s];
+    }
+    for (int rd = blockIdx.x; rd < seg_first[NXCD]; rd += gridDim.x) {
+        int seg = 0;
+#pragma unroll
+        for (int s = 1; s < NXCD; ++s) seg += rd >= seg_first[s] ? 1 : 0;
+        int first = 0;
+#pragma unroll
+        for (int s = 0; s < NXCD; ++s) if (s == seg) first = seg_first[s];
+        const uint8_t* const rec = S.w_round + ((size_t)seg * round_cap + (rd - first)) * ROUND_BYTES;
+        bool live[PP];
+        int pv[PP], jj[PP], nn[PP], sbq[PP], prk[PP];
+        const uint8_t* pts[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int q = u * 64 + lane;
+            pv[u] = rec[q];
+            nn[u] = rec[64 * PP + q];
+            sbq[u] = rec[2 * 64 * PP + q];
+            prk[u] = (int)((const uint32_t*)(rec + 3 * 64 * PP))[q];
+            lpts[q] = (uint8_t)pv[u];
+        }
+        IRBPP_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            live[u] = nn[u] > 0;
+            jj[u] = u * 64 + lane - sbq[u];
+            if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; pv[u] = 0; }
+            pts[u] = lpts + sbq[u];
+        }
+        approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
         IRBPP_WAVE_SYNC();
     }
 }
