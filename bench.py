@@ -2,7 +2,7 @@
 """bench.py -- placement-steps/s of the batched packing environment on N MI355X.
 
 One "step" = one batched transition of every bin on this rank: the transition kernel applies the
-actions (placement, reward, termination, auto-reset), the trace and emit kernels produce the next
+actions (placement, reward, termination, auto-reset), the trace, polygon and emit kernels produce the next
 observation and, fused into the emit kernel, the scripted MINZ policy's action on it.  Inputs
 (shape tables, trajectories, heightmaps, observations) are resident in HBM before the timed
 region; nothing crosses PCIe inside it.
@@ -388,8 +388,8 @@ def main():
 
     if rank == 0:
         total_steps = a.bins * world * a.steps
-        # Roofline on the whole step: the transition is three kernels per group and the groups overlap, so no single
-        # launch duration prices the step's algorithmic bytes; its wall time (policy kernel and gaps included) does
+        # Roofline on the whole step: the transition is four kernels per group and the groups overlap, so no single
+        # launch duration prices the step's algorithmic bytes; its wall time (gaps included) does
         achieved = bps * a.bins / (elapsed / a.steps) / 1e9
         prof, why = pmc_profile(a.workload)
         traffic, issue = None, None
@@ -413,8 +413,9 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "basis": "algorithmic bytes of one step of this rank's bins / wall time of one step",
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "lds_bytes_per_workgroup": lds_bytes,
-                         "kernel_note": "kernel_ms = HIP events around each group's transition (transition + trace + emit "
-                                        "kernels) on its stream, summed over the groups; the groups overlap on the chip",
+                         "kernel_note": "a step is four kernels (transition, trace, polygon, emit), none of which carries the "
+                                        "step's bytes alone: kernel_ms = HIP events around the four on their stream (summed "
+                                        "over the groups), and `achieved` prices the step's algorithmic bytes on its wall time",
                          "algorithmic_bytes_per_step": bps},
             "episodes": {"finished_in_timed_region": finished, "finished_since_reset": float(tot[0]),
                          "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,

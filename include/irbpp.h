@@ -257,6 +257,8 @@ int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
 #define IRBPP_DEVERR_TRACE_GUARD   2   /* border following exceeded its iteration guard      */
 #define IRBPP_DEVERR_BAD_ITEM      4   /* item id outside the loaded shape table             */
 #define IRBPP_DEVERR_BAD_BIN       8   /* irbpp_reset_bins: bin index outside [0, num_bins)  */
+#define IRBPP_DEVERR_CAPACITY     16   /* a die's candidate list overflowed (it holds twice the worst case of a fair
+                                          share of the bins): results of that step are incomplete                */
 
 #ifdef __cplusplus
 }

@@ -213,6 +213,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
+    P.wimg = P.R * 64;
+    P.seg_cap = 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;
+    P.round_cap = (P.N / NXCD + 64) * 16;
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes_full > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
@@ -233,13 +236,13 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_posz, N * P.R * P.AC);
     ALLOC(w_vmask, N * P.R * 16);
     ALLOC(w_meta, N * WMETA);
-    ALLOC(w_img, N * WIMG * 32);
-    ALLOC(w_imgrot, N * WIMG);
-    ALLOC(w_cand, (size_t)NXCD * flat_segment_capacity(P.N));
+    ALLOC(w_img, N * P.wimg * 32);
+    ALLOC(w_imgrot, N * P.wimg);
+    ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
     ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
-    ALLOC(w_round, (size_t)NXCD * round_segment_capacity(P.N) * ROUND_BYTES);
+    ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     env->reorder = !P.split;               // the split pipeline's transition kernel is uniform enough: ordering buys nothing (measured)

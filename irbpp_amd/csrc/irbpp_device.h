@@ -26,16 +26,11 @@ constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 // words each; R * 64 are possible in theory) and WCAND candidate start pixels per bin; a bin that exceeds
 // either resolves its contours inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
 // several bins per wave, which is what keeps its lanes busy: one bin alone has ~25 borders to follow.
-constexpr int WIMG = 256, WCAND = 1024, WMETA = 8;
+constexpr int WMETA = 8;
 constexpr int NXCD = 8;                            // accelerator dies of the MI355X: one flat candidate list each
 constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each
-// Capacity of one XCD's flat candidate list: a fair share of the bins' worst case plus room for an uneven share.  A
-// bin whose batch does not fit resolves its contours inside the transition kernel, so the capacity never changes results.
-__host__ __device__ constexpr int flat_segment_capacity(int n_bins) { return (n_bins / NXCD + 64) * 128; }
-// Round records of the polygon kernel (one per 128 contour points): capacity of one XCD's list, bytes of a record
-// ([points | border length | border start] per position, then the vertex-row index of the position's border).
-__host__ __device__ constexpr int round_segment_capacity(int n_bins) { return flat_segment_capacity(n_bins) / 8; }
-constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;
+constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;   // a round record of the polygon kernel: [points | border length | border
+                                                                     // start] per position, then the vertex-row index of the position's border
 constexpr int MAX_BINS = 32768;                   // bins per device: a flat-list entry has 15 bits for the bin (irbpp_create refuses more)
 
 struct ShapeRot {
@@ -112,12 +107,12 @@ struct State {
     double* w_posz;        // [N][R*AC] posZValid of the observed item
     uint32_t* w_vmask;     // [N][R*16] vertex bits: isolated pixels from the transition kernel, the rest from the trace kernel
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
-    uint16_t* w_img;       // [N][WIMG][32] level images: 16 row words then 16 column words
-    uint8_t* w_imgrot;     // [N][WIMG] rotation of each level image
-    uint32_t* w_cand;      // [NXCD][flat_segment_capacity(N)] flat lists of the launch's candidate starts, in arrival order:
-                           // bin<<16 | image<<8 | y0<<4 | x0
+    uint16_t* w_img;       // [N][wimg][32] level images: 16 row words then 16 column words
+    uint8_t* w_imgrot;     // [N][wimg] rotation of each level image
+    uint32_t* w_cand;      // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
+                           // bin<<17 | image<<8 | y0<<4 | x0
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
-    uint8_t* w_round;      // [NXCD][round_segment_capacity(N)][ROUND_BYTES] round records, trace kernel -> polygon kernel
+    uint8_t* w_round;      // [NXCD][round_cap][ROUND_BYTES] round records, trace kernel -> polygon kernel
     int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list
     int32_t* w_total;      // [NXCD * XCD_STRIDE] candidates in each XCD's list (XCD-local atomicAdd in the transition kernel, zeroed by the emit kernel)
 };
@@ -153,6 +148,9 @@ struct Params {
     // 16 whole contour stage.
     int32_t dbg_repeat;
     int32_t split;         // 1: transition kernel -> trace kernel -> emit kernel; 0: everything in the transition kernel
+    int32_t wimg;          // level images a bin can hand over: R * 64
+    int32_t seg_cap;       // entries of one XCD's flat candidate list: twice the worst case (R*AC per bin) of its share of the bins
+    int32_t round_cap;     // round records of one XCD's list (a full list makes the trace kernel approximate in place)
     int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
 };
 

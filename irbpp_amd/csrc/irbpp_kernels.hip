@@ -143,16 +143,41 @@ __device__ __forceinline__ KernArgsPtr cold_args() {
 
 __device__ __forceinline__ uint32_t div_magic_dev(int d) { return d >= 2 ? (uint32_t)(0x100000000ull / (uint64_t)d + 1ull) : 0u; }
 
-// heightmap cell (row, col) / linear heightmap index (row*Hy + col) -> LDS tile index in the phase-plane layout
-__device__ __forceinline__ int tile_rc(const Params& P, int row, int col) {
-    const int qr = fdiv(row, P.pp, P.mg_pp), mr = row - qr * P.pp;
-    const int qc = fdiv(col, P.pp, P.mg_pp), mc = col - qc * P.pp;
-    return (mr * P.pp + mc) * P.PL + qr * P.LY + qc;
+// heightmap cell (row, col) / linear heightmap index (row*Hy + col) -> LDS tile index in the phase-plane layout.
+// The index is a sum of a row part and a column part, so loops over rows x columns compute each part once.
+__device__ __forceinline__ int tile_row_part(const Params& P, int row) {
+    const int q = fdiv(row, P.pp, P.mg_pp);
+    return (row - q * P.pp) * P.pp * P.PL + q * P.LY;
 }
+__device__ __forceinline__ int tile_col_part(const Params& P, int col) {
+    const int q = fdiv(col, P.pp, P.mg_pp);
+    return (col - q * P.pp) * P.PL + q;
+}
+__device__ __forceinline__ int tile_rc(const Params& P, int row, int col) { return tile_row_part(P, row) + tile_col_part(P, col); }
 __device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
     const int row = fdiv(g, P.Hy, P.mg_hy);
     return tile_rc(P, row, g - row * P.Hy);
 }
+// Walk of the whole heightmap by the workgroup, element i = tid + k*BLOCK of the row-major map: when BLOCK is a
+// multiple of Hy the column of a thread's elements never changes and its row advances by BLOCK/Hy per trip.
+struct TileWalk {
+    int col_part, row, row_step, lin;
+    bool regular;
+};
+__device__ __forceinline__ TileWalk tile_walk_begin(const Params& P, int tid) {
+    TileWalk w;
+    const int row = fdiv(tid, P.Hy, P.mg_hy), col = tid - row * P.Hy;
+    w.regular = BLOCK % P.Hy == 0;
+    w.row = row;
+    w.row_step = BLOCK / P.Hy;
+    w.col_part = tile_col_part(P, col);
+    w.lin = tid;
+    return w;
+}
+__device__ __forceinline__ int tile_walk_index(const Params& P, const TileWalk& w) {      // tile index of element w.lin
+    return w.regular ? tile_row_part(P, w.row) + w.col_part : tile_of_linear(P, w.lin);
+}
+__device__ __forceinline__ void tile_walk_next(TileWalk& w) { w.lin += BLOCK; w.row += w.row_step; }
 // footprint cell `ij` (i | j << 16) of an item whose corner sits on action cell (lx, ly)
 __device__ __forceinline__ int tile_of_cell(const Params& P, int lx, int ly, int ij) {
     return tile_rc(P, lx * P.step + (ij & 0xFFFF), ly * P.step + (ij >> 16));
@@ -556,8 +581,15 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
             double m = -1e300;
-            for (int i = 0; i < P.block_b; ++i)
-                for (int j = 0; j < P.block_b; ++j) m = fmax(m, L.hm[tile_rc(P, pi * P.step + i, pj * P.step + j)]);
+            int colp[8];                                     // block_b <= 8 (irbpp_load_shapes)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) colp[j] = j < P.block_b ? tile_col_part(P, pj * P.step + j) : 0;
+            for (int i = 0; i < P.block_b; ++i) {
+                const double* rowp = L.hm + tile_row_part(P, pi * P.step + i);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (j < P.block_b) m = fmax(m, rowp[colp[j]]);
+            }
             L.mb[t] = m;
         }
     }
@@ -818,7 +850,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
     if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
-    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)L.hm[tile_of_linear(P, i)];
+    for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) obs[5 * P.S + 9 + w.lin] = (float)L.hm[tile_walk_index(P, w)];
     __syncthreads();
     stamp(io, b, 2);
 
@@ -1060,26 +1092,24 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
 
 // ---------------------------------------------------------------------------------------
 // Split pipeline, hand-over of one bin from the transition kernel: level images, candidate starts, the
-// vertex bits of isolated pixels, posZValid and the scalars of the observation go to global memory for
-// the trace and emit kernels.  A bin with more level images or candidates than the hand-over holds
-// (speckled height fields) resolves its contours right here instead and hands over nothing to trace.
+// vertex bits of isolated pixels and the scalars of the observation go to global memory for the trace and
+// emit kernels (posZValid is there already).  The hand-over holds whatever a bin can produce: a rotation has at
+// most 64 levels, and every candidate start is a pixel of exactly one level image of its rotation, so a bin has at
+// most R*64 images and R*AC candidates; an XCD's candidate list holds twice the worst case of its share of the bins
+// (IRBPP_DEVERR_CAPACITY if the dispatcher ever gave one die more than twice its share of such bins).
 // ---------------------------------------------------------------------------------------
 __device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid) {
     const int tid = threadIdx.x;
     const KernArgsPtr ka = cold_args();
     const int ntasks = contour_tasks(P, L);
-    int nimg = 0, ncand = 0;
-    bool here = ntasks > WIMG;
-    uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * WIMG * 32);
-    uint8_t* gr = ka->S.w_imgrot + (size_t)b * WIMG;
+    int ncand = 0;
+    uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 32);
+    uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
     const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
-    const int seg_cap = flat_segment_capacity(P.N);
-    for (int base = 0; base < ntasks && !here; base += CONTOUR_IMGS) {       // one batch of level images at a time
+    for (int base = 0; base < ntasks; base += CONTOUR_IMGS) {                // one batch of level images at a time
         contour_images(P, L, base);
         uint32_t my_cand[CONTOUR_IPT];
         const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
-        if (batch_total > CONTOUR_CLIST || ncand + batch_total > WCAND) { here = true; break; }
-        const int total = contour_list(L, my_cand, 1, 0);
         const int nb = ntasks - base < CONTOUR_IMGS ? ntasks - base : CONTOUR_IMGS;
         // rows [IMGS][16] and columns [IMGS][16] in LDS -> [image][16 rows | 16 columns] in global, as dwords
         const uint32_t* lr = (const uint32_t*)L.img;
@@ -1089,42 +1119,39 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
             gi[(size_t)base * 16 + i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
         }
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
-        // The candidates join a flat list (bin<<16 | image<<8 | y0<<4 | x0), one allocation per batch, in whatever
-        // order the bins arrive -- the trace kernel's results do not depend on it.  One list per XCD: the line of a
-        // counter that only the workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide
-        // counter travels between the eight L2s with every allocation (measured: +22 us per launch).
-        if (tid == 0) {
-            int at = 0;
-            if (total > 0) {
-                at = atomicAdd(ka->S.w_total + xcd * XCD_STRIDE, total);
-                if (at + total > seg_cap) at = -1;                 // this XCD's list is full: resolve the contours here
+        // The candidates join a flat list (bin<<17 | image<<8 | y0<<4 | x0), in whatever order the bins arrive -- the
+        // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
+        // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
+        // between the eight L2s with every allocation (measured: +22 us per launch).  The LDS list holds CLIST
+        // entries; a batch with more candidates (speckle) goes image by image (an image has at most 64).
+        const int nsub = batch_total <= CONTOUR_CLIST ? 1 : CONTOUR_IMGS;
+        for (int sub = 0; sub < nsub; ++sub) {
+            const int total = contour_list(L, my_cand, nsub, sub);
+            if (tid == 0) {
+                int at = 0;
+                if (total > 0) {
+                    at = atomicAdd(ka->S.w_total + xcd * XCD_STRIDE, total);
+                    if (at + total > P.seg_cap) { atomicOr(S.err, IRBPP_DEVERR_CAPACITY); at = -1; }
+                }
+                L.redi[11] = at;
             }
-            L.redi[11] = at;
-        }
-        __syncthreads();
-        if (L.redi[11] < 0) { here = true; break; }
-        {
-            uint32_t* flat = ka->S.w_cand + (size_t)xcd * seg_cap + L.redi[11];
-            for (int i = tid; i < total; i += BLOCK) {
-                const uint32_t e = L.clist[i];
-                flat[i] = ((uint32_t)b << 16) | ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u);
+            __syncthreads();
+            if (L.redi[11] >= 0) {
+                uint32_t* flat = ka->S.w_cand + (size_t)xcd * P.seg_cap + L.redi[11];
+                for (int i = tid; i < total; i += BLOCK) {
+                    const uint32_t e = L.clist[i];
+                    flat[i] = ((uint32_t)b << 17) | ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u);
+                }
             }
+            ncand += total;
         }
-        ncand += total;
-        nimg = base + nb;
         __syncthreads();                             // the next batch rebuilds the images and the list
-    }
-    if (here) {
-        nimg = ncand = 0;
-        __syncthreads();
-        contour_stage(P, S, L, nullptr);             // vertex bits of isolated pixels set above are simply set again
-        __syncthreads();
     }
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
     for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
-        m[0] = nimg;
+        m[0] = ntasks;
         m[1] = ncand;
         m[2] = nvalid;
         m[3] = item;
@@ -1227,7 +1254,7 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
     __shared__ uint8_t dpscratch[64 * PP];
     const int lane = threadIdx.x;
     // the eight lists, one after the other, cut into chunks of TRACE_CPW candidates (a list's last chunk may be short)
-    const int seg_cap = flat_segment_capacity(P.N);
+    const int seg_cap = P.seg_cap;
     int seg_n[NXCD], seg_first[NXCD + 1];                                    // candidates of list s, its first chunk
     seg_first[0] = 0;
 #pragma unroll
@@ -1253,11 +1280,11 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
         uint8_t* const my_slot = slots + lane * SLOT;
         if (have) {
             const uint32_t e = S.w_cand[g];
-            const int b = (int)(e >> 16), img = (int)((e >> 8) & 255u);
+            const int b = (int)(e >> 17), img = (int)((e >> 8) & 511u);
             x0 = e & 15u;
             y0 = (e >> 4) & 15u;
-            rk = b * P.R + (int)S.w_imgrot[(size_t)b * WIMG + img];
-            const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * WIMG + img) * 32);
+            rk = b * P.R + (int)S.w_imgrot[(size_t)b * P.wimg + img];
+            const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * P.wimg + img) * 32);
             uint32_t* li = (uint32_t*)im;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -1317,7 +1344,7 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
                 }
         }
         // their records: one allocation in this XCD's list (L2-local atomic, like the candidate lists)
-        const int round_cap = round_segment_capacity(P.N);
+        const int round_cap = P.round_cap;
         const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));
         int at = 0;
         if (n_rounds > 0) {
@@ -1385,7 +1412,7 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
                 for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
         }
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
-            const int b0 = (int)(S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW] >> 16);
+            const int b0 = (int)(S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW] >> 17);
             long long* row = prof + (size_t)b0 * PHASE_ROW;
             const long long t_end = (long long)clock64();
             row[11] = t_end - t_start;
@@ -1409,7 +1436,7 @@ irbpp_polygon_kernel(const Params P, const State S) {
     __shared__ uint8_t dpscratch[64 * PP];
     __shared__ __attribute__((aligned(16))) uint8_t lpts[64 * PP];
     const int lane = threadIdx.x;
-    const int round_cap = round_segment_capacity(P.N);
+    const int round_cap = P.round_cap;
     int seg_n[NXCD], seg_first[NXCD + 1];
     seg_first[0] = 0;
 #pragma unroll
@@ -1454,14 +1481,18 @@ irbpp_polygon_kernel(const Params P, const State S) {
 // ---------------------------------------------------------------------------------------
 // The environment transition kernel: one workgroup per bin.
 // ---------------------------------------------------------------------------------------
-// Two builds of one body.  irbpp_env_kernel is held to 80 VGPRs (six waves per SIMD): used when the
-// LDS layout lets six workgroups share a CU (R <= 4 on a 32x32 heightmap).  With larger layouts LDS
-// caps the CU at four or five workgroups anyway and irbpp_env_kernel_wide lets the register
-// allocator have what it wants (+8 % on the R=8 "general" workload).
+// Two builds of one body.  irbpp_env_kernel is held to 64 VGPRs (eight waves per SIMD, eight workgroups per CU:
+// 4096 bins are exactly two rounds of the chip): the block path of lattice data, whose per-bin work is short and
+// latency-bound (measured 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups per CU).  irbpp_env_kernel_wide lets
+// the register allocator have what it wants: the generic path, whose inner loop keeps eight float64 accumulators
+// and a chunk of scalar operands live (see use_wide_kernel in irbpp_capi.hip).
 __device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
-extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(6, 6)))
+#ifndef IRBPP_ENV_WAVES
+#define IRBPP_ENV_WAVES 8
+#endif
+extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRBPP_ENV_WAVES, IRBPP_ENV_WAVES)))
 irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     env_transition(P, T, S, io, mode, smem);
@@ -1502,7 +1533,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;
             __syncthreads();
         }
-        for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
+        for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) L.hm[tile_walk_index(P, w)] = ghm[w.lin];
     }
     __syncthreads();
 

@@ -237,7 +237,7 @@ class GpuPackingEnv(object):
         lds, wide = C.c_int32(0), C.c_int32(0)
         _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(wide)), "irbpp_debug_kernel_info")
         name = "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
-        return lds.value, name + " + irbpp_trace_kernel + irbpp_emit_kernel"
+        return lds.value, name + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
 
     def enable_kernel_timing(self, capacity: int) -> None:
         """Tooling: bracket the transition kernel of the next ``capacity`` launches with HIP events

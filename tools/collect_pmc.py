@@ -5,9 +5,11 @@ the kernel sources they were taken on (bench.py quotes them only while that hash
     python tools/collect_pmc.py <dir with fetch/ write/ sq/ [sq2/] sub-directories> <workload> <bins> [<git rev>]
 
 Each sub-directory holds the counter_collection.csv of ONE pass (MI355X_MICROARCH.md: FETCH_SIZE and
-WRITE_SIZE do not fit one pass; SQ has eight slots).  HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE
-(KB -> bytes): gfx950's FETCH_SIZE reports half the bytes of wide coalesced reads (same guide, HBM section);
-the policy kernel, whose read volume is known exactly, is kept as the calibration of that factor."""
+WRITE_SIZE do not fit one pass; SQ has eight slots).  A step is four kernels (transition, trace, polygon,
+emit), each launched once per step: per-step figures are sums of the kernels' per-launch averages over the
+second half of the run (prefill and warm-up dropped).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes):
+gfx950's FETCH_SIZE reports half the bytes of wide coalesced reads (same guide, HBM section); the emit kernel,
+whose reads and writes per bin are known exactly, is kept as the calibration of both factors."""
 import collections
 import csv
 import glob
@@ -21,6 +23,7 @@ from irbpp_amd.build import source_hash  # noqa: E402
 
 src, workload, bins = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rev = sys.argv[4] if len(sys.argv) > 4 else ""
+STEP_KERNELS = ("irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel")
 
 
 def agg(sub):
@@ -29,12 +32,21 @@ def agg(sub):
         with open(path) as f:
             for r in csv.DictReader(f):
                 d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    summ = os.path.join(src, sub + "_summary.json")          # written by tools/gpu_profile.sh when the CSV was too large to keep
+    if not d and os.path.exists(summ):
+        for k, cs in json.load(open(summ)).items():
+            for c, v in cs.items():
+                d[k][c] = [v["avg_second_half"]] * 2
     return d
 
 
 def tail_avg(v):
-    v = v[len(v) // 2:]              # the timed half: prefill and warm-up launches dropped
+    v = v[len(v) // 2:]
     return sum(v) / len(v)
+
+
+def step_kernels(d):
+    return [k for k in d if k.startswith(STEP_KERNELS)]
 
 
 out_path = os.path.join(ROOT, "profiles", "pmc_hbm.json")
@@ -42,36 +54,49 @@ doc = json.load(open(out_path)) if os.path.exists(out_path) else {}
 if doc.get("kernel_source_sha") != source_hash():
     doc = {"kernel_source_sha": source_hash(), "git_rev": rev, "workloads": {}}
 f, w = agg("fetch"), agg("write")
-env = [k for k in f if k.startswith("irbpp_env_kernel")][0]
-pol = [k for k in f if "policy" in k]
-fk, wk = tail_avg(f[env]["FETCH_SIZE"]), tail_avg(w[env]["WRITE_SIZE"])
-entry = {"bins": bins, "kernel": env, "FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk,
-         "hbm_bytes_per_launch": (2 * fk + wk) * 1024,
-         "hbm_bytes_per_bin_step": (2 * fk + wk) * 1024 / bins,
+per_kernel = {}
+for k in step_kernels(f):
+    fk = tail_avg(f[k]["FETCH_SIZE"])
+    wk = tail_avg(w[k]["WRITE_SIZE"]) if k in w else 0.0
+    per_kernel[k] = {"FETCH_SIZE_KB_avg": fk, "WRITE_SIZE_KB_avg": wk, "hbm_bytes_per_launch": (2 * fk + wk) * 1024}
+total = sum(v["hbm_bytes_per_launch"] for v in per_kernel.values())
+entry = {"bins": bins, "kernels": per_kernel, "hbm_bytes_per_launch": total, "hbm_bytes_per_bin_step": total / bins,
+         "note": "hbm_bytes_per_launch = one step = one launch of each of the listed kernels",
          "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --bins %d --workload %s "
                     "--no-cpu-baseline --no-extra (each counter group in its own pass)" % (bins, workload)}
-if pol:
-    entry["calibration"] = {"policy_kernel_FETCH_SIZE_KB": tail_avg(f[pol[0]]["FETCH_SIZE"]),
-                            "policy_kernel_true_read_bytes": bins * 2500 * 4,
-                            "note": "the policy kernel reads every 128-B line of the [bins][2500] f32 candidate block"}
-sq = {}
+if "irbpp_emit_kernel" in per_kernel and len(sys.argv) > 5:
+    r_ac, sel = int(sys.argv[5]), 500
+    true_r, true_w = bins * (r_ac * 8 + r_ac // 16 * 4 + 32), bins * (5 * sel * 4 + sel * 4 + 4)
+    e = per_kernel["irbpp_emit_kernel"]
+    entry["calibration"] = {"kernel": "irbpp_emit_kernel", "true_read_bytes": true_r, "true_write_bytes": true_w,
+                            "two_x_FETCH_SIZE_over_true_reads": 2 * e["FETCH_SIZE_KB_avg"] * 1024 / true_r,
+                            "WRITE_SIZE_over_true_writes": e["WRITE_SIZE_KB_avg"] * 1024 / true_w}
+sq = collections.defaultdict(dict)
 for sub in ("sq", "sq2"):
-    for c, v in agg(sub).get(env, {}).items():
-        sq[c] = tail_avg(v)
+    d = agg(sub)
+    for k in step_kernels(d):
+        for c, v in d[k].items():
+            sq[k][c] = tail_avg(v)
 if sq:
     entry["sq_per_launch_avg"] = sq
-    wc = sq.get("SQ_WAVE_CYCLES")
+    tot = collections.defaultdict(float)
+    for k, cs in sq.items():
+        for c, v in cs.items():
+            tot[c] += v
+    wc = tot.get("SQ_WAVE_CYCLES")
     if wc:
-        entry["issue"] = {k2: sq[k1] / wc for k1, k2 in (("SQ_ACTIVE_INST_VALU", "valu_share_of_wave_cycles"),
-                                                          ("SQ_ACTIVE_INST_SCA", "salu_share_of_wave_cycles"),
-                                                          ("SQ_ACTIVE_INST_LDS", "lds_share_of_wave_cycles"),
-                                                          ("SQ_WAIT_ANY", "wait_share_of_wave_cycles"),
-                                                          ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"))
-                          if k1 in sq}
-        if "SQ_INSTS_VALU" in sq:
-            entry["issue"]["valu_insts_per_bin_step"] = sq["SQ_INSTS_VALU"] / bins
-        if "SQ_INSTS_SALU" in sq:
-            entry["issue"]["salu_insts_per_bin_step"] = sq["SQ_INSTS_SALU"] / bins
+        entry["issue"] = {k2: tot[k1] / wc for k1, k2 in (("SQ_ACTIVE_INST_VALU", "valu_share_of_wave_cycles"),
+                                                           ("SQ_ACTIVE_INST_SCA", "salu_share_of_wave_cycles"),
+                                                           ("SQ_ACTIVE_INST_LDS", "lds_share_of_wave_cycles"),
+                                                           ("SQ_WAIT_ANY", "wait_share_of_wave_cycles"),
+                                                           ("SQ_WAIT_INST_ANY", "issue_stall_share_of_wave_cycles"))
+                          if k1 in tot}
+        if "SQ_INSTS_VALU" in tot:
+            entry["issue"]["valu_insts_per_bin_step"] = tot["SQ_INSTS_VALU"] / bins
+        if "SQ_INSTS_SALU" in tot:
+            entry["issue"]["salu_insts_per_bin_step"] = tot["SQ_INSTS_SALU"] / bins
+        entry["issue"]["per_kernel_wait_share"] = {k: cs["SQ_WAIT_ANY"] / cs["SQ_WAVE_CYCLES"] for k, cs in sq.items()
+                                                   if "SQ_WAIT_ANY" in cs and cs.get("SQ_WAVE_CYCLES")}
 doc["workloads"][workload] = entry
 json.dump(doc, open(out_path, "w"), indent=1)
-print(json.dumps(entry, indent=1))
+print(json.dumps(entry, indent=1)[:3000])

@@ -11,6 +11,7 @@ mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --workload $WL --no-cpu-baseline --no-extra"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o r02 -- $B --steps 200 --warmup 20 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+python $R/tools/kernel_trace_summary.py "$OUT/kt" 200 --rm > "$OUT/kernel_trace_timed_region.json"
 P="$B --bins $BINS --steps 60 --warmup 10 --prefill 150"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r02 -- $P > "$OUT/bench_pmc_fetch.json" 2> "$OUT/fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o r02 -- $P > /dev/null 2> "$OUT/write.err"
