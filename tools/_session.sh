@@ -1,15 +1,16 @@
-O=gpurun_out/r2k; mkdir -p $O
+O=gpurun_out/r2l; mkdir -p $O
 R=$PWD
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
 tail -5 $O/pytest_gpu.txt
-timeout 900 python bench.py > $O/bench_default.json 2>$O/bench_default.err; tail -c 1800 $O/bench_default.json
-for wl in general abc_fine blockout_r8 cube blockout_k10; do
-timeout 600 python bench.py --no-cpu-baseline --no-extra --workload $wl > $O/bench_$wl.json 2>/dev/null
-python -c "
-import json; d=json.load(open('$O/bench_$wl.json')); print('$wl value', round(d['value']), 'ms', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4))"
-done
-bash tools/gpu_profile.sh r2k/prof blockout 16384 2>&1 | tail -3
-cat $O/prof/kernel_trace_timed_region.json | head -40
-timeout 300 python tools/vecenv_throughput.py > $O/vecenv.txt 2>&1; tail -1 $O/vecenv.txt
-timeout 300 python tools/phase_profile.py > $O/phase_blockout.json 2>/dev/null; python -c "
-import json; d=json.load(open('$O/phase_blockout.json')); print(d['split_pipeline'])"
+run() { # name workload env...
+  n=$1; wl=$2; shift 2
+  env "$@" timeout 600 python bench.py --no-cpu-baseline --no-extra --workload $wl > $O/bench_$n.json 2>$O/bench_$n.err || tail -3 $O/bench_$n.err
+  python -c "
+import json; d=json.load(open('$O/bench_$n.json')); print('$n value', round(d['value']), 'ms', round(d['ms_per_step'],4), 'kernel_ms', round(d['roofline']['kernel_ms'],4), 'lds', d['roofline']['lds_bytes_per_workgroup'])"
+}
+run blockout blockout A=1
+run blockout_w7 blockout IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_w7.so
+run blockout_w6 blockout IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_w6.so
+run blockout_b blockout A=1
+run general general A=1
+run k10 blockout_k10 A=1
