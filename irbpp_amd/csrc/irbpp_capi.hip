@@ -121,15 +121,14 @@ void layout_lds(Params& P) {
     P.lds_bytes = off;
     P.o_posz = off;                                    // only the heuristic kernel keeps posZValid in LDS
     P.lds_bytes_full = off + align16(P.R * P.AC * 8);
-    // emit kernel: posZValid, vertex bits, reductions, the radix-select counters, candidate keys + selected keys
+    // emit kernel: vertex bits, reductions, the radix-select counters / sort keys / row values, candidate keys + selected keys
     int32_t e = 0;
-    P.e_posz = e;   e += align16(P.R * P.AC * 8);
     P.e_vmask = e;  e += align16(P.R * 16 * 4);
     P.e_red = e;    e += 256;
     {   // 256 radix counters, later the sort keys of the selected rows: 10 bytes per entry of the next power of two
         int32_t npad = 64;
         while (npad < P.S) npad <<= 1;
-        P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);
+        P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);       // >= 4 * S bytes for the rows' values too
     }
     P.e_keys = e;   e += align16(keys);
     P.emit_lds_bytes = e;

@@ -87,7 +87,9 @@ struct alignas(64) BinState {
     int32_t traj_row;      // row of the current episode's trajectory in seq: (traj_start + g + e*G) mod n_traj
     double ratio_acc;      // sequential sum of packed volumes (get_ratio, binPhy.py:149-153)
     double ep_reward;      // sequential sum of rewards (Monitor 'r')
-    double pad1[2];
+    int32_t nrows;         // candidate rows of the last location observation (entries of `cand` that are current)
+    int32_t pad0;
+    double pad1[1];
 };
 
 struct State {
@@ -133,7 +135,7 @@ struct Params {
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red, o_dps;
     int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;   // lds_bytes: transition kernel (no posZValid region)
     int32_t lds_bytes_full;   // + posZValid at o_posz: heuristic kernel
-    int32_t e_posz, e_vmask, e_red, e_hist, e_keys, emit_lds_bytes;   // the emit kernel's own carve-up
+    int32_t e_vmask, e_red, e_hist, e_keys, emit_lds_bytes;   // the emit kernel's own carve-up
     int32_t big_slot_bytes;   // bytes of the scratch region the serial redo of an oversized border may use
     // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid

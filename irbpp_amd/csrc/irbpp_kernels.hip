@@ -833,7 +833,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
 }
 
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
-                                        int nvalid, float* obs);
+                                        int nvalid, float* obs, const double* zsrc);
 __device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid);
 
 // ---------------------------------------------------------------------------------------
@@ -869,7 +869,8 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
 // everything: (1) radix select on the order-preserving 64-bit image of the float64 values finds the
 // want-th smallest value T in eight histogram rounds, (2) the elements below T plus the first few equal to
 // T are compacted in position order, (3) only those `want` elements are sorted.
-// Element e is the candidate key(e) = rot<<16 | lx<<8 | ly with value posZValid[rot, lx, ly]; out[rank] = its key.
+// Element e is the candidate key(e) = rot<<16 | lx<<8 | ly with value zsrc[rot, lx, ly] (posZValid, read where it
+// lies in global memory: this path is rare); out[rank] = its key.
 // `sel` ([n] words, may be the array key() reads) and `hist` ([256] words) are LDS.  All threads call it.
 // ---------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned long long sortable_f64(double v) {
@@ -879,10 +880,10 @@ __device__ __forceinline__ unsigned long long sortable_f64(double v) {
 constexpr int SEL_PER_THREAD = (8 * 256 + BLOCK - 1) / BLOCK;           // R*AC <= 2048 elements
 
 template <typename KEY>
-__device__ inline void select_smallest(const Params& P, const Lds& L, int n, int want, const KEY& key, uint32_t* out,
-                                       uint32_t* sel, uint32_t* hist) {
+__device__ inline void select_smallest(const Params& P, const Lds& L, const double* zsrc, int n, int want, const KEY& key,
+                                       uint32_t* out, uint32_t* sel, uint32_t* hist) {
     const int tid = threadIdx.x;
-    auto value = [&](uint32_t k) { return L.posz[(k >> 16) * P.AC + ((k >> 8) & 255u) * P.Ay + (k & 255u)]; };
+    auto value = [&](uint32_t k) { return zsrc[(k >> 16) * P.AC + ((k >> 8) & 255u) * P.Ay + (k & 255u)]; };
     unsigned long long sk[SEL_PER_THREAD];
     uint32_t ky[SEL_PER_THREAD];
 #pragma unroll
@@ -982,7 +983,7 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, int n, int
 // L.posz; also records the candidate keys for the next step's action_to_position.
 // ---------------------------------------------------------------------------------------
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
-                                        int nvalid, float* obs) {
+                                        int nvalid, float* obs, const double* zsrc) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
@@ -1010,7 +1011,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         rows = keys;
     } else if (n > P.S) {
         // np.argsort(candidates[:,3])[:S] (binPhy.py:209-212), ties by ascending index
-        select_smallest(P, L, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist);
+        select_smallest(P, L, zsrc, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist);
         nrows = P.S;
         rows = okey;
         __syncthreads();
@@ -1027,36 +1028,46 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
             for (int e = tid; e < want; e += BLOCK) okey[e] = cell_key(e);
             __syncthreads();
         } else {
-            select_smallest(P, L, total_cells, want, cell_key, okey, keys, hist);
+            select_smallest(P, L, zsrc, total_cells, want, cell_key, okey, keys, hist);
         }
         nrows = total_cells < P.S ? total_cells : P.S;
         rows = okey;
         __syncthreads();
     }
 
-    // ---- emit: candidate block [S][5], item vector [9], heightmap [Hc]; float32 cast last
+    // ---- the rows' one data-dependent float: H = (float) posZValid of the row, or in the fallback its validity flag.
+    // posZValid is read where it lies (global memory, L2 / Infinity Cache): only the ~100 rows of the bin, not the
+    // whole [R][AC] grid -- the emit kernel is bandwidth-bound and the grid was 40 % of what it moved.
+    float* rowval = (float*)hist;                   // [S]: the radix counters / sort keys are done with
+    for (int i = tid; i < nrows; i += BLOCK) {
+        const uint32_t k = rows[i];
+        const double z = zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];
+        rowval[i] = fallback ? (z < 1e3 ? 1.0f : 0.0f) : (float)z;
+    }
+    __syncthreads();
+    // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last
     for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
     for (int e = tid; e < 5 * P.S; e += BLOCK) {
         const int row = e / 5, col = e - row * 5;
         float v = 0.0f;
         if (row < nrows) {
             const uint32_t k = rows[row];
-            const int r = k >> 16, lx = (k >> 8) & 255, ly = k & 255;
-            const double z = L.posz[r * AC + lx * Ay + ly];
             switch (col) {
-                case 0: v = (float)r; break;
-                case 1: v = (float)lx; break;
-                case 2: v = (float)ly; break;
-                case 3: v = fallback ? (float)P.bin_z : (float)z; break;
-                default: v = fallback ? (z < 1e3 ? 1.0f : 0.0f) : 1.0f; break;
+                case 0: v = (float)(k >> 16); break;
+                case 1: v = (float)((k >> 8) & 255u); break;
+                case 2: v = (float)(k & 255u); break;
+                case 3: v = fallback ? (float)P.bin_z : rowval[row]; break;
+                default: v = fallback ? rowval[row] : 1.0f; break;
             }
         }
         obs[e] = v;
     }
-    for (int i = tid; i < P.S; i += BLOCK) S.cand[(size_t)b * P.S + i] = i < nrows ? rows[i] : 0u;
+    // candidate keys for the next apply: only the rows that exist (BinState::nrows tells apply where they end)
+    for (int i = tid; i < nrows; i += BLOCK) S.cand[(size_t)b * P.S + i] = rows[i];
     if (tid == 0) {
         S.bs[b].cur_item = item;
         S.bs[b].nvalid = nvalid;
+        S.bs[b].nrows = nrows;
     }
     // The scripted MINZ policy on the rows just written (irbpp_policy_minz on this observation gives the same):
     // the row with the lowest float32 H among V == 1, first on ties.  Fallback rows all carry H = bin_z and are
@@ -1066,8 +1077,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         int bi = 0x7fffffff;
         if (!fallback)
             for (int i = tid; i < nrows; i += BLOCK) {
-                const uint32_t k = rows[i];
-                const float h = (float)L.posz[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];
+                const float h = rowval[i];
                 if (h < best) { best = h; bi = i; }              // ascending i per thread: the first of equals stays
             }
         for (int o = 32; o > 0; o >>= 1) {
@@ -1165,11 +1175,10 @@ extern "C" __global__ void __launch_bounds__(BLOCK)
 irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
-    L.posz = (double*)(smem + P.e_posz);
     L.vmask = (uint32_t*)(smem + P.e_vmask);
     L.redd = (double*)(smem + P.e_red);
     L.redi = (int*)(L.redd + 8);
-    L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select
+    L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select, the sort keys, the rows' values
     L.scratch = smem + P.e_keys;
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;
     const int slot = (int)blockIdx.x + io.block_off;
@@ -1182,14 +1191,12 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
-    const double* gz = S.w_posz + (size_t)b * P.R * P.AC;
-    for (int i = tid; i < P.R * P.AC; i += BLOCK) L.posz[i] = gz[i];
     const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
     for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
     const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
     __syncthreads();
     stamp(io, b, 3);
-    emit_observation(P, S, io, L, b, item, nvalid, obs);
+    emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1577,7 +1584,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     } else {                             // PackingGame.step (binPhy.py:248-337)
         int a = io.actions[b];
         a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
-        const uint32_t key = S.cand[(size_t)b * P.S + a];            // action_to_position (:234-236)
+        const uint32_t key = a < S.bs[b].nrows ? S.cand[(size_t)b * P.S + a] : 0u;      // action_to_position (:234-236); rows beyond the last are zeros
         const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
         const int item0 = S.bs[b].cur_item;                          // same 64-byte line, wave-uniform
         const int oa = S.bs[b].order_action;
