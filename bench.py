@@ -272,6 +272,10 @@ def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
         if k == 1:
             env.policy_minz_group(g, cur[g], actions_out=act[g])
         env.groups[g].set_auto_policy(act[g])
+        # the ping-pong observation buffers belong to the library from here on (irbpp_register_obs_buffer): it clears
+        # the candidate rows a bin no longer has instead of rewriting the zero tail of all S rows every step
+        for t in ([loc[g]] if k > 1 else [cur[g], nxt[g]]):
+            env.groups[g].register_obs_buffer(t)
     torch.cuda.synchronize(dev)
 
     def one_step():

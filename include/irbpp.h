@@ -145,6 +145,14 @@ int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stri
  * needs no policy kernel between two steps.  The buffer may be the one the next irbpp_step reads its actions from. */
 int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev);
 
+/* Registers a location-observation buffer (float32[num_bins][obs_len(1)], i.e. what irbpp_reset / irbpp_step of an
+ * online environment / irbpp_get_action_candidates write) that from now on ONLY this library writes: it remembers
+ * how many candidate rows each bin's block holds, so a later call that is handed the same pointer stores the rows
+ * that exist and clears the ones that existed before, instead of rewriting the zero tail of all `selected` rows
+ * (typically 80 % of the block).  The contents delivered are the same as for an unregistered buffer.  Up to 8
+ * buffers (a ring of 2-3 is what an actor loop needs); not for irbpp_reset_bins. */
+int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev);
+
 /* -- stage-level entry points (parity tests and tooling) ------------------------------- */
 
 /* Space.get_possible_position (space.py:98-129) for item_ids_dev[b] on bin b's current

@@ -50,6 +50,7 @@ SIGNATURES = {
     "irbpp_get_action_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_set_auto_policy": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "irbpp_register_obs_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
     "irbpp_possible_position": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_heuristic_action": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_shot_item": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <new>
+#include <utility>
 #include <vector>
 
 #include "../../include/irbpp.h"
@@ -28,6 +29,7 @@ struct irbpp_env {
     bool reorder = true;                   // launch the bins most-expensive-first (IRBPP_NO_ORDER=1: identity order, A/B tool)
     long long* phase_cycles = nullptr;
     int32_t* auto_actions = nullptr;       // irbpp_set_auto_policy
+    std::vector<std::pair<const float*, int32_t*>> obs_buffers;   // irbpp_register_obs_buffer: buffer -> rows per bin
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
     std::vector<void*> allocs;
@@ -450,6 +452,10 @@ static bool use_wide_kernel(const Params& P) {
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
     io.auto_action = env->auto_actions;
+    io.obs_rows = nullptr;
+    if (mode != MODE_RESET || io.bin_list == nullptr)                    // (reset_specific writes a row per listed bin: never a registered buffer)
+        for (auto& rb : env->obs_buffers)
+            if (rb.first == io.obs) io.obs_rows = rb.second;
     if ((mode == MODE_STEP || mode == MODE_CANDS) && env->reorder)      // most expensive bins first (see irbpp_env_kernel)
         hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, st, env->S.cost, env->S.order, first, n);
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
@@ -562,6 +568,20 @@ int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stri
 int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev) {
     if (!env) return IRBPP_ERR_ARG;
     env->auto_actions = actions_dev;
+    return IRBPP_OK;
+}
+
+int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev) {
+    if (!env || !obs_dev) return IRBPP_ERR_ARG;
+    for (auto& rb : env->obs_buffers)
+        if (rb.first == obs_dev) return IRBPP_OK;
+    if (env->obs_buffers.size() >= 8) return IRBPP_ERR_ARG;
+    HIP_TRY(hipSetDevice(env->cfg.device));
+    int32_t* rows = nullptr;
+    int rc = dev_alloc(env, &rows, (size_t)env->P.N);
+    if (rc != IRBPP_OK) return rc;
+    HIP_TRY(hipMemset(rows, 0xFF, (size_t)env->P.N * sizeof(int32_t)));      // -1: contents unknown, write everything once
+    env->obs_buffers.emplace_back(obs_dev, rows);
     return IRBPP_OK;
 }
 

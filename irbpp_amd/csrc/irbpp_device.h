@@ -182,6 +182,8 @@ struct StepIO {
     int32_t heur_dir;           // dirIdx 0..3: (Xflip, Yflip) (space.py:163-166)
     const int32_t* bin_list;    // MODE_RESET on a subset (reset_specific): workgroup i resets bin bin_list[i]
     int32_t reset_next;         // MODE_RESET of all bins: 0 = episode 0 (first reset), 1 = every bin moves on to its next episode
+    int32_t* obs_rows;          // optional [N]: this obs buffer is registered (irbpp_register_obs_buffer): candidate rows it holds per bin
+                                // from the last call that wrote it (-1 unknown); rows beyond are known to be zero
     int32_t* auto_action;       // optional [N]: the scripted MINZ policy's choice for the observation just emitted (row with the
                                 // lowest H among V == 1, first on ties; 0 if none) -- irbpp_set_auto_policy
     int32_t* err_out;           // optional [1]: copy of the device error word, written by the emit kernel (split pipeline)

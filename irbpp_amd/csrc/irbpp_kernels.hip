@@ -1046,8 +1046,18 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     }
     __syncthreads();
     // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last
+    // A registered observation buffer (irbpp_register_obs_buffer) is only ever written by this library, which
+    // remembers per bin how many rows it wrote last time: the rows beyond are still zero and are not written again
+    // (typically 100 of 500 rows exist).
+    int write_rows = P.S;
+    if (io.obs_rows != nullptr) {
+        const int prev = io.obs_rows[b];
+        if (prev >= 0) write_rows = prev > nrows ? prev : nrows;
+        __syncthreads();                             // everyone has read the old count
+        if (tid == 0) io.obs_rows[b] = nrows;
+    }
     for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
-    for (int e = tid; e < 5 * P.S; e += BLOCK) {
+    for (int e = tid; e < 5 * write_rows; e += BLOCK) {
         const int row = e / 5, col = e - row * 5;
         float v = 0.0f;
         if (row < nrows) {

@@ -176,6 +176,17 @@ class GpuPackingEnv(object):
         self._auto_actions = actions                # keep the buffer alive
         _lib.check(self.lib.irbpp_set_auto_policy(self._h, _ptr(actions)), "irbpp_set_auto_policy")
 
+    def register_obs_buffer(self, obs: torch.Tensor) -> torch.Tensor:
+        """Hand a location-observation buffer ([N, loc_obs_len] float32, contiguous) over to the library for good:
+        calls that get it as ``obs_out`` then store only the candidate rows that exist and clear the ones that
+        existed before instead of rewriting the zero tail (irbpp_register_obs_buffer).  Nobody else may write it."""
+        assert obs.dtype == torch.float32 and obs.is_cuda and obs.is_contiguous() and obs.shape == (self.num_bins, self.loc_obs_len)
+        if not hasattr(self, "_obs_buffers"):
+            self._obs_buffers = []
+        self._obs_buffers.append(obs)                # keep it alive
+        _lib.check(self.lib.irbpp_register_obs_buffer(self._h, _ptr(obs)), "irbpp_register_obs_buffer")
+        return obs
+
     # -- stage-level access (tests, tooling) ---------------------------------------------------
     def possible_position(self, item_ids: torch.Tensor):
         posz = torch.empty((self.num_bins, self.n_rot, self.Ax, self.Ay), dtype=torch.float64, device=self.device)

@@ -785,3 +785,32 @@ def test_fused_policy_matches_policy_kernel(workload, n, steps):
     if workload == "general":
         assert seen_fallback > 0 and seen_sorted > 0
     env.close()
+
+
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 128, 150), ("general", 64, 50)])
+def test_registered_obs_buffers_deliver_the_same_observations(workload, n, steps):
+    """irbpp_register_obs_buffer: two registered ping-pong buffers (poisoned before the hand-over) against an
+    environment that writes fresh, unregistered buffers -- every observation identical, through auto-resets, the
+    >S selection and the no-candidate fallback."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload(workload)
+    a = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)
+    b = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)
+    bufs = [torch.full((n, a.loc_obs_len), 7.5, dtype=torch.float32, device=DEV) for _ in range(2)]
+    for t in bufs:
+        a.register_obs_buffer(t)
+    oa = bufs[0]
+    a_first = a.reset()                                # unregistered buffer: plain full write
+    ob = b.reset()
+    assert torch.equal(a_first, ob)
+    act = b.policy_minz(ob)
+    for t in range(steps):
+        dst = bufs[t % 2]
+        oa, _, _ = a.step(act, obs_out=dst)
+        ob, _, _ = b.step(act)
+        assert oa.data_ptr() == dst.data_ptr()
+        assert torch.equal(oa, ob), f"step {t}: registered buffer differs"
+        act = b.policy_minz(ob)
+    a.check_device_error()
+    a.close()
+    b.close()
