@@ -452,6 +452,7 @@ static bool use_wide_kernel(const Params& P) {
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
     io.auto_action = env->auto_actions;
+    io.use_order = env->reorder ? 1 : 0;
     io.obs_rows = nullptr;
     if (mode != MODE_RESET || io.bin_list == nullptr)                    // (reset_specific writes a row per listed bin: never a registered buffer)
         for (auto& rb : env->obs_buffers)

@@ -187,6 +187,7 @@ struct StepIO {
     int32_t* auto_action;       // optional [N]: the scripted MINZ policy's choice for the observation just emitted (row with the
                                 // lowest H among V == 1, first on ties; 0 if none) -- irbpp_set_auto_policy
     int32_t* err_out;           // optional [1]: copy of the device error word, written by the emit kernel (split pipeline)
+    int32_t use_order;          // 1: launch slot -> bin through State::order (most-expensive-first launches); 0: identity
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
 };
 

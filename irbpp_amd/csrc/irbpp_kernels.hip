@@ -568,12 +568,12 @@ typedef const __attribute__((address_space(4))) int32_t* ConstIntPtr;
 // posZValid goes to `zdst` ([R][AC]): global memory in the transition kernel (the emit kernel reads it from there; the
 // transition kernel's own LDS layout has no room for it, which is worth two more workgroups per CU), LDS elsewhere.
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                   const Lds& L, int b, int item, bool debug_out, double* zdst) {
+                                   const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
     int* srw = L.sr;                                         // all R ShapeRots of the item in ONE coalesced load
-    if (item >= 0)
+    if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
     for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
@@ -840,12 +840,12 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
 // ---------------------------------------------------------------------------------------
 __device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                        const Lds& L, int b, int item, float* obs, bool debug_out) {
+                                        const Lds& L, int b, int item, float* obs, bool debug_out, bool sr_staged) {
     item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
-    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC);
+    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
@@ -1192,7 +1192,7 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     L.scratch = smem + P.e_keys;
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;
     const int slot = (int)blockIdx.x + io.block_off;
-    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
     // device error word to the step outputs: every bit of this step was raised by the transition or the trace
@@ -1529,7 +1529,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     // stragglers would otherwise decide the kernel's duration.
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;          // reset_specific
     const int slot = (int)blockIdx.x + io.block_off;
-    const int b = (mode == MODE_STEP || mode == MODE_CANDS) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
         if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
@@ -1541,6 +1541,21 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     float* obs = io.obs ? io.obs + (size_t)(some ? slot : b) * io.obs_stride : nullptr;
 
     stamp(io, b, 0);
+    // MODE_STEP: a bin's transition is a chain of dependent global reads (action -> candidate key -> ShapeRot ->
+    // footprint cells; bin state -> next item id -> its ShapeRots -> its lists), each a round trip of 1-2 k cycles
+    // under load -- more than the arithmetic of the whole apply phase.  The reads are therefore issued as early as
+    // their addresses are known, in four rounds, and carried in registers to where they are used.
+    int st_a = 0, st_item0 = -1, st_oa = 0, st_nvalid = 0, st_nrows = 0, st_cursor = 0, st_trow = 0;
+    if (mode == MODE_STEP) {                          // round 1: needs only b; in flight together with the tile
+        st_a = io.actions[b];
+        const BinState* ps0 = S.bs + b;
+        st_item0 = ps0->cur_item;
+        st_oa = ps0->order_action;
+        st_nvalid = ps0->nvalid;
+        st_nrows = ps0->nrows;
+        st_cursor = ps0->cursor;
+        st_trow = ps0->traj_row;
+    }
     // stage the heightmap tile
     if (mode == MODE_RESET) {
         for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;
@@ -1552,11 +1567,18 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         }
         for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) L.hm[tile_walk_index(P, w)] = ghm[w.lin];
     }
+    uint32_t st_key = 0u;
+    int st_next = -2;                                 // -2: not prefetched
+    if (mode == MODE_STEP) {                          // round 2: candidate key, the next item of the trajectory
+        st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);
+        st_key = st_a < st_nrows ? S.cand[(size_t)b * P.S + st_a] : 0u;     // rows beyond the last are zeros
+        if (P.K == 1) st_next = st_cursor < T.seq_len ? T.seq[(long long)st_trow * T.seq_len + st_cursor] : -1;
+    }
     __syncthreads();
 
     // every mode ends in at most one call of observe_location (single call site: small code)
     int obs_item = -1;
-    bool do_observe = true, debug_out = false;
+    bool do_observe = true, debug_out = false, sr_staged = false;
 
     if (mode == MODE_POSSIBLE) {
         obs_item = io.actions[b];
@@ -1592,15 +1614,21 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         }
         __syncthreads();
     } else {                             // PackingGame.step (binPhy.py:248-337)
-        int a = io.actions[b];
-        a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
-        const uint32_t key = a < S.bs[b].nrows ? S.cand[(size_t)b * P.S + a] : 0u;      // action_to_position (:234-236); rows beyond the last are zeros
+        const uint32_t key = st_key;                                 // action_to_position (:234-236)
         const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
-        const int item0 = S.bs[b].cur_item;                          // same 64-byte line, wave-uniform
-        const int oa = S.bs[b].order_action;
-        bool ok = item0 >= 0 && S.bs[b].nvalid > 0 && rot < P.R;     // prejudge (:238-245)
+        const int item0 = st_item0;
+        const int oa = st_oa;
+        bool ok = item0 >= 0 && st_nvalid > 0 && rot < P.R;          // prejudge (:238-245)
+        // round 3: the placed item's ShapeRot and volume, and -- speculatively, for the observation that follows a
+        // successful placement -- the R ShapeRots of the next item (one dword per thread, stored to LDS further down)
         ShapeRot sr = {};
         if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
+        double vol0 = 0.0;
+        if (tid == 0 && item0 >= 0) vol0 = T.volume[item0];
+        constexpr int SRW_ = sizeof(ShapeRot) / 4;
+        int sr_pref = 0;
+        const bool pref_ok = st_next >= 0 && st_next < T.n_shapes;
+        if (pref_ok && tid < P.R * SRW_) sr_pref = ((const int*)(T.sr + (size_t)st_next * P.R))[tid];
         if (ok) {
             const double tx = P.txs[lx & 15], ty = P.txs[ly & 15];       // np.round(lx*resA, 6), precomputed
             if (round6_scaled(tx + sr.ext_x - P.bin_x) > 0.0 || round6_scaled(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
@@ -1610,6 +1638,9 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         // self.packed either way (binPhy.py:266,296): with a placement log attached, a refused placement needs
         // its height too.
         const bool in_grid = item0 >= 0 && rot < P.R && lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay;
+        // round 4: the thread's first top cell (heightmap update) is requested together with its bottom cells
+        Cell tc0 = {};
+        if (ok && tid < sr.nt) tc0 = T.tcell[sr.ot + tid];
         if (in_grid && (ok || cold_args()->S.log_meta != nullptr)) {
             const Cell* cells = T.bcell + sr.ob;
             double m = sr.has_out ? 0.0 : -1e300;
@@ -1656,10 +1687,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
             const Cell* cells = T.tcell + sr.ot;
             for (int e = tid; e < sr.nt; e += BLOCK) {
-                const int ij = cells[e].ij;
+                const Cell tc = e == tid ? tc0 : cells[e];
+                const int ij = tc.ij;
                 const int row = lx * P.step + (ij & 0xFFFF), col = ly * P.step + (ij >> 16);
                 const int c = tile_rc(P, row, col);
-                const double h = fmax(L.hm[c], cells[e].v + z);
+                const double h = fmax(L.hm[c], tc.v + z);
                 L.hm[c] = h;
                 ghm[row * P.Hy + col] = h;
             }
@@ -1671,11 +1703,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             BinState* ps = S.bs + b;                                 // field-wise: no struct copy (keeps scratch at 0)
             const KernArgsPtr ka = cold_args();                      // outputs, totals, log: loaded here, not at entry
             if (ok) {
-                const double vol = T.volume[item0];
+                const double vol = vol0;
                 const double reward = (vol / P.bin_vol) * 10.0;      // binPhy.py:321-322
                 const double epr = ps->ep_reward + reward;
                 const int epl = ps->ep_len + 1;
-                const int cursor = ps->cursor;
+                const int cursor = st_cursor;
                 const int slot = ps->item_idx;                       // self.packed.append(...) (binPhy.py:296)
                 if (ka->S.log_meta && slot < ka->S.log_cap) {
                     ka->S.log_meta[(size_t)b * ka->S.log_cap + slot] = (uint32_t)item0 | ((uint32_t)rot << 16) |
@@ -1687,7 +1719,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 ps->item_idx += 1;
                 ps->ratio_acc += vol;
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
-                q[P.K - 1] = fetch_item(T, S, ps->traj_row, cursor);        // generate_item (:325)
+                int nxt = st_next;                                    // generate_item (:325): prefetched for K == 1
+                if (nxt == -2) nxt = fetch_item(T, S, st_trow, cursor);
+                else if (nxt >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
+                else if (nxt < 0) nxt = -1;
+                q[P.K - 1] = nxt;
                 ps->cursor = cursor + 1;
                 if (ka->io.reward) ka->io.reward[b] = reward;
                 if (ka->io.done) ka->io.done[b] = 0;
@@ -1729,6 +1765,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             }
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
+        // the placement stood, so the item observed next is the one whose ShapeRots came with round 3
+        if (ok && pref_ok) {
+            if (tid < P.R * SRW_) L.sr[tid] = sr_pref;
+            sr_staged = true;
+        }
         __syncthreads();
     }
 
@@ -1743,7 +1784,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
         }
     }
-    if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out);
+    if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
     if (tid == 0 && mode != MODE_POSSIBLE) {
         // Scheduling hint for the next launch.  A bin's cycle count is nearly uncorrelated with its
         // own previous step (r = -0.1 on the blockout workload) but a third of its variance is
@@ -1821,7 +1862,7 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(S.bs[b].cur_item);
-    overlap_test(P, T, S, io, L, b, item, false, L.posz);
+    overlap_test(P, T, S, io, L, b, item, false, L.posz, false);
     __syncthreads();
     double best = 1e300;
     int best_i = 0x7fffffff;

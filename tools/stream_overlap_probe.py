@@ -19,12 +19,13 @@ for nsplit in (1, 2, 4, 8):
         with torch.cuda.stream(s):
             o = e.reset()
             obs.append(o); nxt.append(torch.empty_like(o))
-            act.append(torch.empty((per,), dtype=torch.int32, device="cuda:0"))
+            act.append(e.policy_minz(o))
+            e.set_auto_policy(act[-1])                # fused policy, as in bench.py
 
     def step_all():
         for i, (e, s) in enumerate(zip(envs, streams)):
             with torch.cuda.stream(s):
-                e.policy_minz(obs[i], actions_out=act[i]); e.step(act[i], obs_out=nxt[i])
+                e.step(act[i], obs_out=nxt[i])
                 obs[i], nxt[i] = nxt[i], obs[i]
 
     for _ in range(100):
