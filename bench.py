@@ -287,8 +287,9 @@ def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
 
     for _ in range(prefill + warmup):
         one_step()
-    for e in env.groups:
-        e.enable_kernel_timing(steps * launches)   # HIP events around each transition, on its stream
+    every = int(os.environ.get("IRBPP_BENCH_TIMING_EVERY", "4" if launches == 1 else "3"))   # odd for k > 1: both kinds of launch get sampled
+    for e in env.groups:                           # HIP events around every fourth transition, on its stream (an event
+        e.enable_kernel_timing((steps * launches + every - 1) // every, every)   # pair per step costs the stream ~5 %)
     done_before = float(env.episode_totals()[0].item())
     barrier()
     t0 = time.perf_counter()

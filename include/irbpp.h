@@ -256,6 +256,9 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
  * of it launches: 0 = irbpp_env_kernel (80 VGPRs, six workgroups per CU), 1 = irbpp_env_kernel_wide. */
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide);
 int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);
+/* events around every `every`-th transition only (default 1): two event packets per step cost the stream ~5 % at
+ * 0.15 ms per step, so bench.py samples every fourth step of its timed region */
+int irbpp_debug_kernel_timing_every(irbpp_env* env, int32_t every);
 int irbpp_debug_kernel_times(irbpp_env* env, float* ms_host, int32_t max_count, int32_t* count);
 
 /* Device-side error word raised by kernels (0 = none).  Synchronises the stream. */

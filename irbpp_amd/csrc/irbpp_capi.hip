@@ -32,6 +32,7 @@ struct irbpp_env {
     std::vector<std::pair<const float*, int32_t*>> obs_buffers;   // irbpp_register_obs_buffer: buffer -> rows per bin
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
+    int timing_every = 1, timing_phase = 0;   // events go around every timing_every-th transition only
     std::vector<void*> allocs;
 };
 
@@ -485,7 +486,9 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int gri
     if (grid <= 0) grid = env->P.N;
     io.phase_cycles = env->phase_cycles;
     hipStream_t st = (hipStream_t)stream;
-    const size_t pairs = env->timing.size() / 2, slot = env->timing_next;
+    size_t pairs = env->timing.size() / 2;
+    const size_t slot = env->timing_next;
+    if (pairs && (env->timing_phase++ % env->timing_every) != 0) pairs = 0;       // not a sampled launch
     if (pairs) hipEventRecord(env->timing[2 * slot], st);
     launch_group(env, io, mode, st, 0, grid);
     if (pairs) {
@@ -715,6 +718,13 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* w
     if (!env || !lds_bytes || !wide) return IRBPP_ERR_ARG;
     *lds_bytes = env->P.lds_bytes;
     *wide = use_wide_kernel(env->P) ? 1 : 0;
+    return IRBPP_OK;
+}
+
+int irbpp_debug_kernel_timing_every(irbpp_env* env, int32_t every) {
+    if (!env || every < 1) return IRBPP_ERR_ARG;
+    env->timing_every = every;
+    env->timing_phase = 0;
     return IRBPP_OK;
 }
 

@@ -1895,32 +1895,55 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
 
 // shot_item (tools.py:98-135): footprint tables of one mesh by vertical ray casting.  The mesh is
 // already rotated and translated so that its bounding-box minimum sits at the origin; ray (i, j)
-// passes through (i*res + shift, j*res + shift).  One thread per ray, all triangles per thread:
-// the bottom table is the lowest intersection, the top table the highest, masks flag a hit.
+// passes through (i*res + shift, j*res + shift).  One thread per ray; the triangles go through LDS in chunks of
+// SHOT_CHUNK (vertices gathered once per workgroup instead of once per ray, edge-on triangles dropped while
+// staging): the bottom table is the lowest intersection, the top table the highest, masks flag a hit.
+constexpr int SHOT_CHUNK = 128;
 extern "C" __global__ void __launch_bounds__(BLOCK)
 irbpp_shot_item_kernel(const double* verts, const int32_t* faces, int n_faces, int fx, int fy, double res, double shift,
                        double* top, double* bottom, double* mtop, double* mbot, int32_t* any_hit) {
+    __shared__ double tri[SHOT_CHUNK][10];           // a, b, d (x, y, z each) and the signed double area
+    __shared__ int n_staged;
     const int c = blockIdx.x * BLOCK + threadIdx.x;
-    if (c >= fx * fy) return;
+    const bool mine = c < fx * fy;
     const double px = (double)(c / fy) * res + shift, py = (double)(c % fy) * res + shift;
     double zmin = 1e300, zmax = -1e300;
     bool hit = false;
-    for (int f = 0; f < n_faces; ++f) {
-        const double* a = verts + 3 * faces[3 * f + 0];
-        const double* b = verts + 3 * faces[3 * f + 1];
-        const double* d = verts + 3 * faces[3 * f + 2];
-        const double area = (b[0] - a[0]) * (d[1] - a[1]) - (b[1] - a[1]) * (d[0] - a[0]);
-        if (area == 0.0) continue;                              // edge-on triangle: a vertical ray cannot cross it
-        const double w0 = (b[0] - px) * (d[1] - py) - (b[1] - py) * (d[0] - px);
-        const double w1 = (d[0] - px) * (a[1] - py) - (d[1] - py) * (a[0] - px);
-        const double w2 = (a[0] - px) * (b[1] - py) - (a[1] - py) * (b[0] - px);
-        const bool inside = area > 0.0 ? (w0 >= 0.0 && w1 >= 0.0 && w2 >= 0.0) : (w0 <= 0.0 && w1 <= 0.0 && w2 <= 0.0);
-        if (!inside) continue;
-        const double z = (a[2] == b[2] && b[2] == d[2]) ? a[2] : (w0 * a[2] + w1 * b[2] + w2 * d[2]) / area;
-        zmin = fmin(zmin, z);
-        zmax = fmax(zmax, z);
-        hit = true;
+    for (int f0 = 0; f0 < n_faces; f0 += SHOT_CHUNK) {
+        __syncthreads();
+        if (threadIdx.x == 0) n_staged = 0;
+        __syncthreads();
+        if (threadIdx.x < SHOT_CHUNK && f0 + threadIdx.x < n_faces) {
+            const int f = f0 + threadIdx.x;
+            const double* a = verts + 3 * faces[3 * f + 0];
+            const double* b = verts + 3 * faces[3 * f + 1];
+            const double* d = verts + 3 * faces[3 * f + 2];
+            const double area = (b[0] - a[0]) * (d[1] - a[1]) - (b[1] - a[1]) * (d[0] - a[0]);
+            if (area != 0.0) {                                  // edge-on triangle: a vertical ray cannot cross it
+                double* t = tri[atomicAdd(&n_staged, 1)];       // (order within a chunk is irrelevant: min / max)
+                t[0] = a[0]; t[1] = a[1]; t[2] = a[2]; t[3] = b[0]; t[4] = b[1]; t[5] = b[2];
+                t[6] = d[0]; t[7] = d[1]; t[8] = d[2]; t[9] = area;
+            }
+        }
+        __syncthreads();
+        if (mine)
+            for (int k = 0; k < n_staged; ++k) {
+                const double* a = tri[k];
+                const double* b = a + 3;
+                const double* d = a + 6;
+                const double area = a[9];
+                const double w0 = (b[0] - px) * (d[1] - py) - (b[1] - py) * (d[0] - px);
+                const double w1 = (d[0] - px) * (a[1] - py) - (d[1] - py) * (a[0] - px);
+                const double w2 = (a[0] - px) * (b[1] - py) - (a[1] - py) * (b[0] - px);
+                const bool inside = area > 0.0 ? (w0 >= 0.0 && w1 >= 0.0 && w2 >= 0.0) : (w0 <= 0.0 && w1 <= 0.0 && w2 <= 0.0);
+                if (!inside) continue;
+                const double z = (a[2] == b[2] && b[2] == d[2]) ? a[2] : (w0 * a[2] + w1 * b[2] + w2 * d[2]) / area;
+                zmin = fmin(zmin, z);
+                zmax = fmax(zmax, z);
+                hit = true;
+            }
     }
+    if (!mine) return;
     top[c] = hit ? zmax : 0.0;
     bottom[c] = hit ? zmin : 0.0;
     mtop[c] = hit ? 1.0 : 0.0;

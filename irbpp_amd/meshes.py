@@ -126,3 +126,32 @@ def voxel_mesh(occ: np.ndarray, cube: float):
                         verts.append([(i + c[0]) * cube, (j + c[1]) * cube, (k + c[2]) * cube])
                     faces += [[base, base + 1, base + 2], [base, base + 2, base + 3]]
     return np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int32)
+
+
+def possible_position_custom(env, verts: np.ndarray, faces: np.ndarray, rot_idx: int = 0):
+    """``Space.get_possible_position_custom`` (space.py:131-160): the overlap test of a mesh that is NOT in the data
+    set, in the pose it is given (one "rotation"), on the current heightmaps of every bin of ``env``
+    (a GpuPackingEnv).  The reference ray-casts the mesh (``shot_item``) and runs the same window loop as
+    ``get_possible_position``; here: ``irbpp_shot_item``, then ``irbpp_possible_position`` of a scratch environment
+    that shares the geometry and the heightmaps and holds just this shape.  Returns (posZmap, naiveMask) as
+    float64 / uint8 device tensors [N, R, Ax, Ay] with only row ``rot_idx`` filled (posZmap 1e3, mask 0 elsewhere),
+    which is what the reference leaves in ``self.posZmap`` / returns."""
+    from .vec_env import GpuPackingEnv
+    res_h = env.resolutionH
+    ext, tab = shot_item_gpu(np.asarray(verts, dtype=np.float64), np.asarray(faces, dtype=np.int32), res_h, env.device)
+    one = ShapeSet(np.array([[ext]]), np.array([mesh_volume(np.asarray(verts, dtype=np.float64), np.asarray(faces))]),
+                   [[tab]], name="custom", meta={"res_h": res_h, "n_rot": 1})
+    tmp = GpuPackingEnv(one, np.zeros((1, 1), dtype=np.int32), env.num_bins, device=env.device, resolutionA=env.resolutionA,
+                        resolutionH=res_h, resolutionZ=env.resolutionZ, bin_dimension=env.bin_dimension,
+                        selectedAction=env.S, bufferSize=1)
+    try:
+        tmp.reset()
+        tmp.set_heightmaps(env.get_heightmaps())
+        z1, m1 = tmp.possible_position(torch.zeros((env.num_bins,), dtype=torch.int32, device=env.device))
+    finally:
+        tmp.close()
+    posz = torch.full((env.num_bins, env.n_rot, env.Ax, env.Ay), 1e3, dtype=torch.float64, device=env.device)
+    mask = torch.zeros((env.num_bins, env.n_rot, env.Ax, env.Ay), dtype=torch.uint8, device=env.device)
+    posz[:, rot_idx] = z1.reshape(env.num_bins, env.Ax, env.Ay)
+    mask[:, rot_idx] = m1.reshape(env.num_bins, env.Ax, env.Ay)
+    return posz, mask

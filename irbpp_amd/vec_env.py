@@ -74,6 +74,8 @@ class GpuPackingEnv(object):
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _lib.check(self.lib.irbpp_create(C.byref(cfg), C.byref(self._h)), "irbpp_create")
+        self.resolutionA, self.resolutionH, self.resolutionZ = float(resolutionA), float(resolutionH), float(resolutionZ)
+        self.bin_dimension = tuple(float(x) for x in bin_r)
         self.Hx = int(np.ceil(bin_r[0] / resolutionH))
         self.Hy = int(np.ceil(bin_r[1] / resolutionH))
         self.Ax = int(np.ceil(bin_r[0] / resolutionA))
@@ -250,9 +252,10 @@ class GpuPackingEnv(object):
         name = "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
         return lds.value, name + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
 
-    def enable_kernel_timing(self, capacity: int) -> None:
-        """Tooling: bracket the transition kernel of the next ``capacity`` launches with HIP events
-        on their stream (``capacity`` 0 switches it off)."""
+    def enable_kernel_timing(self, capacity: int, every: int = 1) -> None:
+        """Tooling: bracket the kernels of the next transitions with HIP events on their stream, ``capacity`` pairs
+        in a ring (0 switches it off), around every ``every``-th transition only."""
+        _lib.check(self.lib.irbpp_debug_kernel_timing_every(self._h, int(every)), "irbpp_debug_kernel_timing_every")
         _lib.check(self.lib.irbpp_debug_kernel_timing(self._h, int(capacity)), "irbpp_debug_kernel_timing")
         self._timing_cap = int(capacity)
 

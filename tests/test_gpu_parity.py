@@ -814,3 +814,40 @@ def test_registered_obs_buffers_deliver_the_same_observations(workload, n, steps
     a.check_device_error()
     a.close()
     b.close()
+
+
+def test_possible_position_custom_matches_oracle_on_a_mesh_outside_the_dataset():
+    """Space.get_possible_position_custom (space.py:131-160): ray-cast a mesh that is not in the data set and run
+    the overlap test on the bins' current heightmaps; against the numpy Space fed with the same tables."""
+    from irbpp_amd import meshes
+    shapes = synthetic.blockout_shapes(16, seed=3)
+    seqs = synthetic.make_sequences(16, n_traj=40, length=60, seed=4)
+    n = 6
+    env = GpuPackingEnv(shapes, seqs, n, device=DEV)
+    obs = env.reset()
+    for _ in range(12):
+        obs, _, _ = env.step(env.policy_minz(obs))
+    occ = np.zeros((2, 3, 2), dtype=bool)
+    occ[0, :, 0] = True
+    occ[1, 1, :] = True                                # an L/T-shaped polycube that blockout_shapes(seed=3) need not contain
+    verts, faces = meshes.voxel_mesh(occ, 0.04)
+    posz, mask = meshes.possible_position_custom(env, verts, faces, rot_idx=2)
+    hm = env.get_heightmaps().cpu().numpy().reshape(n, env.Hx, env.Hy)
+    ext, tab = meshes.shot_item_gpu(verts, faces, 0.01, DEV)
+    for b in range(n):
+        zmap = np.full((env.Ax, env.Ay), 1e3)
+        nm = np.zeros((env.Ax, env.Ay))
+        T, B, mH, mB = tab
+        bs = np.round(ext, 6)
+        fx, fy = np.ceil(bs[0:2] / 0.01).astype(int)
+        ax, ay = np.ceil(bs[0:2] / 0.02).astype(int)
+        for X in range(env.Ax - ax + 1):
+            for Y in range(env.Ay - ay + 1):
+                z = np.max((hm[b][2 * X:2 * X + fx, 2 * Y:2 * Y + fy] - B) * mB)
+                if np.round(z + bs[2] - 0.30, 6) <= 0:
+                    nm[X, Y] = 1
+                zmap[X, Y] = z
+        assert np.array_equal(posz[b, 2].cpu().numpy(), zmap)
+        assert np.array_equal(mask[b, 2].cpu().numpy(), nm.astype(np.uint8))
+        assert (posz[b, [0, 1, 3]].cpu().numpy() == 1e3).all() and not mask[b, [0, 1, 3]].any()
+    env.close()
