@@ -41,18 +41,13 @@ def needs_build(path: str = LIB_PATH) -> bool:
     return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
 
 
-ABLATE_LIB_PATH = os.path.join(PKG_DIR, "libirbpp_hip_ablate.so")
-
-
-def build(force: bool = False, verbose: bool = False, ablate: bool = False) -> str:
-    """Compile csrc/irbpp_capi.hip (which includes the kernels) into libirbpp_hip.so.
-
-    ``ablate=True`` builds the tooling variant libirbpp_hip_ablate.so (-DIRBPP_ABLATE: phases can be
-    run twice, see tools/ablate.py); it is selected with IRBPP_LIBRARY and never loaded by default."""
-    out = ABLATE_LIB_PATH if ablate else LIB_PATH
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/irbpp_capi.hip (which includes the kernels) into libirbpp_hip.so.  (A/B builds under another
+    name: tools/build_variant.sh, selected with IRBPP_LIBRARY.)"""
+    out = LIB_PATH
     if not force and not needs_build(out):
         return out
-    cmd = [_hipcc()] + HIPCC_FLAGS + (["-DIRBPP_ABLATE"] if ablate else []) + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", out]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", out]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)
