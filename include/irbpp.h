@@ -211,6 +211,14 @@ int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, i
  * outputs [n_env][draws]: leaf value, data index (tree index - capacity + 1), tree index. */
 int irbpp_sumtree_find(const float* tree_dev, int32_t n_env, int32_t capacity, const float* values_dev, int32_t draws,
                        float* prob_dev, int64_t* data_idx_dev, int64_t* tree_idx_dev, void* stream);
+/* ReplayMemory._get_samples_from_segments (memory.py:161-176) for all envs: draws one position per (env, segment)
+ * -- `draws` segments of p_total/draws each -- with the rejection loop of memory.py:170-176 run on the device
+ * (redraw while the position straddles the write index index_dev[env] +- n_step / history or has probability 0).
+ * Counter-based uniform numbers from `seed`; failed_dev[0] |= 1 if a draw found nothing valid in max_tries tries. */
+int irbpp_sumtree_sample(const float* tree_dev, const int64_t* index_dev, int32_t n_env, int32_t capacity, int32_t draws,
+                         int32_t n_step, uint64_t seed, int32_t max_tries, float* prob_dev, int64_t* data_idx_dev,
+                         int64_t* tree_idx_dev, int32_t* failed_dev, void* stream);
+
 /* replaces: SegmentTree.update/_propagate (memory.py:47-58) for `leaves` (tree index, value) pairs per env, applied
  * in list order, every ancestor recomputed as left + right in float32; max_dev float32[n_env] is SegmentTree.max.
  * env_mask_dev (may be NULL) uint8[n_env]: envs with 0 are skipped.  IRBPP_ERR_ARG if 2*capacity-1 > 16384 (the

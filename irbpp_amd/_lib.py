@@ -60,6 +60,8 @@ SIGNATURES = {
     "irbpp_set_heightmaps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_episode_totals": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_set_placement_log": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]),
+    "irbpp_sumtree_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_uint64, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_sumtree_find": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                      C.c_void_p, C.c_void_p]),
     "irbpp_sumtree_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,

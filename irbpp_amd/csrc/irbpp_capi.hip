@@ -675,11 +675,23 @@ int irbpp_sumtree_find(const float* tree_dev, int32_t n_env, int32_t capacity, c
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
+int irbpp_sumtree_sample(const float* tree_dev, const int64_t* index_dev, int32_t n_env, int32_t capacity, int32_t draws,
+                         int32_t n_step, uint64_t seed, int32_t max_tries, float* prob_dev, int64_t* data_idx_dev,
+                         int64_t* tree_idx_dev, int32_t* failed_dev, void* stream) {
+    if (!tree_dev || !index_dev || !prob_dev || !data_idx_dev || !tree_idx_dev || !failed_dev || n_env < 1 || capacity < 1 ||
+        draws < 1 || n_step < 0 || max_tries < 1)
+        return IRBPP_ERR_ARG;
+    const int n = n_env * draws;
+    hipLaunchKernelGGL(irbpp_sumtree_sample_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, tree_dev, index_dev,
+                       n_env, capacity, draws, n_step, seed, max_tries, prob_dev, data_idx_dev, tree_idx_dev, failed_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
 int irbpp_sumtree_update(float* tree_dev, float* max_dev, int32_t n_env, int32_t capacity, const int64_t* tree_idx_dev,
                          const float* priority_dev, int32_t leaves, const uint8_t* env_mask_dev, void* stream) {
     if (!tree_dev || !max_dev || !tree_idx_dev || !priority_dev || n_env < 1 || capacity < 1 || leaves < 1) return IRBPP_ERR_ARG;
     if (2 * capacity - 1 > SUMTREE_LDS) return IRBPP_ERR_ARG;        // caller keeps its host-side path for longer rows
-    hipLaunchKernelGGL(irbpp_sumtree_update_kernel, dim3(n_env), dim3(64), 0, (hipStream_t)stream, tree_dev, max_dev, capacity,
+    hipLaunchKernelGGL(irbpp_sumtree_update_kernel, dim3(n_env), dim3(64), (size_t)(2 * capacity - 1) * sizeof(float), (hipStream_t)stream, tree_dev, max_dev, capacity,
                        tree_idx_dev, priority_dev, leaves, env_mask_dev);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }

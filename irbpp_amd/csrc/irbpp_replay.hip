@@ -32,6 +32,57 @@ irbpp_sumtree_find_kernel(const float* __restrict__ tree, int n_env, int cap, co
     tree_idx[t] = idx;
 }
 
+// ReplayMemory._get_samples_from_segments (memory.py:161-176) for every (env, segment) at once: draw a position
+// uniformly in the segment, walk the tree, and redraw while the draw straddles the write index or has probability 0
+// (the reference's rejection loop) -- all inside one kernel instead of a host loop of launch / test / sync rounds.
+// The uniform numbers come from a counter-based generator (splitmix64 of seed, env, segment, try): a different
+// stream from numpy's, as any vectorised sampler's must be.  failed[0] is set if some draw found no valid position
+// within max_tries (too few transitions appended).  One thread per (env, segment).
+__device__ __forceinline__ float uniform01(uint64_t seed, uint32_t env, uint32_t j, uint32_t attempt) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * (((uint64_t)env << 32) ^ ((uint64_t)j << 8) ^ (uint64_t)attempt ^ 0xD1B54A32D192ED03ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z = z ^ (z >> 31);
+    return (float)(z >> 40) * (1.0f / 16777216.0f);              // 24 random bits -> [0, 1)
+}
+extern "C" __global__ void __launch_bounds__(256)
+irbpp_sumtree_sample_kernel(const float* __restrict__ tree, const int64_t* __restrict__ index, int n_env, int cap, int b, int n_step,
+                            uint64_t seed, int max_tries, float* __restrict__ prob, int64_t* __restrict__ data_idx,
+                            int64_t* __restrict__ tree_idx, int32_t* __restrict__ failed) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_env * b) return;
+    const int env = t / b, j = t - env * b;
+    const int len = 2 * cap - 1;
+    const float* row = tree + (size_t)env * len;
+    const float segment = row[0] / (float)b;                      // p_total / batch_size (memory.py:195)
+    const float lo = (float)j * segment;
+    const int w = (int)index[env];
+    float p = 0.0f;
+    int idx = 0;
+    bool ok = false;
+    for (int attempt = 0; attempt < max_tries && !ok; ++attempt) {
+        float v = lo + uniform01(seed, (uint32_t)env, (uint32_t)j, (uint32_t)attempt) * segment;
+        idx = 0;
+        for (;;) {
+            const int left = 2 * idx + 1;
+            if (left >= len) break;
+            const float lv = row[left];
+            if (v <= lv) idx = left;
+            else { v = v - lv; idx = left + 1; }
+        }
+        p = row[idx];
+        const int d = idx - (cap - 1);
+        int a = (w - d) % cap, c = (d - w) % cap;                 // Python's % : non-negative
+        if (a < 0) a += cap;
+        if (c < 0) c += cap;
+        ok = a > n_step && c >= 1 && p != 0.0f;                   // memory.py:175
+    }
+    if (!ok) atomicOr(failed, 1);
+    prob[t] = p;
+    data_idx[t] = idx - (cap - 1);
+    tree_idx[t] = idx;
+}
+
 // SegmentTree.update (memory.py:55-58) for b leaves per env, applied in list order (a leaf listed twice keeps its
 // last value, as in the reference's sequential loop), then every ancestor recomputed as left + right from its
 // final children -- which is what the sequence of _propagate calls leaves behind.  One wave per env, the tree
@@ -40,7 +91,7 @@ constexpr int SUMTREE_LDS = 16384;                       // floats: capacities u
 extern "C" __global__ void __launch_bounds__(64)
 irbpp_sumtree_update_kernel(float* __restrict__ tree, float* __restrict__ maxp, int cap, const int64_t* __restrict__ tree_idx,
                             const float* __restrict__ prio, int b, const uint8_t* __restrict__ row_mask) {
-    __shared__ float row[SUMTREE_LDS];
+    extern __shared__ float row[];                       // 2*cap - 1 floats (dynamic: a 64-transition ring needs 508 bytes, not 64 KB)
     const int env = blockIdx.x, lane = threadIdx.x;
     if (row_mask && !row_mask[env]) return;              // append() of a subset of the envs
     const int len = 2 * cap - 1;

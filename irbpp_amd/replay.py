@@ -203,12 +203,28 @@ class VectorReplayMemory(object):
         Returns (tree_idxs [N,B], states, actions, returns, next_states, nonterminals [N*B,1], weights)."""
         N, B = self.N, int(segment_size)
         p_total = self.total()                                                    # [N]
-        segment = p_total / B
-        lo = torch.arange(B, device=self.device, dtype=torch.float32)[None, :] * segment[:, None]
+        if values is not None or self._lib is None:
+            segment = p_total / B
+            lo = torch.arange(B, device=self.device, dtype=torch.float32)[None, :] * segment[:, None]
         if values is not None:
             prob, data_idx, tree_idx = self.find(values.to(self.device))
             if not bool(self._valid(prob, data_idx).all()):
                 raise ValueError("a supplied sample position is invalid (memory.py:175)")
+        elif self._lib is not None:
+            # draw + tree walk + the rejection loop of memory.py:170-176 in ONE launch; the only host round trip is
+            # the failure flag
+            from . import _lib
+            gdev = "cpu" if generator is None else generator.device          # a CPU generator costs no device round trip
+            seed = int(torch.randint(0, 2 ** 62, (1,), generator=generator, device=gdev).item())
+            prob = torch.empty((N, B), dtype=torch.float32, device=self.device)
+            data_idx = torch.empty((N, B), dtype=torch.int64, device=self.device)
+            tree_idx = torch.empty((N, B), dtype=torch.int64, device=self.device)
+            failed = torch.zeros((1,), dtype=torch.int32, device=self.device)
+            _lib.check(self._lib.irbpp_sumtree_sample(_p(self.sum_tree), _p(self.index), N, self.capacity, B, self.n, seed,
+                                                      int(max_tries), _p(prob), _p(data_idx), _p(tree_idx), _p(failed),
+                                                      _stream(self.device)), "irbpp_sumtree_sample")
+            if int(failed.item()):
+                raise RuntimeError("could not draw a valid sample from every segment; append more transitions first")
         else:
             draw = lambda: lo + torch.rand((N, B), device=self.device, generator=generator) * segment[:, None]  # noqa: E731
             prob, data_idx, tree_idx = self.find(draw())

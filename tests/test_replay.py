@@ -249,3 +249,38 @@ def test_masked_greedy_action_is_agent_act():
     assert got[5] == 0 and got[7] == 10
     cpu = masked_greedy_action(torch.from_numpy(q), torch.from_numpy(state), S).numpy()   # torch formulation (CPU)
     np.testing.assert_array_equal(cpu, want)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("capacity,n_step", [(16, 1), (64, 3)])
+def test_fused_sampling_kernel_draws_valid_stratified_positions(capacity, n_step):
+    """irbpp_sumtree_sample (draw + tree walk + the rejection loop of memory.py:170-176 in one launch): every
+    position satisfies the reference's validity test, lies in its own segment of the priority mass, the same seed
+    gives the same draws, and an empty memory reports failure instead of looping."""
+    rng = np.random.RandomState(capacity)
+    n_envs, obs_len, B = 37, 4, 8
+    mem = VectorReplayMemory(n_envs, capacity, obs_len, multi_step=n_step, device="cuda:0")
+    with pytest.raises(RuntimeError):
+        mem.sample(2)                                   # nothing appended yet
+    for t in range(3 * capacity):
+        mem.append(torch.from_numpy(rng.uniform(0, 0.3, size=(n_envs, obs_len)).astype(np.float32)).cuda(),
+                   torch.from_numpy(rng.randint(0, 500, size=n_envs)).cuda(),
+                   torch.from_numpy(rng.uniform(0, 1, size=n_envs).astype(np.float32)).cuda(),
+                   torch.from_numpy(rng.rand(n_envs) < 0.1).cuda())
+        if t % 9 == 8 and bool(mem.full.all()):
+            idx = mem.find((torch.rand((n_envs, B), device="cuda:0") * mem.total()[:, None]).clamp(min=1e-6))[2]
+            mem.update_priorities(idx, torch.rand((n_envs, B), device="cuda:0") + 0.05)
+    g1, g2 = torch.Generator().manual_seed(5), torch.Generator().manual_seed(5)
+    a, b = mem.sample(B, generator=g1), mem.sample(B, generator=g2)
+    assert torch.equal(a[0], b[0])                      # same seed, same positions
+    tree_idx = a[0]
+    prob = mem.sum_tree[torch.arange(n_envs, device="cuda:0")[:, None], tree_idx]
+    data_idx = tree_idx - (capacity - 1)
+    assert bool(mem._valid(prob, data_idx).all())
+    # stratification: the prefix mass in front of leaf j's position lies in segment j (up to the leaf's own mass)
+    leaves = mem.sum_tree[:, capacity - 1:]
+    before = torch.cumsum(leaves, dim=1) - leaves
+    seg = mem.total()[:, None] / B
+    lo = torch.arange(B, device="cuda:0")[None, :] * seg
+    start = torch.gather(before, 1, data_idx)
+    assert bool((start <= lo + seg + 1e-3).all()) and bool((start + prob >= lo - 1e-3).all())
