@@ -89,6 +89,19 @@ def test_online_odd_geometry_matches_oracle():
     assert _run_online(sh, seqs, 6, 40, bin_dimension=(0.32, 0.24, 0.30), selectedAction=120, resolutionZ=0.02) >= 2
 
 
+@pytest.mark.parametrize("shapes_kind", ["cube", "general"])
+def test_online_odd_action_grid_matches_oracle(shapes_kind):
+    """A 0.30 x 0.26 m bin: 15 x 13 action cells, i.e. the 2 x 2 blocks of the overlap test and the phase planes of the
+    heightmap tile have padding entries (8 x 7 lanes, tile larger than the heightmap); block path impossible (30 and
+    26 cells), so cubes take the generic path here too."""
+    if shapes_kind == "cube":
+        sh = synthetic.cube_shapes()
+    else:
+        sh = synthetic.general_shapes(n_shapes=20, n_rot=8, fmin=4, fmax=14, seed=6)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 60, seed=41)
+    assert _run_online(sh, seqs, 5, 40, bin_dimension=(0.30, 0.26, 0.30), selectedAction=150) >= 1
+
+
 def test_online_fine_heightmap_matches_oracle():
     sh = synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=4)
     assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 32, 60, seed=2), 3, 14, resolutionH=0.005) >= 1
