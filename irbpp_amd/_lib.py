@@ -92,6 +92,10 @@ def load(path: str = "") -> C.CDLL:
         raise RuntimeError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). irbpp_amd has no CPU fallback.")
+    # torch first: it ships its own HIP runtime (torch/lib/libamdhip64.so), and a process must hold exactly one.
+    # Loaded before torch, this library would pull in /opt/rocm's copy and every later call would talk to a
+    # runtime that knows nothing of torch's device context (irbpp_create then fails with a HIP error).
+    import torch  # noqa: F401
     lib = C.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
