@@ -471,8 +471,11 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
-        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(n), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
-        hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(2 * n), dim3(64), 0, st, env->P, env->S);
+        static const int tg = getenv("IRBPP_TRACE_GRID_PCT") ? atoi(getenv("IRBPP_TRACE_GRID_PCT")) : 100;      // A/B tools: grid sizes in
+        static const int pg = getenv("IRBPP_POLY_GRID_PCT") ? atoi(getenv("IRBPP_POLY_GRID_PCT")) : 200;        // per cent of the bins
+        const int tgrid = n * tg / 100 > 0 ? n * tg / 100 : 1, pgrid = n * pg / 100 > 0 ? n * pg / 100 : 1;
+        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
+        hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }

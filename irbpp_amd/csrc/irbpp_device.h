@@ -6,8 +6,8 @@
 //   cand      u32 [N][S]         (rot<<16 | lx<<8 | ly) of the candidate rows handed out last
 //   bs        BinState [N]       64-byte line of per-bin scalars (cursor, episode, cur_item, nvalid,
 //                                order_action, item_idx, ep_len, ratio_acc, ep_reward); totals f64 [N][4]
-//   ShapeRot  72 B per (shape, rot) + compact lists (u16 tile offset, f64 height) of the masked-in
-//                                footprint cells (read-only, shared by all bins -> L2 resident)
+//   ShapeRot  104 B per (shape, rot) + compact lists of the masked-in footprint cells, of uniform b x b blocks and
+//                                of the generic path's positions (read-only, shared by all bins -> L2 / MALL resident)
 //   seq       i32 [n_traj][L]    pre-drawn item ids
 #pragma once
 #include <stdint.h>
@@ -21,11 +21,10 @@ namespace irbpp {
 #endif
 constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 
-// Split pipeline (Params.split): the transition kernel stops after the overlap test and hands the contour
-// work of a bin to the trace kernel through global memory -- up to WIMG level images (16 row + 16 column
-// words each; R * 64 are possible in theory) and WCAND candidate start pixels per bin; a bin that exceeds
-// either resolves its contours inside the transition kernel instead, so the capacities never change results.  The trace kernel serves
-// several bins per wave, which is what keeps its lanes busy: one bin alone has ~25 borders to follow.
+// Split pipeline: the transition kernel stops after the overlap test and hands the contour work of a bin on through
+// global memory -- its level images (at most R * 64) and the candidate start pixels of their outer borders (at most
+// R * AC), sized for the worst case.  The trace kernel serves the candidates of all bins as one flat list per XCD,
+// which is what keeps its lanes busy: one bin alone has ~20 borders to follow.
 constexpr int WMETA = 8;
 constexpr int NXCD = 8;                            // accelerator dies of the MI355X: one flat candidate list each
 constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each

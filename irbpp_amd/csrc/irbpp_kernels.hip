@@ -1,19 +1,19 @@
 // irbpp_kernels.hip -- CDNA4 (gfx950) kernels of the batched packing environment.
 //
-// One 256-thread workgroup (4 wave64) owns one bin for a whole environment transition:
-//   apply    action -> (rot,lx,ly) -> prejudge -> drop height -> height check ->
-//            heightmap update / episode end + auto-reset          (binPhy.py:248-337)
-//   observe  overlap test over (rot,X,Y)                           (space.py:98-129)
-//            height levels -> per-level binary images -> border following ->
-//            approxPolyDP -> convex vertices -> candidate set      (cvTools.py:61-102)
-//            select/pad S rows, assemble the float32 observation   (binPhy.py:183-232)
-// The float64 heightmap tile of the bin lives in LDS for the whole transition (8 KiB at
-// 32x32, 32 KiB at 64x64); footprint tables are wave-uniform reads served from L2; all
-// intermediate grids (posZValid, levels, level images, vertex bit grids, candidate keys)
-// stay in LDS.  HBM traffic per transition is the heightmap tile in/out, the observation
-// row out and ~2 KiB of candidate keys.  Arithmetic is float64 in the reference's operation
-// order (compile with -ffp-contract=off), so results are bit-identical to the numpy code.
-// No MFMA: this is subtract/max/compare and integer border following, not a contraction.
+// A transition of all bins is four kernels on the caller's stream:
+//   irbpp_env_kernel      one 256-thread workgroup (4 wave64) per bin: apply the action -> (rot,lx,ly) -> prejudge ->
+//                         drop height -> height check -> heightmap update / episode end + auto-reset (binPhy.py:248-337);
+//                         overlap test of the next item over (rot,X,Y) (space.py:98-129); height levels -> per-level
+//                         binary images -> candidate start pixels of their outer borders (cvTools.py:61-84)
+//   irbpp_trace_kernel    border following over the candidates of ALL bins, one per lane (cv2.findContours)
+//   irbpp_polygon_kernel  approxPolyDP + convex vertices of 128 contour points per wave (cvTools.py:40-59,91-96)
+//   irbpp_emit_kernel     one workgroup per bin: candidate set -> select/pad S rows -> float32 observation (binPhy.py:183-232)
+// The float64 heightmap tile of a bin lives in LDS for the whole transition kernel (8 KiB at 32x32, 32 KiB at 64x64);
+// footprint tables are wave-uniform reads served from L2; levels, level images and vertex bit grids stay in LDS;
+// posZValid, the images, the candidate lists and the polygon rounds are handed from kernel to kernel through
+// global memory (L2 / Infinity Cache).  Arithmetic is float64 in the reference's operation order (compile with
+// -ffp-contract=off), so results are bit-identical to the numpy code.  No MFMA: this is subtract/max/compare and
+// integer border following, not a contraction.
 //
 // LDS heightmap tile layout ("phase planes" of period pp = 2*step): heightmap cell (row, col) with
 // row = Lx*pp + u, col = Ly*pp + v (u, v < pp) lives at plane (u*pp + v), entry Lx*LY + Ly; a plane has
@@ -34,7 +34,7 @@ namespace irbpp {
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
 
-// Tooling build only (-DIRBPP_ABLATE, tools/ablate.py): phase `bit` runs twice when Params.dbg_repeat has the
+// Tooling build only (tools/build_variant.sh NAME -DIRBPP_ABLATE): phase `bit` runs twice when Params.dbg_repeat has the
 // bit set.  Every repeated phase is idempotent, so results do not change and the slow-down of a launch
 // prices the phase at full chip load.  In the product build the trip count is the constant 1.
 #ifdef IRBPP_ABLATE
@@ -1248,11 +1248,12 @@ __device__ __forceinline__ int wave_inclusive_max(int v) {
 #define IRBPP_TRACE_P 2
 #endif
 #ifndef IRBPP_TRACE_SHORT
-#define IRBPP_TRACE_SHORT 8
+#define IRBPP_TRACE_SHORT 0
 #endif
 constexpr int TRACE_P = IRBPP_TRACE_P;                                // contour points per lane and polygon round
 constexpr int TRACE_CAP = 128, TRACE_SLOT = TRACE_CAP + 4;            // points per border slot; 33 dwords: odd stride
-constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points are approximated first
+constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points get rounds of their own, ahead of the
+                                                                      // long ones (0 = one class: measured 27.46 vs 27.25 M steps/s for 8)
 static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
 static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
@@ -1334,11 +1335,9 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
         }
         const long long t_traced = prof ? (long long)clock64() : 0;
         // ---- the closed borders go to the polygon kernel in rounds of 64 * PP contour points, borders packed back
-        // to back (two classes: a round lasts as many recursion levels as its deepest border needs, so the short
-        // borders -- the majority, done after two or three levels -- share rounds, and so do the long ones).  A wave
-        // traces for as long as its longest border takes and has 2 to 6 rounds' worth of points: approximating them
-        // here would stretch the slowest waves, which set the kernel's duration; as records in global memory every
-        // round is one evenly sized work item of irbpp_polygon_kernel.
+        // to back (optionally in two classes, TRACE_SHORT).  A wave traces for as long as its longest border takes and
+        // has 2 to 4 rounds' worth of points: approximating them here would stretch the slowest waves, which set the
+        // kernel's duration; as records in global memory every round is one work item of irbpp_polygon_kernel.
         auto next_round = [&](int cls, int left, int& wn, int& excl, int& base) -> unsigned long long {
             wn = (cls == 0 ? left <= TRACE_SHORT : true) ? left : 0;
             const int incl = wave_inclusive_sum(wn);
