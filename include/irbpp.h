@@ -15,7 +15,15 @@
  *     stream); a handle is not thread-safe; one outstanding step per handle (the
  *     reference's `waiting_step` rule, shmem_vec_env.py:58-74).
  *   - observation buffers are written in full on every call, so the caller may hand a
- *     fresh buffer each step (trainer.py:184-186 keeps the previous `state` alive).
+ *     fresh buffer each step (trainer.py:184-186 keeps the previous `state` alive); a buffer
+ *     handed over with irbpp_register_obs_buffer is kept complete by the library instead
+ *     (same contents, fewer stores).
+ *
+ * Limits (irbpp_create returns IRBPP_ERR_ARG beyond them): action grid <= 16 x 16 cells,
+ * heightmap <= 128 x 128 cells with resolutionA an integer multiple of resolutionH and the bin an
+ * integer number of action cells; n_rot <= 8; selected <= 1024; buffer_size <= 16;
+ * bin[2] / resolution_z <= 31 height levels (cvTools.py:78 codes a level in 6 bits: level + 32);
+ * num_bins <= 32768 per device.  Item ids are < 65536 in the placement log.
  */
 #ifndef IRBPP_H
 #define IRBPP_H

@@ -163,7 +163,7 @@ const char* irbpp_status_string(int status) {
     }
 }
 
-int irbpp_version(void) { return 100; }
+int irbpp_version(void) { return 200; }      // 2xx: set_auto_policy, register_obs_buffer, sumtree_sample, debug_kernel_timing_every
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
