@@ -60,6 +60,39 @@ __device__ __forceinline__ uint32_t start_candidates(uint32_t row, uint32_t up) 
     return row & ~(row << 1) & ~up & ~(up << 1) & ~(up >> 1) & 0xFFFFu;
 }
 
+// Transposed copy of a level image, in place on 16 registers: r[y] = row word y (bit x = pixel (x, y)) becomes
+// r[x] = column word x (bit y = pixel (x, y)).  Four block-swap stages of the 16 x 16 bit matrix (8, 4, 2, 1).
+__device__ __forceinline__ void transpose16(uint32_t (&r)[16]) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t t = ((r[k] >> 8) ^ r[k + 8]) & 0x00FFu;
+        r[k + 8] ^= t;
+        r[k] ^= t << 8;
+    }
+#pragma unroll
+    for (int g = 0; g < 16; g += 8)
+#pragma unroll
+        for (int k = g; k < g + 4; ++k) {
+            const uint32_t t = ((r[k] >> 4) ^ r[k + 4]) & 0x0F0Fu;
+            r[k + 4] ^= t;
+            r[k] ^= t << 4;
+        }
+#pragma unroll
+    for (int g = 0; g < 16; g += 4)
+#pragma unroll
+        for (int k = g; k < g + 2; ++k) {
+            const uint32_t t = ((r[k] >> 2) ^ r[k + 2]) & 0x3333u;
+            r[k + 2] ^= t;
+            r[k] ^= t << 2;
+        }
+#pragma unroll
+    for (int k = 0; k < 16; k += 2) {
+        const uint32_t t = ((r[k] >> 1) ^ r[k + 1]) & 0x5555u;
+        r[k + 1] ^= t;
+        r[k] ^= t << 1;
+    }
+}
+
 // Straight runs.  After a step in an axis direction d the walk keeps going straight exactly
 // while the three neighbours probed before d (directions d+5, d+6, d+7) are background and the
 // neighbour in direction d is foreground; no point is emitted inside a run (CHAIN_APPROX_SIMPLE

@@ -238,7 +238,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_posz, N * P.R * P.AC);
     ALLOC(w_vmask, N * P.R * 16);
     ALLOC(w_meta, N * WMETA);
-    ALLOC(w_img, N * P.wimg * 32);
+    ALLOC(w_img, N * P.wimg * 16);
     ALLOC(w_imgrot, N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
     ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)

@@ -108,7 +108,7 @@ struct State {
     double* w_posz;        // [N][R*AC] posZValid of the observed item
     uint32_t* w_vmask;     // [N][R*16] vertex bits: isolated pixels from the transition kernel, the rest from the trace kernel
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
-    uint16_t* w_img;       // [N][wimg][32] level images: 16 row words then 16 column words
+    uint16_t* w_img;       // [N][wimg][16] level images: 16 row words (bit x of word y = pixel (x, y))
     uint8_t* w_imgrot;     // [N][wimg] rotation of each level image
     uint32_t* w_cand;      // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
                            // bin<<17 | image<<8 | y0<<4 | x0

@@ -281,8 +281,10 @@ __device__ inline int contour_tasks(const Params& P, const Lds& L) {
     return ntasks;
 }
 
-// level images of the batch starting at task `base`: 16-bit row words, then the transposed copy
-__device__ inline void contour_images(const Params& P, const Lds& L, int base) {
+// level images of the batch starting at task `base`: 16-bit row words and, for the in-kernel trace of the hull
+// kernel only, the transposed copy (the trace kernel of the split pipeline transposes the images it follows itself:
+// 86 k traced images per step instead of 32 slots of every bin)
+__device__ inline void contour_images(const Params& P, const Lds& L, int base, bool with_cols) {
     const int tid = threadIdx.x, R = P.R, AC = P.AC;
     constexpr int IPT = CONTOUR_IPT, IMGS = CONTOUR_IMGS;
     const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
@@ -317,6 +319,7 @@ __device__ inline void contour_images(const Params& P, const Lds& L, int base) {
         }
     }
     __syncthreads();
+    if (!with_cols) return;
     // transposed copy (column words) for the vertical run jumps: thread (g, y) gathers column y
     for (int h = 0; h < IPT; ++h) {
         const int gg = g + h * (BLOCK / 16);
@@ -383,7 +386,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
         const long long t_img = prof ? (long long)clock64() : 0;
-        contour_images(P, L, base);
+        contour_images(P, L, base, true);
         // (a) candidate starts.  The list holds CLIST entries; a batch with more candidates (pathological
         // speckle) is walked one image at a time (an image has at most 64: every other pixel of every other row).
         uint32_t my_cand[CONTOUR_IPT];
@@ -1123,21 +1126,17 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     const KernArgsPtr ka = cold_args();
     const int ntasks = contour_tasks(P, L);
     int ncand = 0;
-    uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 32);
+    uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 16);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
     const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
     for (int base = 0; base < ntasks; base += CONTOUR_IMGS) {                // one batch of level images at a time
-        contour_images(P, L, base);
+        contour_images(P, L, base, false);
         uint32_t my_cand[CONTOUR_IPT];
         const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
         const int nb = ntasks - base < CONTOUR_IMGS ? ntasks - base : CONTOUR_IMGS;
-        // rows [IMGS][16] and columns [IMGS][16] in LDS -> [image][16 rows | 16 columns] in global, as dwords
+        // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)L.img;
-        const uint32_t* lc = (const uint32_t*)(L.img + CONTOUR_IMGS * 16);
-        for (int i = tid; i < nb * 16; i += BLOCK) {
-            const int t = i >> 4, w = i & 15;
-            gi[(size_t)base * 16 + i] = w < 8 ? lr[t * 8 + w] : lc[t * 8 + w - 8];
-        }
+        for (int i = tid; i < nb * 8; i += BLOCK) gi[(size_t)base * 8 + i] = lr[i];
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
         // The candidates join a flat list (bin<<17 | image<<8 | y0<<4 | x0), in whatever order the bins arrive -- the
         // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
@@ -1302,13 +1301,20 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
             x0 = e & 15u;
             y0 = (e >> 4) & 15u;
             rk = b * P.R + (int)S.w_imgrot[(size_t)b * P.wimg + img];
-            const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * P.wimg + img) * 32);
+            const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * P.wimg + img) * 16);
             uint32_t* li = (uint32_t*)im;
+            const uint4 v0 = gi[0], v1 = gi[1];
+            const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            uint32_t r[16];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint4 v = gi[q];
-                li[4 * q] = v.x; li[4 * q + 1] = v.y; li[4 * q + 2] = v.z; li[4 * q + 3] = v.w;
+            for (int q = 0; q < 8; ++q) {
+                li[q] = w[q];                                         // row words 2q, 2q + 1
+                r[2 * q] = w[q] & 0xFFFFu;
+                r[2 * q + 1] = w[q] >> 16;
             }
+            transpose16(r);                                           // column words for the vertical run jumps
+#pragma unroll
+            for (int q = 0; q < 8; ++q) li[8 + q] = r[2 * q] | (r[2 * q + 1] << 16);
         }
         const long long t_staged = prof ? (long long)clock64() : 0;
         // ---- follow the borders, all lanes in lockstep

@@ -45,6 +45,14 @@ void host_start_candidates(const uint16_t* rows, uint32_t* out) {
     for (int y = 0; y < 16; ++y) out[y] = start_candidates(rows[y], y ? rows[y - 1] : 0u);
 }
 
+// rows[16] -> cols[16] (bit y of word x = pixel (x, y)) with the register transpose of the trace kernel
+void host_transpose16(const uint16_t* rows, uint16_t* cols) {
+    uint32_t r[16];
+    for (int y = 0; y < 16; ++y) r[y] = rows[y];
+    transpose16(r);
+    for (int x = 0; x < 16; ++x) cols[x] = (uint16_t)r[x];
+}
+
 // tooling: iterations of the border walk since the last call
 long host_trace_iters(void) { const long v = g_trace_iters; g_trace_iters = 0; return v; }
 

@@ -260,3 +260,18 @@ def test_segmented_douglas_peucker_in_lockstep_emulation(wave, ppl):
             flagged += run([walk(r2, r2.randint(20, 50)), walk(r2, r2.randint(40, 78))])
             done += 3
     assert done > 300 and flagged >= 3                                # the clean-up branch was exercised
+
+
+def test_register_transpose_of_a_level_image(host):
+    """transpose16 (the trace kernel builds the column words of its level image with it): bit y of column word x
+    == bit x of row word y, on random and extreme images."""
+    host.host_transpose16.argtypes = [u16p, u16p]
+    rng = np.random.RandomState(11)
+    imgs = [rng.rand(16, 16) < p for p in (0.05, 0.3, 0.5, 0.8) for _ in range(20)]
+    imgs += [np.zeros((16, 16), bool), np.ones((16, 16), bool), np.eye(16, dtype=bool), np.triu(np.ones((16, 16), bool))]
+    for img in imgs:                                   # img[y, x]
+        rows = np.array([sum(int(img[y, x]) << x for x in range(16)) for y in range(16)], dtype=np.uint16)
+        cols = np.zeros(16, dtype=np.uint16)
+        host.host_transpose16(rows.ctypes.data_as(u16p), cols.ctypes.data_as(u16p))
+        want = np.array([sum(int(img[y, x]) << y for y in range(16)) for x in range(16)], dtype=np.uint16)
+        assert np.array_equal(cols, want)
