@@ -293,29 +293,16 @@ __device__ inline void contour_images(const Params& P, const Lds& L, int base, b
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
     __syncthreads();
-    // Image rows without atomics: thread tid holds action cell (X, Y) = (tid/16, tid%16), so the 16
-    // lanes of a lane group are the 16 columns of row X, and the ballot of "my cell belongs to
-    // image ti" IS that row of the image.  Only this lane group ever writes word (ti, X).
+    // Image rows: thread tid holds action cell (X, Y), bit Y of row word X of the image its level belongs to.  One
+    // LDS atomic OR per rotation (16-bit half of a dword).  The lanes of a row hit one word and are serialised inside
+    // the LDS unit, which has the time; building the words from wave ballots instead (one loop trip per distinct
+    // image of the wave) cost ~30 VALU instructions per rotation and wave on a kernel that is VALU-bound.
     for (int r = 0; r < R; ++r) {
         const int code = tid < AC ? (int)L.lev[r * AC + tid] : 255;
         int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
-        if (ti >= IMGS) ti = -1;
-        if (P.Ay != 16) {                    // lane groups are not image rows: plain LDS atomics
-            if (ti >= 0) {
-                const int w = ti * 16 + X;
-                atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
-            }
-            continue;
-        }
-        unsigned long long todo = __ballot(ti >= 0);
-        while (todo) {
-            const int t0 = __builtin_amdgcn_readlane(ti, __ffsll((long long)todo) - 1);
-            const unsigned long long bal = __ballot(ti == t0);
-            todo &= ~bal;
-            if ((tid & 15) == 0) {
-                const uint32_t rowbits = (uint32_t)(bal >> (tid & 48)) & 0xFFFFu;
-                if (rowbits) rows[t0 * 16 + X] = (uint16_t)rowbits;
-            }
+        if (ti >= 0 && ti < IMGS) {
+            const int w = ti * 16 + X;
+            atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
         }
     }
     __syncthreads();

@@ -1,4 +1,4 @@
-O=gpurun_out/r3e; mkdir -p $O
+O=gpurun_out/r3f; mkdir -p $O
 R=$PWD
 timeout 1500 python -m pytest tests -m gpu -q -x > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt
 tail -3 $O/pytest_gpu.txt
@@ -14,5 +14,6 @@ run new2 blockout A=1
 run prev2 blockout IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_prev.so
 run general_new general A=1
 run general_prev general IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_prev.so
-run abc_new abc_fine A=1
-run abc_prev abc_fine IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_prev.so
+run general_narrow general IRBPP_WIDE=0
+run cube_new cube A=1
+run cube_prev cube IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_prev.so
