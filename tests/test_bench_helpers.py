@@ -1,6 +1,8 @@
 """bench.py's bookkeeping that does not need a GPU: the algorithmic-bytes formula of SURVEY.md 8(d)
 and the host-core count the CPU baseline is allowed to use."""
 import json
+
+import pytest
 import os
 import sys
 
@@ -41,8 +43,14 @@ def test_usable_cores_is_bounded_by_affinity():
     assert 1 <= n <= len(os.sched_getaffinity(0))
 
 
-def test_committed_bench_line_keeps_the_contract():
-    line = json.load(open(os.path.join(ROOT, "profiles", "r01_final", "bench_default.json")))
+@pytest.mark.parametrize("which", ["r01_final", os.path.join("r02", "final")])
+def test_committed_bench_line_keeps_the_contract(which):
+    line = json.load(open(os.path.join(ROOT, "profiles", which, "bench_default.json")))
+    if which != "r01_final":                          # round 2: north_star's 8192-bin figure, steady-state mix, ranks
+        assert line["extra"]["bins8192_one_gpu"]["value"] > line["value"] * 0.5
+        assert line["prefill_steps"] > 0 and line["episodes"]["finished_in_timed_region"] > 0
+        assert line["ranks"]["world_size"] == line["n_gpus"] == 1 and "workload" in line["config"]
+        assert line["config"]["bins_per_gpu"] == 4096 and line["vs_baseline"] is None
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert key in line, key
