@@ -10,7 +10,10 @@ region; nothing crosses PCIe inside it.
 Workload at N=1: BASELINE.json configs[1] -- BlockOut online (bufferSize=1), 4096 bins per
 GPU, resolutionA=0.02, resolutionH=0.01, R=4, S=500 (synthetic polycubes).
 Multi-GPU: bins are sharded, no data-path collective; one RCCL all-reduce of the episode
-totals after the timed region ("weak" scaling: 4096 bins per GPU).
+totals after the timed region.  Default: "weak" scaling, 4096 bins per GPU; `--config cfg4|cfg5` are north_star's
+sharded configs (8192 k=10 bins / 16384 fine-heightmap bins divided over the GPUs: "strong").
+The timed region is repeated in blocks of --steps steps until it adds up to --min-seconds, so the figure does
+not depend on how few steps the caller asked for.
 
 Prints ONE JSON line on rank 0.
 """
@@ -248,12 +251,13 @@ def pmc_profile(workload):
     return prof.get("workloads", {}).get(workload), None
 
 
-def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
+def timed_run(env, a, dev, k, barrier, steps, prefill, warmup, min_seconds=0.0, agree=None):
     """prefill (untimed: every bin deep in its own episode, terminal steps and auto-resets in the mix),
-    warm-up, then exactly `steps` timed steps between two barriers.  `env` is a GroupedPackingEnv: every group of
-    bins is stepped on its own stream, policy kernel then transition, `steps` times, without waiting for the other
-    groups (one group = one launch per kernel over all bins).  -> (seconds, transition ms per placement summed over
-    the groups' own event pairs, episodes finished inside the timed region)."""
+    warm-up, then blocks of exactly `steps` timed steps, each between two barriers, until the timed blocks add up to
+    `min_seconds` (at least one block; `agree` makes the ranks agree on "enough").  `env` is a GroupedPackingEnv: every
+    group of bins is stepped on its own stream, policy kernel then transition, without waiting for the other groups
+    (one group = one launch per kernel over all bins).  -> (seconds, timed steps, transition ms per placement summed
+    over the groups' own event pairs, episodes finished inside the timed blocks)."""
     G, per = env.num_groups, env.per
     launches = 2 if k > 1 else 1               # transitions per placement
     obs = env.reset()
@@ -279,45 +283,103 @@ def timed_run(env, a, dev, k, barrier, steps, prefill, warmup):
     torch.cuda.synchronize(dev)
 
     def one_step():
+        # wait=False: actions and buffers are long-lived and produced on the group's own stream (fused policy)
         for g in range(G):
             if k > 1:                          # one hierarchical placement: candidates of the
-                env.get_action_candidates_group(g, slot0, obs_out=loc[g])    # chosen buffer slot, then the placement
-            env.step_group(g, act[g], obs_out=nxt[g])
+                env.get_action_candidates_group(g, slot0, obs_out=loc[g], wait=False)    # chosen buffer slot, then the placement
+            env.step_group(g, act[g], obs_out=nxt[g], wait=False)
             cur[g], nxt[g] = nxt[g], cur[g]
 
     for _ in range(prefill + warmup):
         one_step()
     every = int(os.environ.get("IRBPP_BENCH_TIMING_EVERY", "4" if launches == 1 else "3"))   # odd for k > 1: both kinds of launch get sampled
-    for e in env.groups:                           # HIP events around every fourth transition, on its stream (an event
-        e.enable_kernel_timing((steps * launches + every - 1) // every, every)   # pair per step costs the stream ~5 %)
     done_before = float(env.episode_totals()[0].item())
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        one_step()
-    barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, timed_steps, kms = 0.0, 0, []
+    while True:
+        for e in env.groups:                       # HIP events around every fourth transition, on its stream (an event
+            e.enable_kernel_timing((steps * launches + every - 1) // every, every)   # pair per step costs the stream ~5 %)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        barrier()
+        elapsed += time.perf_counter() - t0
+        timed_steps += steps
+        kms.append(float(sum(e.kernel_times_ms().mean() for e in env.groups)) * launches)
+        enough = elapsed >= min_seconds
+        if agree is not None:
+            enough = agree(enough)
+        if enough:
+            break
     env.check_device_error()
-    kernel_ms = float(sum(e.kernel_times_ms().mean() for e in env.groups)) * launches
     for e in env.groups:
         e.enable_kernel_timing(0)
     finished = float(env.episode_totals()[0].item()) - done_before
-    return elapsed, kernel_ms, finished
+    return elapsed, timed_steps, float(np.mean(kms)), finished
+
+
+# BASELINE.json configs as bench modes: (workload, global bins or None = --bins per GPU, default scaling)
+CONFIGS = {
+    "cfg2": ("blockout", None, "weak"),            # BlockOut online, 4096 bins per GPU (the headline, `value` at N=1)
+    "cfg3": ("general", None, "weak"),             # General dataset, 4096 bins per GPU
+    "cfg4": ("blockout_k10", 8192, "strong"),      # BlockOut buffered k=10, 8192 bins sharded over the GPUs
+    "cfg5": ("abc_fine", 16384, "strong"),         # ABC fine heightmap, 16384 bins sharded over the GPUs
+}
+
+
+def vecenv_rate(bins, dev, steps=100):
+    """placement-steps/s through the reference-facing GpuVecEnv.step the way trainer.py:161-186 drives it: device
+    policy -> action.cpu().numpy() -> envs.step() -> (obs on device, reward CPU tensor, done numpy, infos), once with
+    the trainer's per-env Python loop over infos and once with the same bookkeeping vectorised."""
+    from irbpp_amd.vec_env import GpuVecEnv
+    shapes, seqs, kw = make_workload("blockout")
+    envs = GpuVecEnv(shapes, seqs, bins, device=dev, **kw)
+    state = envs.reset()
+    for _ in range(60):
+        state, _, _, _ = envs.step(envs.env.policy_minz(state).cpu().numpy())
+
+    def run(per_env_loop, device_actions=False):
+        nonlocal state
+        finished = 0
+        torch.cuda.synchronize(dev)
+        t = time.perf_counter()
+        for _ in range(steps):
+            action = envs.env.policy_minz(state)
+            state, reward, done, infos = envs.step(action if device_actions else action.cpu().numpy())
+            if per_env_loop:
+                for i in range(len(infos)):                 # trainer.py:167-178
+                    if done[i] and infos[i]["Valid"]:
+                        finished += 1
+            else:
+                finished += int(done.sum())
+        torch.cuda.synchronize(dev)
+        return bins * steps / (time.perf_counter() - t)
+
+    out = {"bins": bins, "with_trainer_per_env_loop": run(True), "without_per_env_loop": run(False),
+           "device_action_tensor_no_loop": run(False, True), "unit": "placement-steps/s",
+           "note": "GpuVecEnv.step incl. host actions H2D, one pinned D2H of reward/done/info + sync per step"}
+    envs.close()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=200, help="steps per timed block")
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--min-seconds", type=float, default=1.0,
+                    help="repeat the timed block of --steps steps until the timed blocks add up to this (0 = one block)")
     ap.add_argument("--prefill", type=int, default=300,
                     help="untimed steps before the warm-up that bring every bin to a steady-state episode mix")
-    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU")
-    ap.add_argument("--workload", default="blockout")
+    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU (weak scaling) / ignored for a sharded --config")
+    ap.add_argument("--workload", default=None)
+    ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json config as a bench mode")
+    ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
+                    help="weak: --bins per GPU; strong: the global bins (of --config, else --bins) divided over the GPUs")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent groups of bins, each stepped on its own stream (0 = one group)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (8192 bins, one launch group)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other configs, 8192 bins, grouped, VecEnv)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl is RCCL on ROCm "
                     "(gloo + several ranks on one device is only for dry runs of the multi-rank path)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
@@ -326,11 +388,22 @@ def main():
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         respawn_under_torchrun(a)                          # does not return
 
+    cfg_workload, cfg_global, cfg_scaling = CONFIGS[a.config] if a.config else (None, None, None)
+    workload = a.workload or cfg_workload or "blockout"
+    scaling = a.scaling or cfg_scaling or "weak"
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if scaling == "strong":
+        global_bins = cfg_global or a.bins
+        if global_bins % world:
+            raise SystemExit(f"strong scaling: {global_bins} global bins do not divide over {world} ranks")
+        bins = global_bins // world
+    else:
+        bins = a.bins
+
     from irbpp_amd import distributed as D
     cpu = None
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not a.no_cpu_baseline:
-        cpu = cpu_baseline(a.workload, a.cpu_budget)       # before HIP is initialised: the pool forks
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(workload, a.cpu_budget)         # before HIP is initialised: the pool forks
     if world != a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus} is running as {world} rank(s): launch one rank per GPU "
                          f"(torch.distributed.run --nproc-per-node {a.gpus}) or let bench.py spawn them itself")
@@ -345,75 +418,89 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from irbpp_amd.vec_env import GroupedPackingEnv
-    shapes, seqs, kw = make_workload(a.workload)
+    shapes, seqs, kw = make_workload(workload)
     groups = a.groups if a.groups > 0 else 1               # `value`: ONE group = one launch per kernel over all bins
-    env = GroupedPackingEnv(shapes, seqs, a.bins, groups, device=dev, **D.shard(rank, world, a.bins), **kw)
+    env = GroupedPackingEnv(shapes, seqs, bins, groups, device=dev, **D.shard(rank, world, bins), **kw)
     hc = env.Hx * env.Hy
     k = int(kw.get("bufferSize", 1))
 
     def barrier():
         D.barrier(dev)                 # torch.cuda.synchronize covers every group's stream
 
-    elapsed, kernel_ms, finished = timed_run(env, a, dev, k, barrier, a.steps, a.prefill, a.warmup)
+    def agree(flag):                   # every rank stops after the same block
+        return D.max_over_ranks(0.0 if flag else 1.0, dev) == 0.0
+
+    my_elapsed, timed_steps, kernel_ms, finished = timed_run(env, a, dev, k, barrier, a.steps, a.prefill, a.warmup,
+                                                             a.min_seconds, agree)
     lds_bytes, kernel_name = env.groups[0].kernel_info()
-    elapsed = D.max_over_ranks(elapsed, dev)
+    elapsed = D.max_over_ranks(my_elapsed, dev)
+    fastest = -D.max_over_ranks(-my_elapsed, dev)
     finished = float(D.reduce_totals(torch.tensor([finished, 0, 0, 0], dtype=torch.float64, device=dev))[0].item())
     tot = D.reduce_totals(env.episode_totals()).cpu().numpy()   # the only exchange: 4 doubles over RCCL
     devices = D.gather_strings(f"rank {rank}: cuda:{local_rank} {torch.cuda.get_device_name(local_rank)} "
-                               f"[{torch.cuda.get_device_properties(local_rank).gcnArchName}]")
-
-    # Extra measurement (not `value`): the same bins as four independent groups on four HIP streams
-    # (vec_env.GroupedPackingEnv), so that one group's straggler workgroups overlap the next group's kernels.  How
-    # much that gives depends on how the runtime maps the streams onto its hardware queues (measured 11.7 M or
-    # 20.7 M steps/s for the same code depending on the streams created before), hence informational only.
-    grouped = None
-    if not a.no_extra and groups == 1 and a.bins % 4 == 0 and a.bins >= 2048:
-        env.close()
-        best = None
-        for attempt in range(2):                 # two instances: the stream-to-queue mapping differs between them
-            e4 = GroupedPackingEnv(shapes, seqs, a.bins, 4, device=dev, **D.shard(rank, world, a.bins), **kw)
-            t4, _, _ = timed_run(e4, a, dev, k, barrier, a.steps, a.prefill, a.warmup)
-            t4 = D.max_over_ranks(t4, dev)
-            e4.close()
-            best = t4 if best is None else min(best, t4)
-        grouped = {"groups": 4, "value": a.bins * world * a.steps / best, "ms_per_step": best / a.steps * 1e3,
-                   "note": "better of two instances; see bench.py"}
-
+                               f"[{torch.cuda.get_device_properties(local_rank).gcnArchName}] "
+                               f"{my_elapsed / timed_steps * 1e3:.4f} ms/step")
+    env.close()
     bps = algorithmic_bytes_per_step(shapes, hc, k)
-    # north_star's target configuration, 8192 BlockOut bins on ONE GPU, measured the same way (extra, not `value`)
-    extra = None
-    if world == 1 and not a.no_extra and a.workload == "blockout" and a.bins != 8192:
-        env.close()
-        e2 = GroupedPackingEnv(shapes, seqs, 8192, groups, device=dev, **kw)
-        t2, k2, f2 = timed_run(e2, a, dev, k, barrier, a.steps, a.prefill, a.warmup)
-        extra = {"bins8192_one_gpu": {"value": 8192 * a.steps / t2, "ms_per_step": t2 / a.steps * 1e3, "kernel_ms": k2,
-                                      "roofline_frac": bps * 8192 / (t2 / a.steps) / 1e9 / HBM_PEAK_GBS,
-                                      "episodes_finished_in_timed_region": f2}}
+
+    def side_run(wl, nbins, ngroups=1, min_seconds=0.4):
+        """another configuration measured the same way on this rank's device (extras: never `value`)"""
+        sh, sq, kw2 = make_workload(wl)
+        k2 = int(kw2.get("bufferSize", 1))
+        e2 = GroupedPackingEnv(sh, sq, nbins, ngroups, device=dev, **kw2)
+        t2, n2, km2, f2 = timed_run(e2, a, dev, k2, lambda: torch.cuda.synchronize(dev), a.steps, a.prefill, a.warmup, min_seconds)
+        b2 = algorithmic_bytes_per_step(sh, e2.Hx * e2.Hy, k2)
         e2.close()
+        return {"workload": wl, "bins": nbins, "groups": ngroups, "value": nbins * n2 / t2, "ms_per_step": t2 / n2 * 1e3,
+                "steps": n2, "kernel_ms": km2, "algorithmic_bytes_per_step": b2,
+                "roofline_frac": b2 * nbins / (t2 / n2) / 1e9 / HBM_PEAK_GBS, "episodes_finished_in_timed_region": f2}
+
+    # Extra measurements on one GPU (never `value`): the same bins as four independent groups on four HIP streams
+    # (vec_env.GroupedPackingEnv: one group's straggler workgroups overlap the next group's kernels; how much that gives
+    # depends on how the runtime maps the streams onto its hardware queues, hence the better of two instances),
+    # north_star's 8192 bins on one GPU, the other BASELINE configs at their per-GPU sizes, and the rate a user of the
+    # reference-facing VecEnv API gets.
+    extra, grouped = None, None
+    if world == 1 and not a.no_extra:
+        extra = {}
+        if workload == "blockout" and groups == 1 and bins % 4 == 0 and bins >= 2048:
+            runs = [side_run(workload, bins, 4, 0.3) for _ in range(2)]
+            grouped = max(runs, key=lambda r: r["value"])
+            grouped["note"] = "better of two instances; see bench.py"
+        if workload == "blockout":
+            if bins != 8192:
+                extra["bins8192_one_gpu"] = side_run("blockout", 8192)
+            extra["cfg3_general_4096"] = side_run("general", 4096)
+            extra["cfg4_blockout_k10_1024_per_gpu"] = side_run("blockout_k10", 1024)
+            extra["cfg5_abc_fine_2048_per_gpu"] = side_run("abc_fine", 2048)
+            extra["cfg1_cube_4096"] = side_run("cube", 4096)
+            extra["vecenv_step"] = vecenv_rate(4096, dev)
 
     if rank == 0:
-        total_steps = a.bins * world * a.steps
+        total_steps = bins * world * timed_steps
         # Roofline on the whole step: the transition is four kernels per group and the groups overlap, so no single
         # launch duration prices the step's algorithmic bytes; its wall time (gaps included) does
-        achieved = bps * a.bins / (elapsed / a.steps) / 1e9
-        prof, why = pmc_profile(a.workload)
+        achieved = bps * bins / (elapsed / timed_steps) / 1e9
+        prof, why = pmc_profile(workload)
         traffic, issue = None, None
         if prof is not None:
             # HBM bytes per launch from the PMC passes (taken at prof["bins"] bins per launch, beyond the
             # Infinity Cache); bins are independent, so a launch's traffic scales with their number
-            traffic = prof["hbm_bytes_per_launch"] * a.bins / prof["bins"]
+            traffic = prof["hbm_bytes_per_launch"] * bins / prof["bins"]
             issue = prof.get("issue")
         out = {
             "metric": "env steps/sec (placements/sec) across N parallel bins",
             "value": total_steps / elapsed, "unit": "placement-steps/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "prefill_steps": a.prefill,
-            "ms_per_step": elapsed / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "n_gpus": world, "steps": timed_steps, "steps_per_block": a.steps, "min_seconds": a.min_seconds,
+            "warmup": a.warmup, "prefill_steps": a.prefill,
+            "ms_per_step": elapsed / timed_steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": f"{a.workload} {'online' if k == 1 else 'buffered'} (bufferSize={k}), {a.bins} bins/GPU, resolutionA=0.02 "
+            "config": {"workload": f"{workload} {'online' if k == 1 else 'buffered'} (bufferSize={k}), {bins} bins/GPU, resolutionA=0.02 "
                                    f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy",
-                       "bins_per_gpu": a.bins, "global_bins": a.bins * world, "parallelism": f"bins sharded x{world}",
-                       "groups_per_gpu": groups},
-            "ranks": {"world_size": world, "backend": a.backend if world > 1 else None, "devices": devices},
+                       "baseline_config": a.config, "bins_per_gpu": bins, "global_bins": bins * world,
+                       "parallelism": f"bins sharded x{world}", "groups_per_gpu": groups},
+            "ranks": {"world_size": world, "backend": a.backend if world > 1 else None, "devices": devices,
+                      "ms_per_step_min": fastest / timed_steps * 1e3, "ms_per_step_max": elapsed / timed_steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "basis": "algorithmic bytes of one step of this rank's bins / wall time of one step",
@@ -432,12 +519,11 @@ def main():
             out["roofline"]["issue"] = issue       # the kernel is instruction-issue bound, not HBM bound: SQ busy shares
         if grouped is not None:
             out["grouped_stepping"] = grouped
-        if extra is not None:
+        if extra:
             out["extra"] = extra
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

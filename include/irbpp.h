@@ -23,7 +23,7 @@
  * heightmap <= 128 x 128 cells with resolutionA an integer multiple of resolutionH and the bin an
  * integer number of action cells; n_rot <= 8; selected <= 1024; buffer_size <= 16;
  * bin[2] / resolution_z <= 31 height levels (cvTools.py:78 codes a level in 6 bits: level + 32);
- * num_bins <= 32768 per device.  Item ids are < 65536 in the placement log.
+ * num_bins <= 1048576 per device.  Item ids are < 65536 in the placement log.
  */
 #ifndef IRBPP_H
 #define IRBPP_H
@@ -66,7 +66,21 @@ typedef struct {
                                 0 off; 1 every accepted placement is also rated by a static support test
                                 (irbpp_step_out::stable_dev), results otherwise unchanged; 2 a placement that
                                 fails the test is refused like one that does not fit (episode ends)          */
+    int32_t tuning;          /* bit flags, none of which changes a result (A/B measurements and the parity test that
+                                plays lattice data through both overlap paths): IRBPP_TUNE_*; 0 = the library decides */
+    int32_t item_stream;     /* 0: trajectories (LoadItemCreator, IRcreator.py:74-103): episode e of global bin g reads row
+                                (traj_start + g + e*global_bins) % n_traj from its start.  1: one endless stream per bin
+                                (RandomItemCreator / RandomInstanceCreator / RandomCateCreator, IRcreator.py:26-72): bin b
+                                of this device reads row b % n_traj and a new episode goes on where the last one stopped
+                                (ItemCreator.reset only clears the queue); the row is a ring the host refills
+                                (irbpp_stream_cursors)                                                          */
 } irbpp_config;
+
+#define IRBPP_TUNE_NO_BLOCK_PATH  1   /* lattice data (BlockOut) through the generic overlap test too               */
+#define IRBPP_TUNE_WIDE_KERNEL    2   /* transition kernel without the 64-VGPR cap                                  */
+#define IRBPP_TUNE_NARROW_KERNEL  4   /* transition kernel under the 64-VGPR cap even on the generic path           */
+#define IRBPP_TUNE_NO_BOX_PATH    8   /* box data (Cube) through the generic overlap test too                       */
+#define IRBPP_TUNE_NO_ITEM_ORDER 16   /* launch the bins in index order instead of grouped by observed item per XCD */
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
  * adds on `done` (binPhy.py:299-311,327; monitor.py:58-75).  All device pointers, one entry
@@ -158,8 +172,37 @@ int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev);
  * how many candidate rows each bin's block holds, so a later call that is handed the same pointer stores the rows
  * that exist and clears the ones that existed before, instead of rewriting the zero tail of all `selected` rows
  * (typically 80 % of the block).  The contents delivered are the same as for an unregistered buffer.  Up to 8
- * buffers (a ring of 2-3 is what an actor loop needs); not for irbpp_reset_bins. */
+ * buffers (a ring of 2-3 is what an actor loop needs); not for irbpp_reset_bins.
+ * Lifetime: the registration is keyed by the pointer value, so unregister a buffer BEFORE freeing it (a later
+ * allocation may reuse the address); registering a pointer again, irbpp_invalidate_obs_buffer, and any library call
+ * that writes another layout through it (irbpp_step of a buffered environment) make the next emit rewrite all
+ * `selected` rows.  If the caller itself writes into a registered buffer it must invalidate it afterwards. */
 int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev);
+int irbpp_unregister_obs_buffer(irbpp_env* env, float* obs_dev);
+/* obs_dev == NULL: every registered buffer.  Asynchronous on `stream`. */
+int irbpp_invalidate_obs_buffer(irbpp_env* env, float* obs_dev, void* stream);
+
+/* item_stream = 1 only.  The position of every bin in its stream row, counted in items consumed since the row was
+ * loaded (int32[num_bins], device memory): set == 0 reads them, set != 0 writes them.  The host side of the ring
+ * (irbpp_amd/itemgen.py) reads the cursors, rewrites the consumed part of each row with irbpp_stream_write and never
+ * lets a bin run more than `length` items ahead of what it has written. */
+int irbpp_stream_cursors(irbpp_env* env, int32_t* cursors_dev, int32_t set, void* stream);
+/* Row r of the stream table gets ids_dev[r][0 .. count_dev[r]) (int32[n_traj][width], device memory) at ring positions
+ * (first_dev[r] + c) mod length. */
+int irbpp_stream_write(irbpp_env* env, const int32_t* ids_dev, const int32_t* first_dev, const int32_t* count_dev,
+                       int32_t width, void* stream);
+
+/* replaces: RandomItemCreator / RandomInstanceCreator / RandomCateCreator.generate_item (IRcreator.py:26-72) of ONE
+ * environment whose process was seeded with `seed` (= args.seed + rank, envs.py:41 -> binPhy.py:118-123): host-side,
+ * the same MT19937 words, masks and rejections as np.random.choice on the legacy global generator, so the stream of
+ * item ids equals the reference's.  n_groups > 0: two stages, name = choice(n_groups), item = choice(members of that
+ * group) with group g = members[group_offsets[g] .. group_offsets[g+1]) in the order the reference's dict holds them;
+ * n_groups == 0: one stage over `members` (RandomItemCreator).  irbpp_itemgen_draw appends `count` items. */
+typedef struct irbpp_itemgen irbpp_itemgen;
+int irbpp_itemgen_create(uint32_t seed, int32_t n_groups, const int32_t* group_offsets, const int32_t* members,
+                         int32_t n_members, irbpp_itemgen** out);
+int irbpp_itemgen_draw(irbpp_itemgen* gen, int32_t count, int32_t* out_host);
+int irbpp_itemgen_destroy(irbpp_itemgen* gen);
 
 /* -- stage-level entry points (parity tests and tooling) ------------------------------- */
 

@@ -17,8 +17,11 @@ class IrbppConfig(C.Structure):
         ("resolution_a", C.c_double), ("resolution_h", C.c_double), ("resolution_z", C.c_double),
         ("bin", C.c_double * 3), ("scale_z", C.c_double),
         ("traj_start", C.c_int32), ("global_offset", C.c_int32), ("global_bins", C.c_int32),
-        ("device", C.c_int32), ("stability", C.c_int32),
+        ("device", C.c_int32), ("stability", C.c_int32), ("tuning", C.c_int32), ("item_stream", C.c_int32),
     ]
+
+
+TUNE_NO_BLOCK_PATH, TUNE_WIDE_KERNEL, TUNE_NARROW_KERNEL, TUNE_NO_BOX_PATH, TUNE_NO_ITEM_ORDER = 1, 2, 4, 8, 16
 
 
 class IrbppReplayView(C.Structure):
@@ -51,6 +54,13 @@ SIGNATURES = {
     "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_set_auto_policy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "irbpp_register_obs_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "irbpp_unregister_obs_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "irbpp_invalidate_obs_buffer": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_stream_cursors": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "irbpp_stream_write": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "irbpp_itemgen_create": (C.c_int, [C.c_uint32, C.c_int32, c_i32_p, c_i32_p, C.c_int32, C.POINTER(C.c_void_p)]),
+    "irbpp_itemgen_draw": (C.c_int, [C.c_void_p, C.c_int32, c_i32_p]),
+    "irbpp_itemgen_destroy": (C.c_int, [C.c_void_p]),
     "irbpp_possible_position": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_heuristic_action": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_shot_item": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,

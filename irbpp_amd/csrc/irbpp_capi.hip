@@ -17,6 +17,7 @@
 #include "irbpp_device.h"
 #include "irbpp_kernels.hip"      // single translation unit: kernels + host ABI
 #include "irbpp_replay.hip"
+#include "irbpp_itemgen.h"
 
 using namespace irbpp;
 
@@ -26,7 +27,7 @@ struct irbpp_env {
     Tables T;
     State S;
     bool shapes_loaded = false, seq_loaded = false, was_reset = false;
-    bool reorder = true;                   // launch the bins most-expensive-first (IRBPP_NO_ORDER=1: identity order, A/B tool)
+    bool item_order = false;               // launch slots grouped by observed item, one contiguous range per XCD (generic path)
     long long* phase_cycles = nullptr;
     int32_t* auto_actions = nullptr;       // irbpp_set_auto_policy
     std::vector<std::pair<const float*, int32_t*>> obs_buffers;   // irbpp_register_obs_buffer: buffer -> rows per bin
@@ -120,7 +121,9 @@ void layout_lds(Params& P) {
     P.o_clist = off + P.scratch_bytes - 512;
     P.big_slot_bytes = P.scratch_bytes - 512;          // the serial redo of a border may use everything below the candidate list
     off += P.scratch_bytes;
-    if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tuning: caps workgroups per CU
+#ifdef IRBPP_ABLATE
+    if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tooling build only: caps workgroups per CU
+#endif
     P.lds_bytes = off;
     P.o_posz = off;                                    // only the heuristic kernel keeps posZValid in LDS
     P.lds_bytes_full = off + align16(P.R * P.AC * 8);
@@ -163,7 +166,7 @@ const char* irbpp_status_string(int status) {
     }
 }
 
-int irbpp_version(void) { return 200; }      // 2xx: set_auto_policy, register_obs_buffer, sumtree_sample, debug_kernel_timing_every
+int irbpp_version(void) { return 300; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
@@ -212,7 +215,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.gbins = cfg->global_bins > 0 ? cfg->global_bins : cfg->num_bins;
     P.obs_len1 = 5 * P.S + 9 + P.Hc;
     P.obs_len0 = P.K > 1 ? P.K + P.Hc : P.obs_len1;
-    if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);
+#ifdef IRBPP_ABLATE
+    if (const char* rep = getenv("IRBPP_DEBUG_REPEAT")) P.dbg_repeat = atoi(rep);   // tooling build only (tools/build_variant.sh)
+#endif
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     P.wimg = P.R * 64;
@@ -247,9 +252,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
-    env->reorder = !P.split;               // the split pipeline's transition kernel is uniform enough: ordering buys nothing (measured)
-    if (const char* no = getenv("IRBPP_NO_ORDER")) env->reorder = atoi(no) == 0;
-    {   // identity launch order until the first ordering pass (and for good with IRBPP_NO_ORDER)
+    {   // identity launch order until an ordering pass writes another one
         std::vector<int32_t> ident(N);
         for (size_t i = 0; i < N; ++i) ident[i] = (int32_t)i;
         if (hipMemcpy(S.order, ident.data(), N * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { irbpp_destroy(env); return IRBPP_ERR_HIP; }
@@ -289,7 +292,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     // Block path: the largest b (multiple of step, <= 8) such that every footprint of the dataset is a
     // union of b x b tiles that are fully masked out or fully masked in with one bottom height.
     int block_b = 0;
-    if (!getenv("IRBPP_NO_BLOCKS")) {
+    if (!(env->cfg.tuning & IRBPP_TUNE_NO_BLOCK_PATH)) {
         for (int b = 8; b >= 2 && block_b == 0; --b) {
             if (b % P.step != 0 || (P.Hx - b) % P.step != 0 || (P.Hy - b) % P.step != 0) continue;
             bool ok = true;
@@ -429,8 +432,29 @@ int irbpp_load_sequences(irbpp_env* env, const int32_t* ids, int32_t n_traj, int
     if (rc != IRBPP_OK) return rc;
     env->T.n_traj = n_traj;
     env->T.seq_len = length;
+    env->T.stream = env->cfg.item_stream ? 1 : 0;
     env->seq_loaded = true;
     return IRBPP_OK;
+}
+
+int irbpp_stream_cursors(irbpp_env* env, int32_t* cursors_dev, int32_t set, void* stream) {
+    if (!env || !cursors_dev) return IRBPP_ERR_ARG;
+    if (!env->cfg.item_stream || !env->seq_loaded) return IRBPP_ERR_STATE;
+    hipLaunchKernelGGL(irbpp_stream_cursor_kernel, dim3((env->P.N + 255) / 256), dim3(256), 0, (hipStream_t)stream, env->S.bs,
+                       cursors_dev, env->P.N, set);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
+int irbpp_stream_write(irbpp_env* env, const int32_t* ids_dev, const int32_t* first_dev, const int32_t* count_dev, int32_t width,
+                       void* stream) {
+    if (!env || !ids_dev || !first_dev || !count_dev || width < 0) return IRBPP_ERR_ARG;
+    if (!env->cfg.item_stream || !env->seq_loaded) return IRBPP_ERR_STATE;
+    if (width > env->T.seq_len) return IRBPP_ERR_ARG;
+    if (width == 0) return IRBPP_OK;
+    const long long n = (long long)env->T.n_traj * width;
+    hipLaunchKernelGGL(irbpp_stream_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       const_cast<int32_t*>(env->T.seq), env->T.n_traj, env->T.seq_len, ids_dev, first_dev, count_dev, width);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
 int irbpp_obs_len(const irbpp_env* env, int32_t which) {
@@ -439,12 +463,12 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 }
 
 // Two register budgets of the transition kernel.  The block path (lattice data) is short on work per bin and wants
-// residency: 80 VGPRs, six workgroups per CU.  The generic path keeps eight float64 accumulators and a chunk of
-// scalar operands live in its inner loop: unconstrained (108 VGPRs, four workgroups per CU) it is 8 % faster than
-// squeezed into 80 (measured on "general": 8.5 vs 7.9 M steps/s), and its larger LDS layouts cap residency anyway.
-static bool use_wide_kernel(const Params& P) {
-    static const char* force = getenv("IRBPP_WIDE");            // A/B tool: 0 / 1 forces the build
-    if (force) return atoi(force) != 0;
+// residency: 64 VGPRs, eight workgroups per CU (4096 bins are exactly two rounds of the chip).  The generic and box
+// paths run on the unconstrained build, whose larger LDS layouts cap residency anyway.
+static bool use_wide_kernel(const irbpp_env* env) {
+    const Params& P = env->P;
+    if (env->cfg.tuning & IRBPP_TUNE_WIDE_KERNEL) return true;      // A/B measurements (irbpp_config::tuning)
+    if (env->cfg.tuning & IRBPP_TUNE_NARROW_KERNEL) return false;
     return P.block_b == 0 || 6 * P.lds_bytes > 150 * 1024;
 }
 
@@ -453,27 +477,27 @@ static bool use_wide_kernel(const Params& P) {
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
     io.auto_action = env->auto_actions;
-    io.use_order = env->reorder ? 1 : 0;
+    io.use_order = 0;
     io.obs_rows = nullptr;
-    if (mode != MODE_RESET || io.bin_list == nullptr)                    // (reset_specific writes a row per listed bin: never a registered buffer)
-        for (auto& rb : env->obs_buffers)
-            if (rb.first == io.obs) io.obs_rows = rb.second;
-    if ((mode == MODE_STEP || mode == MODE_CANDS) && env->reorder)      // most expensive bins first (see irbpp_env_kernel)
-        hipLaunchKernelGGL(irbpp_order_kernel, dim3(1), dim3(1024), 0, st, env->S.cost, env->S.order, first, n);
+    const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
+    for (auto& rb : env->obs_buffers)
+        if (rb.first == io.obs) {
+            // reset_specific writes a row per LISTED bin and a buffered environment's step / reset write the order
+            // observation: through a registered pointer either leaves the per-bin row counts meaningless
+            if (observes && !(mode == MODE_RESET && io.bin_list != nullptr)) io.obs_rows = rb.second;
+            else hipMemsetAsync(rb.second, 0xFF, (size_t)env->P.N * sizeof(int32_t), st);
+        }
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
     // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
-    const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
     const bool split = env->P.split && observes;
     StepIO io_env = io;
-    if (!use_wide_kernel(env->P))
+    if (!use_wide_kernel(env))
         hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
     else
         hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
-        static const int tg = getenv("IRBPP_TRACE_GRID_PCT") ? atoi(getenv("IRBPP_TRACE_GRID_PCT")) : 100;      // A/B tools: grid sizes in
-        static const int pg = getenv("IRBPP_POLY_GRID_PCT") ? atoi(getenv("IRBPP_POLY_GRID_PCT")) : 200;        // per cent of the bins
-        const int tgrid = n * tg / 100 > 0 ? n * tg / 100 : 1, pgrid = n * pg / 100 > 0 ? n * pg / 100 : 1;
+        const int tgrid = n, pgrid = 2 * n;      // (half / a third of either grid with striding measured -4 ... -9 %)
         hipLaunchKernelGGL(irbpp_trace_kernel, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
         hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
@@ -580,16 +604,41 @@ int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev) {
 
 int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev) {
     if (!env || !obs_dev) return IRBPP_ERR_ARG;
-    for (auto& rb : env->obs_buffers)
-        if (rb.first == obs_dev) return IRBPP_OK;
-    if (env->obs_buffers.size() >= 8) return IRBPP_ERR_ARG;
     HIP_TRY(hipSetDevice(env->cfg.device));
+    for (auto& rb : env->obs_buffers)
+        if (rb.first == obs_dev) {           // registered again (e.g. a new allocation at an old address): contents unknown
+            HIP_TRY(hipMemset(rb.second, 0xFF, (size_t)env->P.N * sizeof(int32_t)));
+            return IRBPP_OK;
+        }
     int32_t* rows = nullptr;
-    int rc = dev_alloc(env, &rows, (size_t)env->P.N);
-    if (rc != IRBPP_OK) return rc;
+    for (auto& rb : env->obs_buffers)        // a slot freed by irbpp_unregister_obs_buffer keeps its row counts' memory
+        if (rb.first == nullptr && rows == nullptr) { rows = rb.second; rb.first = obs_dev; }
+    if (rows == nullptr) {
+        if (env->obs_buffers.size() >= 8) return IRBPP_ERR_ARG;
+        int rc = dev_alloc(env, &rows, (size_t)env->P.N);
+        if (rc != IRBPP_OK) return rc;
+        env->obs_buffers.emplace_back(obs_dev, rows);
+    }
     HIP_TRY(hipMemset(rows, 0xFF, (size_t)env->P.N * sizeof(int32_t)));      // -1: contents unknown, write everything once
-    env->obs_buffers.emplace_back(obs_dev, rows);
     return IRBPP_OK;
+}
+
+int irbpp_unregister_obs_buffer(irbpp_env* env, float* obs_dev) {
+    if (!env || !obs_dev) return IRBPP_ERR_ARG;
+    for (auto& rb : env->obs_buffers)
+        if (rb.first == obs_dev) { rb.first = nullptr; return IRBPP_OK; }
+    return IRBPP_ERR_ARG;
+}
+
+int irbpp_invalidate_obs_buffer(irbpp_env* env, float* obs_dev, void* stream) {
+    if (!env) return IRBPP_ERR_ARG;
+    bool found = obs_dev == nullptr;
+    for (auto& rb : env->obs_buffers)
+        if (rb.first != nullptr && (obs_dev == nullptr || rb.first == obs_dev)) {
+            HIP_TRY(hipMemsetAsync(rb.second, 0xFF, (size_t)env->P.N * sizeof(int32_t), (hipStream_t)stream));
+            found = true;
+        }
+    return found ? IRBPP_OK : IRBPP_ERR_ARG;
 }
 
 int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double* posz_dev, uint8_t* mask_dev, void* stream) {
@@ -732,7 +781,7 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide) {
     if (!env || !lds_bytes || !wide) return IRBPP_ERR_ARG;
     *lds_bytes = env->P.lds_bytes;
-    *wide = use_wide_kernel(env->P) ? 1 : 0;
+    *wide = use_wide_kernel(env) ? 1 : 0;
     return IRBPP_OK;
 }
 

@@ -10,6 +10,7 @@
 //                                of the generic path's positions (read-only, shared by all bins -> L2 / MALL resident)
 //   seq       i32 [n_traj][L]    pre-drawn item ids
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace irbpp {
@@ -30,7 +31,7 @@ constexpr int NXCD = 8;                            // accelerator dies of the MI
 constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each
 constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;   // a round record of the polygon kernel: [points | border length | border
                                                                      // start] per position, then the vertex-row index of the position's border
-constexpr int MAX_BINS = 32768;                   // bins per device: a flat-list entry has 15 bits for the bin (irbpp_create refuses more)
+constexpr int MAX_BINS = 1 << 20;                 // bins per device (irbpp_create refuses more): keeps every per-launch index an int32
 
 struct ShapeRot {
     int32_t fx, fy;        // footprint in heightmap cells: ceil(round(extents,6)/resH)  (space.py:105)
@@ -72,6 +73,7 @@ struct Tables {
     const double* volume;  // [n_shapes]
     const int32_t* seq;    // [n_traj][seq_len]
     int32_t n_shapes, n_traj, seq_len;
+    int32_t stream;        // irbpp_config::item_stream: rows of seq are per-bin item rings instead of trajectories
 };
 
 // Per-bin scalars, one 64-byte line per bin: a transition touches exactly one line of it.
@@ -110,8 +112,8 @@ struct State {
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
     uint16_t* w_img;       // [N][wimg][16] level images: 16 row words (bit x of word y = pixel (x, y))
     uint8_t* w_imgrot;     // [N][wimg] rotation of each level image
-    uint32_t* w_cand;      // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
-                           // bin<<17 | image<<8 | y0<<4 | x0
+    uint2* w_cand;         // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
+                           // (bin, image<<8 | y0<<4 | x0)
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
     uint8_t* w_round;      // [NXCD][round_cap][ROUND_BYTES] round records, trace kernel -> polygon kernel
     int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list

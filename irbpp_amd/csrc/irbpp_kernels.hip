@@ -107,14 +107,19 @@ __device__ inline int block_scan_flag(bool flag, int* red, int& total) {
 // LoadItemCreator.generate_item (IRcreator.py:97-103) on the pre-drawn trajectories; the
 // trajectory of global bin g in its e-th episode is (traj_start + g + e*global_bins) % n_traj.
 // The 64-bit modulo runs once per episode (trajectory_row, kept in BinState::traj_row), not per item.
+// Stream mode (irbpp_config::item_stream, the Random*Creator classes of IRcreator.py:26-72): bin b of this device owns
+// row b % n_traj for good, the row is a ring the host keeps ahead of the bin, and `cursor` counts the items the bin has
+// drawn since the row was loaded -- a new episode goes on where the last one stopped (ItemCreator.reset only clears
+// the queue).
 __device__ inline int trajectory_row(const Params& P, const Tables& T, int b, int episode) {
-    long long row = (long long)P.traj_start + P.goff + b + (long long)episode * P.gbins;
+    long long row = T.stream ? (long long)b : (long long)P.traj_start + P.goff + b + (long long)episode * P.gbins;
     row %= T.n_traj;
     if (row < 0) row += T.n_traj;
     return (int)row;
 }
 __device__ inline int fetch_item(const Tables& T, const State& S, int row, int cursor) {
-    if (cursor >= T.seq_len) return -1;
+    if (T.stream) cursor = (int)((uint32_t)cursor % (uint32_t)T.seq_len);
+    else if (cursor >= T.seq_len) return -1;
     const int id = T.seq[(long long)row * T.seq_len + cursor];
     if (id >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); return -1; }
     return id < 0 ? -1 : id;
@@ -1121,7 +1126,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         const uint32_t* lr = (const uint32_t*)L.img;
         for (int i = tid; i < nb * 8; i += BLOCK) gi[(size_t)base * 8 + i] = lr[i];
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
-        // The candidates join a flat list (bin<<17 | image<<8 | y0<<4 | x0), in whatever order the bins arrive -- the
+        // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
         // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
         // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
         // between the eight L2s with every allocation (measured: +22 us per launch).  The LDS list holds CLIST
@@ -1130,19 +1135,29 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         for (int sub = 0; sub < nsub; ++sub) {
             const int total = contour_list(L, my_cand, nsub, sub);
             if (tid == 0) {
-                int at = 0;
+                // This die's list; should it be full (the dispatcher gave this die far more than its share of speckled
+                // bins, or the device runs in a partition mode where XCC_ID does not spread the workgroups over eight
+                // values) the batch goes to the next list that has room.  A failed reservation is taken back, so the
+                // counters end up exact; the lists together hold twice the worst case of all bins.
+                int at = -1, seg = xcd;
                 if (total > 0) {
-                    at = atomicAdd(ka->S.w_total + xcd * XCD_STRIDE, total);
-                    if (at + total > P.seg_cap) { atomicOr(S.err, IRBPP_DEVERR_CAPACITY); at = -1; }
+                    for (int k = 0; k < NXCD && at < 0; ++k) {
+                        seg = (xcd + k) & (NXCD - 1);
+                        const int got = atomicAdd(ka->S.w_total + seg * XCD_STRIDE, total);
+                        if (got + total <= P.seg_cap) at = got;
+                        else atomicSub(ka->S.w_total + seg * XCD_STRIDE, total);
+                    }
+                    if (at < 0) atomicOr(S.err, IRBPP_DEVERR_CAPACITY);
                 }
                 L.redi[11] = at;
+                L.redi[12] = seg;
             }
             __syncthreads();
             if (L.redi[11] >= 0) {
-                uint32_t* flat = ka->S.w_cand + (size_t)xcd * P.seg_cap + L.redi[11];
+                uint2* flat = ka->S.w_cand + (size_t)L.redi[12] * P.seg_cap + L.redi[11];
                 for (int i = tid; i < total; i += BLOCK) {
                     const uint32_t e = L.clist[i];
-                    flat[i] = ((uint32_t)b << 17) | ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u);
+                    flat[i] = make_uint2((uint32_t)b, ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u));
                 }
             }
             ncand += total;
@@ -1279,8 +1294,9 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
         uint16_t* const im = simg + lane * TRACE_ISTRIDE;
         uint8_t* const my_slot = slots + lane * SLOT;
         if (have) {
-            const uint32_t e = S.w_cand[g];
-            const int b = (int)(e >> 17), img = (int)((e >> 8) & 511u);
+            const uint2 ce = S.w_cand[g];
+            const uint32_t e = ce.y;
+            const int b = (int)ce.x, img = (int)((e >> 8) & 511u);
             x0 = e & 15u;
             y0 = (e >> 4) & 15u;
             rk = b * P.R + (int)S.w_imgrot[(size_t)b * P.wimg + img];
@@ -1417,7 +1433,7 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
                 for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
         }
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
-            const int b0 = (int)(S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW] >> 17);
+            const int b0 = (int)S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW].x;
             long long* row = prof + (size_t)b0 * PHASE_ROW;
             const long long t_end = (long long)clock64();
             row[11] = t_end - t_start;
@@ -1560,7 +1576,10 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     if (mode == MODE_STEP) {                          // round 2: candidate key, the next item of the trajectory
         st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);
         st_key = st_a < st_nrows ? S.cand[(size_t)b * P.S + st_a] : 0u;     // rows beyond the last are zeros
-        if (P.K == 1) st_next = st_cursor < T.seq_len ? T.seq[(long long)st_trow * T.seq_len + st_cursor] : -1;
+        if (P.K == 1) {
+            const int at = T.stream ? (int)((uint32_t)st_cursor % (uint32_t)T.seq_len) : st_cursor;
+            st_next = at < T.seq_len ? T.seq[(long long)st_trow * T.seq_len + at] : -1;
+        }
     }
     __syncthreads();
 
@@ -1586,10 +1605,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             // episode is dropped without statistics (monitor.py reset)
             const int ep = (some || io.reset_next) ? ps->episode + 1 : 0;
             const int trow = trajectory_row(P, T, b, ep);
-            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, i);
+            const int c0 = T.stream ? ps->cursor : 0;                // a stream goes on, a trajectory starts at its first item
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, c0 + i);
             ps->episode = ep;
             ps->traj_row = trow;
-            ps->cursor = P.K;
+            ps->cursor = c0 + P.K;
             ps->cur_item = -1;
             ps->nvalid = 0;
             ps->order_action = 0;
@@ -1744,8 +1764,9 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 const int trow = trajectory_row(P, T, b, ep);
                 ps->episode = ep;
                 ps->traj_row = trow;
-                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, i);
-                ps->cursor = P.K;
+                const int c0 = T.stream ? st_cursor : 0;
+                for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, c0 + i);
+                ps->cursor = c0 + P.K;
                 ps->item_idx = 0;
                 ps->ratio_acc = 0.0;
                 ps->ep_reward = 0.0;
@@ -2003,6 +2024,23 @@ irbpp_policy_minz_kernel(const float* obs, int obs_stride, int S_rows, int N, in
         if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
     }
     if (lane == 0) actions[wave] = bi == 0x7fffffff ? 0 : bi;
+}
+
+// irbpp_stream_cursors / irbpp_stream_write: the host side of the item ring of stream mode
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_stream_cursor_kernel(BinState* bs, int32_t* cursors, int N, int set) {
+    const int b = blockIdx.x * BLOCK + threadIdx.x;
+    if (b >= N) return;
+    if (set) bs[b].cursor = cursors[b];
+    else cursors[b] = bs[b].cursor;
+}
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_stream_write_kernel(int32_t* seq, int n_traj, int seq_len, const int32_t* ids, const int32_t* first, const int32_t* count,
+                          int width) {
+    const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= (long long)n_traj * width) return;
+    const int row = (int)(t / width), c = (int)(t - (long long)row * width);
+    if (c < count[row]) seq[(long long)row * seq_len + (int)((uint32_t)(first[row] + c) % (uint32_t)seq_len)] = ids[t];
 }
 
 extern "C" __global__ void __launch_bounds__(BLOCK)

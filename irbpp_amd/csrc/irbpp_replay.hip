@@ -102,7 +102,9 @@ irbpp_sumtree_update_kernel(float* __restrict__ tree, float* __restrict__ maxp, 
         float m = maxp[env];
         for (int j = 0; j < b; ++j) {
             const float v = prio[(size_t)env * b + j];
-            row[tree_idx[(size_t)env * b + j]] = v;
+            const int64_t ti = tree_idx[(size_t)env * b + j];
+            if (ti < cap - 1 || ti >= len) continue;     // not a leaf of this row: never write outside the staged tree
+            row[ti] = v;
             m = fmaxf(m, v);                             // self.max = max(value, self.max)
         }
         maxp[env] = m;

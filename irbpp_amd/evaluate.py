@@ -1,4 +1,6 @@
-"""Batched evaluation in the shape of the reference's ``tools.test`` (tools.py:303-358).
+"""Batched evaluation in the shape of the reference's ``tools.test`` (tools.py:303-358) and, for buffered
+environments, ``tools.test_hierachical`` (tools.py:361-431: order action -> get_action_candidates -> location action
+per placement).
 
 The reference evaluates one environment, episode after episode, over the trajectories of
 ``test_sequence.pt`` (LoadItemCreator, IRcreator.py:74-103: episode e reads trajectory e+1) and
@@ -28,13 +30,18 @@ def rotation_quaternion_xyzw(rot_idx: int) -> np.ndarray:
     return np.array([0.0, 0.0, z, w])
 
 
-def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] = None, device="cuda:0",
+def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] = None,
+             order_policy: Optional[Callable] = None, device="cuda:0",
              names: Optional[Dict[int, str]] = None, traj_start: int = 1, max_steps: int = 4096,
              log_capacity: int = 256, save: Optional[str] = None, **env_kw):
     """Run ``n_episodes`` evaluation episodes, one per bin.
 
-    ``policy(env, obs) -> int32[N] device tensor`` picks the actions; default = the scripted MINZ
-    policy kernel.  Returns a dict with the statistics ``tools.test`` prints and ``trajs``: a list
+    ``policy(env, loc_obs) -> int32[N] device tensor`` picks the location actions; default = the scripted MINZ
+    policy kernel.  With ``bufferSize`` > 1 every placement follows tools.py:379-388: ``order_policy(env, order_obs)
+    -> int32[N]`` picks the buffer slot (orderDQN.act; default slot 0), ``get_action_candidates`` builds the location
+    observation of that item (binPhy.py:161-169), ``policy`` acts on it, ``step`` places the item and refills the
+    queue (update_item_queue + generate_item, binPhy.py:324-325).
+    Returns a dict with the statistics ``tools.test`` prints and ``trajs``: a list
     over episodes of ``env.packed`` (binPhy.py:296), i.e. one row ``[item_id, name, positionFLB(3),
     quaternion_xyzw(4)]`` per placement INCLUDING the refused one that ended the episode (the reference
     appends before it looks at ``success``).  ``save``: also write them as ``tools.test`` does
@@ -42,8 +49,6 @@ def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] =
     """
     env = GpuPackingEnv(shapes, sequences, n_episodes, device=device, traj_start=traj_start,
                         global_bins=n_episodes, **env_kw)
-    if env.K != 1:
-        raise ValueError("evaluate() drives the online (bufferSize=1) protocol of tools.test")
     meta, logz = env.enable_placement_log(log_capacity)
     res_a = env_kw.get("resolutionA", 0.02)
     scale = np.array([100.0, 100.0, 100.0])
@@ -56,8 +61,14 @@ def evaluate(shapes, sequences, n_episodes: int, *, policy: Optional[Callable] =
     length = np.zeros(n, dtype=np.int64)
     trajs = [None] * n
     pick = policy if policy is not None else (lambda e, o: e.policy_minz(o))
+    slot0 = torch.zeros((n,), dtype=torch.int32, device=env.device)
+    pick_order = order_policy if order_policy is not None else (lambda e, o: slot0)
     for _ in range(max_steps):
-        obs, _, _ = env.step(pick(env, obs))
+        if env.K > 1:                                     # tools.py:379-388
+            loc = env.get_action_candidates(pick_order(env, obs).to(torch.int32))
+            obs, _, _ = env.step(pick(env, loc))
+        else:
+            obs, _, _ = env.step(pick(env, obs))
         h = env.step_info_host()
         newly = h["done"] & ~finished
         if newly.any():

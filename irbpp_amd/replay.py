@@ -279,7 +279,7 @@ class VectorReplayMemory(object):
         if self._lib is not None:                                  # all B leaves of every env in one launch
             from . import _lib
             _lib.check(self._lib.irbpp_sumtree_update(_p(self.sum_tree), _p(self.max), N, self.capacity,
-                                                      _p(tree_idxs.to(self.device).contiguous()), _p(pr.contiguous()), B, _p(None),
+                                                      _p(tree_idxs.to(self.device, torch.int64).contiguous()), _p(pr.contiguous()), B, _p(None),
                                                       _stream(self.device)), "irbpp_sumtree_update")
             return
         for j in range(B):
@@ -308,7 +308,7 @@ def masked_greedy_action(q: torch.Tensor, state: torch.Tensor, selected_action: 
         return masked.argmax(1)
     from . import _lib
     q = q.to(torch.float32).contiguous()
-    state = state.contiguous()
+    state = state.to(torch.float32).contiguous()         # the kernel reads the validity flags as float32
     out = torch.empty((q.shape[0],), dtype=torch.int64, device=q.device)
     _lib.check(lib.irbpp_masked_argmax(_p(q), q.stride(0), _p(state), state.stride(0), int(selected_action), q.shape[0],
                                        _p(out), _stream(q.device)), "irbpp_masked_argmax")

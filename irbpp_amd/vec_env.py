@@ -51,7 +51,8 @@ class GpuPackingEnv(object):
                  resolutionA: float = 0.02, resolutionH: float = 0.01, resolutionZ: float = 0.01,
                  bin_dimension=BIN_DIMENSION, selectedAction: int = 500, bufferSize: int = 1,
                  scale_z: float = 100.0, traj_start: int = 1, global_offset: int = 0,
-                 global_bins: Optional[int] = None, device="cuda:0", stability: int = 0):
+                 global_bins: Optional[int] = None, device="cuda:0", stability: int = 0, tuning: int = 0,
+                 item_stream: int = 0):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise RuntimeError("GpuPackingEnv needs a HIP device; irbpp_amd has no CPU fallback")
@@ -70,7 +71,7 @@ class GpuPackingEnv(object):
             resolution_a=resolutionA, resolution_h=resolutionH, resolution_z=resolutionZ,
             bin=(C.c_double * 3)(*bin_r), scale_z=scale_z, traj_start=traj_start,
             global_offset=global_offset, global_bins=self.num_bins if global_bins is None else global_bins,
-            device=dev_index, stability=int(stability))
+            device=dev_index, stability=int(stability), tuning=int(tuning), item_stream=int(item_stream))
         self._h = C.c_void_p()
         torch.cuda.set_device(self.device)
         _lib.check(self.lib.irbpp_create(C.byref(cfg), C.byref(self._h)), "irbpp_create")
@@ -91,7 +92,10 @@ class GpuPackingEnv(object):
         n = self.num_bins
         off_err = (34 * n + 3) & ~3
         self._out = torch.zeros((off_err + 4,), dtype=torch.uint8, device=self.device)
-        self._out_host = torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True)
+        # two pinned host copies, used in turn: the arrays step_info_host returns are views of one of them and stay
+        # valid until the step after the next (the trainer is done with `infos` long before, trainer.py:167-186)
+        self._out_hosts = [torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
+        self._out_turn = 0
         self._out_f64 = self._out[:24 * n].view(torch.float64).view(3, n)           # reward, ratio, ep_reward
         self._out_i32 = self._out[24 * n:32 * n].view(torch.int32).view(2, n)       # counter, ep_len
         self._out_done = self._out[32 * n:33 * n]
@@ -189,6 +193,17 @@ class GpuPackingEnv(object):
         _lib.check(self.lib.irbpp_register_obs_buffer(self._h, _ptr(obs)), "irbpp_register_obs_buffer")
         return obs
 
+    def unregister_obs_buffer(self, obs: torch.Tensor) -> None:
+        """Give a registered buffer back (before it is freed: the registration is keyed by its address)."""
+        _lib.check(self.lib.irbpp_unregister_obs_buffer(self._h, _ptr(obs)), "irbpp_unregister_obs_buffer")
+        self._obs_buffers = [t for t in getattr(self, "_obs_buffers", []) if t.data_ptr() != obs.data_ptr()]
+
+    def invalidate_obs_buffers(self, obs: Optional[torch.Tensor] = None) -> None:
+        """After the caller wrote into a registered buffer itself (all of them with ``None``): the next emit through it
+        rewrites every row."""
+        if getattr(self, "_obs_buffers", None):
+            _lib.check(self.lib.irbpp_invalidate_obs_buffer(self._h, _ptr(obs), self._stream()), "irbpp_invalidate_obs_buffer")
+
     # -- stage-level access (tests, tooling) ---------------------------------------------------
     def possible_position(self, item_ids: torch.Tensor):
         posz = torch.empty((self.num_bins, self.n_rot, self.Ax, self.Ay), dtype=torch.float64, device=self.device)
@@ -277,16 +292,18 @@ class GpuPackingEnv(object):
         stream synchronisation -> dict of numpy arrays.  Raises if a kernel raised its error word."""
         n = self.num_bins
         st = torch.cuda.current_stream(self.device)
-        self._out_host.copy_(self._out, non_blocking=True)
+        host = self._out_hosts[self._out_turn]
+        self._out_turn ^= 1
+        host.copy_(self._out, non_blocking=True)
         st.synchronize()
-        h = self._out_host.numpy()
+        h = host.numpy()
         err = int(h[-4:].view(np.int32)[0])
         if err:
             raise _lib.IrbppError(f"device error flags={err}: " + _lib.load().irbpp_status_string(-4).decode())
         f64 = h[:24 * n].view(np.float64).reshape(3, n)
         i32 = h[24 * n:32 * n].view(np.int32).reshape(2, n)
-        return dict(reward=f64[0].copy(), ratio=f64[1].copy(), ep_reward=f64[2].copy(), counter=i32[0].copy(),
-                    ep_len=i32[1].copy(), done=h[32 * n:33 * n].astype(bool), stable=h[33 * n:34 * n].astype(bool))
+        return dict(reward=f64[0], ratio=f64[1], ep_reward=f64[2], counter=i32[0], ep_len=i32[1],
+                    done=h[32 * n:33 * n].view(np.bool_), stable=h[33 * n:34 * n].view(np.bool_))
 
     def close(self):
         if getattr(self, "_h", None) is not None and self._h.value:
@@ -309,8 +326,14 @@ class GroupedPackingEnv(object):
     see irbpp_capi.hip).  This is the shape of an actor loop with double-buffered environment groups: act on
     group g while the other groups step.  Group g owns the global bins [g*n/G, (g+1)*n/G) and row block g of
     every [num_bins, ...] tensor; trajectories are assigned by global bin index, so results are the same as
-    one GpuPackingEnv over all bins (tests/test_gpu_parity.py).  Nothing here synchronises except
-    ``synchronize()`` and ``reset()``."""
+    one GpuPackingEnv over all bins (tests/test_grouped.py).  Nothing here synchronises except
+    ``synchronize()`` and ``reset()``.
+
+    Stream discipline: ``step`` / ``get_action_candidates`` make every group's stream wait for the caller's current
+    stream (the actions may have been computed there) and tell the caching allocator that the action and
+    observation tensors are in use on the group streams (``record_stream``), so a temporary the caller drops right
+    after the call is not handed out again before the kernels have read it.  The ``*_group`` methods do the same
+    for their one stream."""
 
     def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_bins: int, num_groups: int = 4, *, device="cuda:0",
                  global_offset: int = 0, global_bins: Optional[int] = None, **kw):
@@ -342,36 +365,48 @@ class GroupedPackingEnv(object):
             cur.wait_stream(st)
         return obs
 
-    def step_group(self, g: int, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
-        """Group g alone, on its stream: (obs, reward, done) of its ``per`` bins."""
+    def _enter(self, g: int, *tensors, wait: bool = True) -> None:
+        """Group g's stream is about to read/write ``tensors`` that live on (and may be produced by) the current stream."""
+        st = self.streams[g]
+        cur = torch.cuda.current_stream(self.device)
+        if wait and st != cur:
+            st.wait_stream(cur)
+            for t in tensors:
+                if t is not None:
+                    t.record_stream(st)
+
+    def step_group(self, g: int, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, wait: bool = True):
+        """Group g alone, on its stream: (obs, reward, done) of its ``per`` bins.  ``wait=False``: the caller vouches
+        that the tensors are long-lived and were produced on group g's own stream (the fused policy,
+        ``policy_minz_group``): no cross-stream dependency is inserted."""
+        self._enter(g, actions, obs_out, wait=wait)
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].step(actions, obs_out=obs_out)
 
-    def policy_minz_group(self, g: int, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None):
+    def policy_minz_group(self, g: int, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None, wait: bool = True):
+        self._enter(g, loc_obs, actions_out, wait=wait)
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].policy_minz(loc_obs, actions_out=actions_out)
 
-    def get_action_candidates_group(self, g: int, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+    def get_action_candidates_group(self, g: int, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None,
+                                    wait: bool = True):
+        self._enter(g, order_actions, obs_out, wait=wait)
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].get_action_candidates(order_actions, obs_out=obs_out)
 
     def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Every group on its own stream (no join): row block g of the result belongs to stream g until
-        ``synchronize()``.  ``actions`` must be ready on the current stream."""
+        ``synchronize()``.  ``actions`` may still be in flight on the current stream."""
         obs = obs_out if obs_out is not None else \
             torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
-        cur = torch.cuda.current_stream(self.device)
         for g in range(self.num_groups):
-            self.streams[g].wait_stream(cur)
             self.step_group(g, actions[self.rows(g)], obs_out=obs[self.rows(g)])
         return obs
 
     def get_action_candidates(self, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         obs = obs_out if obs_out is not None else \
             torch.empty((self.num_bins, self.loc_obs_len), dtype=torch.float32, device=self.device)
-        cur = torch.cuda.current_stream(self.device)
         for g in range(self.num_groups):
-            self.streams[g].wait_stream(cur)
             self.get_action_candidates_group(g, order_actions[self.rows(g)], obs_out=obs[self.rows(g)])
         return obs
 
@@ -436,15 +471,24 @@ class _Infos(Sequence):
 
 
 class GpuVecEnv(object):
-    """Drop-in for ``VecPyTorch(ShmemVecEnv(...))`` as the trainer uses it (trainer.py:148,165,267,281)."""
+    """Drop-in for ``VecPyTorch(ShmemVecEnv(...))`` as the trainer uses it (trainer.py:148,165,267,281).
+
+    ``obs_ring`` (default 3): observations are written into a ring of that many buffers owned by the environment
+    and, for online environments, registered with the library (``irbpp_register_obs_buffer``: only the candidate
+    rows that exist are stored), instead of a fresh allocation with a full rewrite per step.  The tensor a call
+    returns is therefore overwritten ``obs_ring`` observation-producing calls later -- the trainer keeps ``state``
+    across exactly one step (trainer.py:184-186,213) and the replay memory copies what it stores, so 3 leaves a
+    spare; a caller that holds observations for longer passes ``obs_ring=0`` (a fresh tensor per call).  Do not
+    write into a returned tensor except through ``reset_specific``'s documented pattern (it invalidates the ring)."""
 
     closed = False
 
     def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0",
-                 allow_early_resets: bool = True, num_groups: int = 1, **env_kw):
+                 allow_early_resets: bool = True, num_groups: int = 1, obs_ring: int = 3, feeder=None, **env_kw):
         """``num_groups`` > 1: the envs are stepped as that many independent groups on their own HIP streams
         (GroupedPackingEnv); ``step()`` still covers all envs, and ``step_async(actions, group=g)`` /
-        ``step_wait(group=g)`` let an actor loop work on one group while the others step."""
+        ``step_wait(group=g)`` let an actor loop work on one group while the others step.
+        ``feeder``: an ``itemgen.StreamFeeder`` for environments created with ``item_stream=1``."""
         self.num_groups = int(num_groups)
         if self.num_groups > 1:
             self.env = GroupedPackingEnv(shapes, sequences, num_envs, self.num_groups, device=device, **env_kw)
@@ -461,35 +505,97 @@ class GpuVecEnv(object):
         self._pending = None
         self._group_pending = {}
         self.tstart = time.time()
+        self.feeder = feeder
+        if feeder is not None:
+            if self.num_groups > 1:
+                raise ValueError("item streams are fed to a single-group environment")
+            feeder.attach(self.env)
+        # persistent action buffers: pinned staging for host actions (no pageable bounce), one device tensor
+        self._act_host = torch.empty((num_envs,), dtype=torch.int32, pin_memory=True)
+        self._act_dev = torch.empty((num_envs,), dtype=torch.int32, device=self.device)
+        self._ring, self._loc_ring, self._turn, self._loc_turn = [], [], 0, 0
+        for _ in range(max(0, int(obs_ring))):
+            self._ring.append(self._new_buffer(self.obs_len, register=self.env.K == 1))
+            if self.env.K > 1:
+                self._loc_ring.append(self._new_buffer(self.env.loc_obs_len, register=True))
+
+    def _envs_and_rows(self):
+        if self.num_groups > 1:
+            return [(e, self.env.rows(g)) for g, e in enumerate(self.env.groups)]
+        return [(self.env, slice(0, self.num_envs))]
+
+    def _new_buffer(self, width: int, register: bool) -> torch.Tensor:
+        t = torch.zeros((self.num_envs, width), dtype=torch.float32, device=self.device)
+        if register:
+            for e, rows in self._envs_and_rows():
+                e.register_obs_buffer(t[rows])
+        return t
+
+    def _next_obs(self) -> Optional[torch.Tensor]:
+        if not self._ring:
+            return None
+        t = self._ring[self._turn]
+        self._turn = (self._turn + 1) % len(self._ring)
+        return t
 
     def _actions_to_device(self, actions) -> torch.Tensor:
-        if isinstance(actions, torch.Tensor):
+        """int32[N] on the device, in flight on the current stream.  Host actions go through the pinned staging buffer
+        (one asynchronous H2D); a device tensor is converted in place of a copy when it already is int32."""
+        if isinstance(actions, torch.Tensor) and actions.is_cuda:
             a = actions.reshape(-1)
-        else:
-            a = torch.from_numpy(np.ascontiguousarray(np.asarray(actions).reshape(-1)))
+            assert a.numel() == self.num_envs
+            if a.dtype == torch.int32 and a.is_contiguous():
+                return a
+            self._act_dev.copy_(a)
+            return self._act_dev
+        a = actions.reshape(-1) if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions).reshape(-1))
         assert a.numel() == self.num_envs
-        return a.to(device=self.device, dtype=torch.int32, non_blocking=True)
+        self._act_host.copy_(a)                                              # dtype conversion on the host
+        self._act_dev.copy_(self._act_host, non_blocking=True)
+        return self._act_dev
 
     def reset(self) -> torch.Tensor:
         if self.waiting_step:
             self.step_wait()
         self.tstart = time.time()
-        return self.env.reset()
+        out = self._next_obs()
+        if out is None:
+            return self.env.reset()
+        if self.num_groups > 1:
+            cur = torch.cuda.current_stream(self.device)
+            for g, (e, st) in enumerate(zip(self.env.groups, self.env.streams)):
+                st.wait_stream(cur)
+                with torch.cuda.stream(st):
+                    _lib.check(e.lib.irbpp_reset(e._h, _ptr(out[self.env.rows(g)]), e._stream()), "irbpp_reset")
+                cur.wait_stream(st)
+        else:
+            e = self.env
+            _lib.check(e.lib.irbpp_reset(e._h, _ptr(out), e._stream()), "irbpp_reset")
+        return out
 
     def step_async(self, actions, group: Optional[int] = None) -> None:
         """All envs, or (grouped envs only) the envs of one group: ``actions`` then has that group's length."""
         if group is not None:
             if self._group_pending.get(group) is not None:
                 raise RuntimeError("already running an async step")
-            e = self.env.groups[group]
-            a = actions if isinstance(actions, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(actions).reshape(-1)))
-            with torch.cuda.stream(self.env.streams[group]):
-                obs, _, _ = e.step(a.reshape(-1).to(device=self.device, dtype=torch.int32, non_blocking=True))
+            per = self.env.per
+            if isinstance(actions, torch.Tensor) and actions.is_cuda:
+                a = actions.reshape(-1).to(dtype=torch.int32)
+            else:                                                           # this group's slice of the staging buffers
+                a = actions.reshape(-1) if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions).reshape(-1))
+                rows = self.env.rows(group)
+                self._act_host[rows].copy_(a)
+                self._act_dev[rows].copy_(self._act_host[rows], non_blocking=True)
+                a = self._act_dev[rows]
+            assert a.numel() == per
+            # the group's stream waits for whatever produced `a` on the current stream, and the allocator learns that
+            # `a` (possibly a temporary of the caller) is read there
+            obs, _, _ = self.env.step_group(group, a)
             self._group_pending[group] = obs
             return
         if self.waiting_step:
             raise RuntimeError("already running an async step")          # vec_env.py:7-16
-        res = self.env.step(self._actions_to_device(actions))
+        res = self.env.step(self._actions_to_device(actions), obs_out=self._next_obs())
         self._pending = res if isinstance(res, torch.Tensor) else res[0]
         self.waiting_step = True
 
@@ -506,9 +612,14 @@ class GpuVecEnv(object):
         if not self.waiting_step:
             raise RuntimeError("not running an async step")              # vec_env.py:19-27
         obs = self._pending
-        h = self.env.step_info_host()                # ONE D2H copy per (group of) envs, error word included: the sync point
+        # ONE pinned D2H copy per (group of) envs, error word included, and the step's only synchronisation.  It cannot
+        # be deferred: the reward comes back as a CPU tensor (envs.py:164) that the trainer clips right away
+        # (trainer.py:180-181), and it travels in the same copy as done / infos.
+        h = self.env.step_info_host()
         self._pending = None
         self.waiting_step = False
+        if self.feeder is not None:
+            self.feeder.tick()
         reward = torch.from_numpy(h["reward"]).unsqueeze(dim=1).float()   # envs.py:164
         return obs, reward, h["done"], _Infos(h, round(time.time() - self.tstart, 6))
 
@@ -522,8 +633,13 @@ class GpuVecEnv(object):
     candidates_on_device = False
 
     def get_action_candidates(self, order_actions):
-        """Location observations [N, 5S+9+Hc] of the chosen buffer slots (shmem_vec_env.py:99-102)."""
-        loc = self.env.get_action_candidates(self._actions_to_device(order_actions))
+        """Location observations [N, 5S+9+Hc] of the chosen buffer slots (shmem_vec_env.py:99-102): a host float32
+        array by default, the device tensor with ``candidates_on_device``."""
+        out = None
+        if self._loc_ring:
+            out = self._loc_ring[self._loc_turn]
+            self._loc_turn = (self._loc_turn + 1) % len(self._loc_ring)
+        loc = self.env.get_action_candidates(self._actions_to_device(order_actions), obs_out=out)
         if self.candidates_on_device:
             return loc
         if self.num_groups > 1:
@@ -531,7 +647,9 @@ class GpuVecEnv(object):
         return loc.cpu().numpy()
 
     def reset_specific(self, indexs) -> torch.Tensor:
-        """shmem_vec_env.py:113-117: reset the listed envs only; their observations in list order."""
+        """shmem_vec_env.py:113-117: reset the listed envs only; their observations in list order (a fresh tensor).
+        A caller that copies these rows into the state tensor it holds (a ring buffer of this class) may do so: the
+        ring's registrations are invalidated here, so the next observation through each buffer is written in full."""
         if not self.allow_early_resets:                                    # every env is mid-episode: auto-reset
             raise RuntimeError("Tried to reset an environment before done. If you want to allow early "
                                "resets, pass allow_early_resets=True")     # monitor.py:45-46
@@ -541,6 +659,8 @@ class GpuVecEnv(object):
         if len(np.unique(idx)) != len(idx) or (len(idx) and (idx.min() < 0 or idx.max() >= self.num_envs)):
             raise ValueError("reset_specific needs distinct env indices in [0, num_envs)")
         obs = self.env.reset_bins(torch.from_numpy(idx).to(self.device))
+        for e, _ in self._envs_and_rows():
+            e.invalidate_obs_buffers()
         self.env.check_device_error()
         return obs
 
@@ -555,18 +675,39 @@ class GpuVecEnv(object):
 
 def make_vec_envs(args, log_dir=None, allow_early_resets=False):
     """Same triple as envs.make_vec_envs (envs.py:67-99): (envs, [obs_space, act_space], obs_len).
-    ``args`` is the reference's namespace plus ``args.sequences`` (pre-drawn item ids) and either
-    ``args.shapes`` (a ShapeSet) or the reference's ``args.shotInfo``/``args.infoDict``."""
+
+    ``args`` is the reference's namespace.  Shapes: ``args.shapes`` (a ShapeSet) or the reference's ``args.shotInfo`` /
+    ``args.infoDict``.  Items, in this order:
+      * ``args.sequences`` (pre-drawn item ids, int32[n_traj][L]) if present -- trajectories, as in evaluation;
+      * ``args.evaluate`` with ``args.test_name``: the trajectories of ``test_sequence.pt`` (LoadItemCreator,
+        binPhy.py:58-59);
+      * otherwise the training-time creators of binPhy.py:60-67 (``args.dataSample`` over ``args.dicPath``), every
+        environment on its own np.random stream seeded ``args.seed + rank`` exactly like envs.py:41: the items each
+        environment sees are the ones the reference's worker of that rank would have drawn (itemgen.py).
+    """
     shapes = getattr(args, "shapes", None)
     if shapes is None:
         shapes = shape_set_from_reference(args.shotInfo, args.infoDict)
     dev = args.device if isinstance(args.device, (str, torch.device)) else f"cuda:{int(args.device)}"
-    envs = GpuVecEnv(shapes, args.sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
-                     resolutionA=args.resolutionA, resolutionH=args.resolutionH,
-                     resolutionZ=getattr(args, "resolutionZ", 0.01),
-                     bin_dimension=tuple(getattr(args, "bin_dimension", BIN_DIMENSION)),
-                     selectedAction=args.selectedAction, bufferSize=args.bufferSize,
-                     scale_z=float(getattr(args, "scale", [100, 100, 100])[2]))
+    kw = dict(resolutionA=args.resolutionA, resolutionH=args.resolutionH,
+              resolutionZ=getattr(args, "resolutionZ", 0.01),
+              bin_dimension=tuple(getattr(args, "bin_dimension", BIN_DIMENSION)),
+              selectedAction=args.selectedAction, bufferSize=args.bufferSize,
+              scale_z=float(getattr(args, "scale", [100, 100, 100])[2]))
+    sequences, feeder = getattr(args, "sequences", None), None
+    if sequences is None and getattr(args, "evaluate", False) and getattr(args, "test_name", None):
+        seqs = torch.load(args.test_name, weights_only=False)
+        length = max(len(t) for t in seqs)
+        sequences = np.full((len(seqs), length), -1, dtype=np.int32)
+        for i, t in enumerate(seqs):
+            sequences[i, :len(t)] = [(-1 if v is None else int(v)) for v in t]
+    if sequences is None:
+        from . import itemgen
+        feeder = itemgen.StreamFeeder(itemgen.streams_for_args(args, args.num_processes),
+                                      ring_len=int(getattr(args, "item_ring", 4096)), buffer_size=args.bufferSize)
+        sequences, kw["item_stream"] = feeder.initial, 1
+    envs = GpuVecEnv(shapes, sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
+                     feeder=feeder, **kw)
     return envs, [envs.observation_space, envs.action_space], envs.obs_len
 
 

@@ -136,6 +136,14 @@ class COracleVecEnv(object):
     def get_action_candidates(self, order_actions):
         return np.array([e.get_action_candidates(int(a)) for e, a in zip(self.envs, order_actions)])
 
+    def reset_specific(self, indexs):
+        """shmem_vec_env.py:113-117: per-env reset of the listed envs (next trajectory, no episode statistics)."""
+        out = []
+        for i in indexs:
+            self.rewards[i] = []
+            out.append(self.envs[i].reset())
+        return np.array(out).reshape(len(out), self.obs_len)
+
     def step(self, actions):
         obs, rews, dones, infos = [], [], [], []
         for i, (e, a) in enumerate(zip(self.envs, actions)):

@@ -92,12 +92,41 @@ class SequenceItemCreator(ItemCreator):
         self.item_index += 1
 
 
+class RandomStreamItemCreator(ItemCreator):
+    """RandomItemCreator / RandomInstanceCreator / RandomCateCreator (IRcreator.py:26-72): every item is one or two
+    ``np.random.choice`` draws on the worker's generator, which envs.py:41 -> binPhy.py:118-123 seeds with
+    ``seed + rank``.  The worker's global generator is a ``RandomState(seed)`` here so that several environments can
+    live in one process; ``reset`` only clears the queue (IRcreator.py:11-12), the stream goes on."""
+
+    def __init__(self, seed, dic_path=None, kind="instance", n_items=None):
+        super().__init__()
+        self.rs = np.random.RandomState(seed)
+        self.kind = kind
+        if kind == "instance":                                   # IRcreator.py:35-46
+            self.groups = {}
+            for k in dic_path.keys():
+                self.groups.setdefault(dic_path[k][0:-6], []).append(k)
+        elif kind == "category":                                 # IRcreator.py:53-68
+            self.groups = {"objects": [], "concave": [], "board": []}
+            for k, item in zip(dic_path.keys(), dic_path.values()):
+                self.groups[item.split("/")[0]].append(k)
+        else:                                                    # 'pose': RandomItemCreator over np.arange(n)
+            self.item_set = np.arange(0, n_items)
+
+    def generate_item(self, **kwargs):
+        if self.kind == "pose":
+            self.item_list.append(int(self.rs.choice(self.item_set)))                  # IRcreator.py:32-33
+        else:
+            name = self.rs.choice(list(self.groups.keys()))                             # IRcreator.py:49-51, 70-72
+            self.item_list.append(int(self.rs.choice(self.groups[name])))
+
+
 class PackingGame(object):
     """binPhy.py:21-337 without pybullet."""
 
     def __init__(self, shapes, sequences, resolutionA=0.02, resolutionH=0.01, resolutionZ=0.01,
                  bin_dimension=(0.32, 0.32, 0.30), selectedAction=500, bufferSize=1,
-                 scale=(100, 100, 100), first_traj=1, traj_stride=1, stability=0):
+                 scale=(100, 100, 100), first_traj=1, traj_stride=1, stability=0, item_creator=None):
         self.stability = stability           # the stability proxy (oracle/stability.py); 0 = the reference's no-physics path
         self.last_stable = False
         self.resolutionAct = resolutionA
@@ -113,7 +142,7 @@ class PackingGame(object):
         self.rangeX_A, self.rangeY_A = np.ceil(self.bin_dimension[0:2] / self.resolutionAct).astype(np.int32)
         self.space = Space(self.bin_dimension, self.resolutionAct, self.resolutionH, self.ZRotNum,
                            shapes.shot_info(), shapes.extents)
-        self.item_creator = SequenceItemCreator(sequences, first_traj, traj_stride)
+        self.item_creator = item_creator if item_creator is not None else SequenceItemCreator(sequences, first_traj, traj_stride)
         self.next_item_vec = np.zeros((9))
         self.item_vec = np.zeros((1000, 9))
         self.item_idx = 0
@@ -263,10 +292,11 @@ class OracleVecEnv(object):
     ``info['episode']`` (wrapper/monitor.py:58-75).  Observations stay float64;
     ``to_float32`` applies the VecPyTorch cast (envs.py:151,163)."""
 
-    def __init__(self, num_envs, shapes, sequences, traj_start=1, global_offset=0, global_num=None, **kw):
+    def __init__(self, num_envs, shapes, sequences, traj_start=1, global_offset=0, global_num=None, item_creators=None, **kw):
         global_num = num_envs if global_num is None else global_num
-        self.envs = [PackingGame(shapes, sequences, first_traj=traj_start + global_offset + g,
-                                 traj_stride=global_num, **kw) for g in range(num_envs)]
+        self.envs = [PackingGame(shapes, sequences, first_traj=traj_start + global_offset + g, traj_stride=global_num,
+                                 item_creator=None if item_creators is None else item_creators[g], **kw)
+                     for g in range(num_envs)]
         self.num_envs = num_envs
         self.obs_len = self.envs[0].obs_len
         self.rewards = [[] for _ in range(num_envs)]

@@ -10,7 +10,8 @@ What executes from /root/reference, unmodified:
     environment/physics0/cvTools.py   find_out_contour, find_convex_vetex, convexHulls,
                                       getConvexHullActions
     environment/physics0/IRcreator.py ItemCreator, LoadItemCreator
-    tools.py                          test (the evaluation loop, with a stub agent), get_mask_from_state
+    tools.py                          test, test_hierachical (the evaluation loops, with stub agents), get_mask_from_state
+    environment/physics0/IRcreator.py RandomItemCreator, RandomInstanceCreator, RandomCateCreator on np.random
     environment/physics0/binPhy.py    PackingGame.__init__/reset/cur_observation/
                                       get_action_candidates/action_to_position/prejudge/
                                       step/get_ratio/get_item_ratio
@@ -375,6 +376,96 @@ def tools_test_golden(episodes=5):
                 avg_reward=np.array(avg_reward), avg_length=np.array(avg_length))
 
 
+def argmin_order_action(order_obs, k):
+    """Scripted order policy of the hierarchical goldens: the buffer slot holding the smallest item id, first on
+    ties -- a function of the order observation alone, so that a batched evaluation can reproduce it."""
+    return int(np.argmin(np.asarray(order_obs)[:k]))
+
+
+def tools_test_hier_golden(episodes=5, k=3):
+    """The reference's own hierarchical evaluation loop ``tools.test_hierachical`` (tools.py:361-431) with two stub
+    agents (order: argmin_order_action, location: scripted MINZ): the statistics it returns and its ``trajs.npy``."""
+    import importlib
+    ref_tools = importlib.import_module("tools")
+    blk = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    seqs = synthetic.make_sequences(blk.n_shapes, 16, 80, seed=1)
+    ref_tools.make_eval_env = lambda args: make_reference_env(blk, seqs, buffer_size=k)
+
+    class _Net(object):
+        training = True
+
+        def eval(self):
+            self.training = False
+
+        def train(self):
+            self.training = True
+
+    class _Order(object):
+        online_net = _Net()
+
+        def act(self, state, mask):
+            return torch.tensor(argmin_order_action(state[0].numpy().astype(np.float64), k))
+
+    class _Loc(object):
+        online_net = _Net()
+
+        def act_e_greedy(self, state, mask, epsilon):
+            return torch.tensor(minz_action(state[0].numpy().astype(np.float64), 500))
+
+    args = types.SimpleNamespace(evaluation_episodes_test=episodes, device="cpu", bufferSize=k, selectedAction=500, action_space=500)
+    real_save = np.save
+    ref_tools.np.save = lambda path, a: real_save(path, np.array(a, dtype=object), allow_pickle=True)
+    cwd, tmp = os.getcwd(), tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "logs", "evaluation", "golden"))
+    os.chdir(tmp)
+    try:
+        avg_reward, avg_length = ref_tools.test_hierachical(args, [_Order(), _Loc()], False, "golden", "")
+    finally:
+        os.chdir(cwd)
+        ref_tools.np.save = real_save
+    trajs = np.load(os.path.join(tmp, "logs", "evaluation", "golden", "trajs.npy"), allow_pickle=True)
+    ep_len = np.array([len(ep) for ep in trajs])
+    rows = [row for ep in trajs for row in ep]
+    return dict(seq=seqs, k=np.array(k), ep_len=ep_len, ids=np.array([r[0] for r in rows]), names=np.array([r[1] for r in rows]),
+                pos=np.array([np.asarray(r[2], dtype=np.float64) for r in rows]),
+                quat=np.array([np.asarray(r[3], dtype=np.float64) for r in rows]),
+                avg_reward=np.array(avg_reward), avg_length=np.array(avg_length))
+
+
+def random_creator_golden(n_items=400):
+    """The reference's own RandomInstanceCreator / RandomCateCreator / RandomItemCreator (IRcreator.py:26-72) drawing
+    on the global numpy generator seeded like envs.py:41 (seed + rank): the item streams of ranks 0..3 and what
+    preview / update_item_queue / generate_item make of them."""
+    import contextlib
+    import io
+    dic_inst = {k: "%s_%d.obj" % (["mug", "bowl", "box", "can", "lamp"][k % 5 if k < 17 else 4], k // 5) for k in range(23)}
+    dic_cate = {k: "%s/%d.obj" % (["objects", "concave", "board"][(k * 7) % 3], k) for k in range(19)}
+    out = {"seed": np.array(123), "dic_inst_keys": np.array(list(dic_inst.keys())), "dic_inst_vals": np.array(list(dic_inst.values())),
+           "dic_cate_keys": np.array(list(dic_cate.keys())), "dic_cate_vals": np.array(list(dic_cate.values()))}
+    for kind in ("instance", "category", "pose"):
+        streams = []
+        for rank in range(4):
+            with contextlib.redirect_stdout(io.StringIO()):        # the constructors print their tables
+                if kind == "instance":
+                    c = ref_ircreator.RandomInstanceCreator(np.arange(0, len(dic_inst)), dic_inst)
+                elif kind == "category":
+                    c = ref_ircreator.RandomCateCreator(np.arange(0, len(dic_cate)), dic_cate)
+                else:
+                    c = ref_ircreator.RandomItemCreator(np.arange(0, 29))
+            np.random.seed(123 + rank)                              # PackingGame.seed (binPhy.py:118-123) via envs.py:41
+            items = []
+            c.reset()
+            while len(items) < n_items:                             # an episode: preview(1), then pop + generate per step
+                items.append(int(c.preview(1)[0]))
+                c.update_item_queue(0)
+                c.generate_item()
+                if len(items) % 37 == 0:
+                    c.reset()                                       # ItemCreator.reset only clears the queue: the stream goes on
+            streams.append(items)
+        out["stream_" + kind] = np.array(streams)
+    return out
+
+
 def main():
     cube = synthetic.cube_shapes()
     blk = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
@@ -389,6 +480,8 @@ def main():
     np.savez_compressed(os.path.join(OUT, "cvtools_cases.npz"), **cvtools_cases())
     np.savez_compressed(os.path.join(OUT, "ircreator_trace.npz"), **ircreator_trace())
     np.savez_compressed(os.path.join(OUT, "tools_test.npz"), **tools_test_golden())
+    np.savez_compressed(os.path.join(OUT, "tools_test_hier.npz"), **tools_test_hier_golden())
+    np.savez_compressed(os.path.join(OUT, "random_creators.npz"), **random_creator_golden())
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

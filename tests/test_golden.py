@@ -128,3 +128,40 @@ def test_tools_test_trajectories_match_reference(golden_dir):
         lens.append(steps)
     assert row == len(g["ids"])
     assert abs(np.mean(rsums) - float(g["avg_reward"])) < 1e-12 and np.mean(lens) == float(g["avg_length"])
+
+
+def test_tools_test_hierachical_trajectories_match_reference(golden_dir):
+    """tools.test_hierachical itself (tools.py:361-431, run by make_golden.py with two stub agents: order = the slot
+    with the smallest item id, location = scripted MINZ) on a k = 3 buffer: ``env.packed`` of every episode and the
+    statistics, reproduced by the oracle's PackingGame driven through the same protocol."""
+    from irbpp_amd.evaluate import rotation_quaternion_xyzw
+    from irbpp_amd import synthetic
+    g = _load(golden_dir, "tools_test_hier")
+    k = int(g["k"])
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    env = PackingGame(sh, g["seq"], selectedAction=S, bufferSize=k)
+    row, rsums, lens = 0, [], []
+    for ep_len in g["ep_len"]:
+        order_obs = env.reset()
+        rsum = steps = 0
+        while True:
+            loc = env.get_action_candidates(int(np.argmin(order_obs[:k])))
+            had_candidate = bool((loc[:5 * S].reshape(S, 5)[:, 4] == 1).any())
+            order_obs, r, d, info = env.step(minz_action(loc, S))
+            rsum += r
+            steps += 1
+            if d:
+                break
+        assert len(env.packed) == ep_len == steps
+        for i, (item, rot, lx, ly, height) in enumerate(env.packed):
+            assert item == g["ids"][row] and g["names"][row] == "%d.obj" % item
+            if i < ep_len - 1 or had_candidate:
+                pos = np.round((lx * 0.02, ly * 0.02, 0.30), decimals=6) * 100.0
+                pos[2] = height * 100.0
+                np.testing.assert_allclose(pos / 100.0, g["pos"][row], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(rotation_quaternion_xyzw(rot), g["quat"][row], rtol=0, atol=1e-12)
+            row += 1
+        rsums.append(rsum)
+        lens.append(steps)
+    assert row == len(g["ids"])
+    assert abs(np.mean(rsums) - float(g["avg_reward"])) < 1e-12 and np.mean(lens) == float(g["avg_length"])

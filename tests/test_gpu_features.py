@@ -1,0 +1,168 @@
+"""GPU parity of the round-3 additions around the hot path: hierarchical evaluation against the golden of the
+reference's own tools.test_hierachical, the training-time item streams behind make_vec_envs against the oracle's
+restatement of the random item creators, lattice data through both overlap paths, the registered-buffer lifetime
+calls."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd import _lib, synthetic
+from irbpp_amd.vec_env import GpuPackingEnv, GpuVecEnv, make_vec_envs
+from oracle.packing import OracleVecEnv, RandomStreamItemCreator
+from helpers import minz_action
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S = 500
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+def test_hierarchical_evaluation_matches_the_reference_golden(golden_dir, tmp_path):
+    """evaluate(bufferSize=k, order_policy=...) against tools.test_hierachical's own trajs.npy and statistics
+    (tests/golden/make_golden.py: tools_test_hier.npz; tools.py:361-431)."""
+    from irbpp_amd.evaluate import evaluate
+    g = np.load(os.path.join(golden_dir, "tools_test_hier.npz"))
+    k = int(g["k"])
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    path = str(tmp_path / "logs" / "evaluation" / "run" / "trajs.npy")
+    out = evaluate(sh, g["seq"], len(g["ep_len"]), device=DEV, save=path, bufferSize=k,
+                   order_policy=lambda env, order_obs: order_obs[:, :k].argmin(dim=1))
+    assert out["episodes"] == len(g["ep_len"]) and out["unfinished"] == 0
+    trajs = np.load(path, allow_pickle=True)
+    assert len(trajs) == len(g["ep_len"])
+    row = 0
+    for ep, want_len in zip(trajs, g["ep_len"]):
+        assert len(ep) == want_len
+        for i, (item, name, pos, quat) in enumerate(ep):
+            assert item == g["ids"][row] and name == g["names"][row]
+            if i < want_len - 1 or g["pos"][row][2] < 1e3:     # (a refused "action 0" with no valid candidate: see test_gpu_parity)
+                np.testing.assert_allclose(pos, g["pos"][row], rtol=0, atol=1e-12)
+                np.testing.assert_allclose(quat, g["quat"][row], rtol=0, atol=1e-12)
+            row += 1
+    assert row == len(g["ids"])
+    assert abs(out["avg_reward"] - float(g["avg_reward"])) < 1e-9 and out["avg_length"] == float(g["avg_length"])
+
+
+@pytest.mark.parametrize("k,sample", [(1, "instance"), (3, "instance"), (1, "category"), (2, "pose")])
+def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample):
+    """make_vec_envs(args) with nothing but the reference's namespace (no args.sequences): every environment draws its
+    items like the reference's worker of that rank (RandomInstanceCreator / RandomCateCreator / RandomItemCreator on
+    np.random seeded seed + rank; IRcreator.py:26-72, envs.py:41).  The oracle side restates the creators on numpy's
+    RandomState itself; the product side is csrc/irbpp_itemgen.h + the per-bin item rings of stream mode, here with
+    a ring of 64 items so that the feeder has to refill it many times."""
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    if sample == "instance":
+        dic = {i: "%s_%d.obj" % (["tee", "ell", "bar", "zig"][i % 4], i // 4) for i in range(20)}
+    elif sample == "category":
+        dic = {i: "%s/%d.obj" % (["objects", "concave", "board"][(i * 5) % 3], i) for i in range(20)}
+    else:
+        dic = {i: "%d.obj" % i for i in range(20)}
+    n, seed = 6, 321
+    args = types.SimpleNamespace(
+        num_processes=n, device=0, seed=seed, shapes=sh, dicPath=dic, dataSample=sample, resolutionA=0.02,
+        resolutionH=0.01, resolutionZ=0.01, bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S,
+        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=64)
+    envs, spaces, obs_len = make_vec_envs(args, "./logs/runinfo", True)
+    envs.candidates_on_device = True
+    creators = [RandomStreamItemCreator(seed + i, dic, sample, n_items=20) for i in range(n)]
+    oenv = OracleVecEnv(n, sh, None, item_creators=creators, bufferSize=k)
+    gobs, oobs = envs.reset(), _f32(oenv.reset())
+    np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+    ndone, refills = 0, 0
+    written0 = envs.feeder.written.copy()
+    for t in range(170):
+        if k > 1:
+            order = (np.arange(n) + t) % k
+            gloc = envs.get_action_candidates(order)
+            oloc = _f32(oenv.get_action_candidates(order))
+            np.testing.assert_array_equal(gloc.cpu().numpy(), oloc)
+        else:
+            oloc = oobs
+        act = np.array([minz_action(o, S) for o in oloc])
+        gobs, grew, gdone, ginfo = envs.step(act)
+        oobs, orew, odone, oinfo = oenv.step(act)
+        oobs = _f32(oobs)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), oobs, err_msg=f"step {t}")
+        np.testing.assert_array_equal(gdone, odone)
+        ndone += int(odone.sum())
+        if t == 60:                                     # a mid-episode reset(): queues are dropped, the streams go on
+            gobs, oobs = envs.reset(), _f32(oenv.reset())
+            np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+        if t == 100:                                    # ... and a per-env reset
+            sub = envs.reset_specific([4, 1])
+            ref = _f32(oenv.reset_specific([4, 1]))
+            np.testing.assert_array_equal(sub.cpu().numpy(), ref)
+            for j, i in enumerate([4, 1]):
+                gobs[i] = sub[j]
+                oobs[i] = ref[j]
+    refills = int(((envs.feeder.written - written0) > 0).sum())
+    envs.env.check_device_error()
+    envs.close()
+    assert ndone >= 6 and refills == n and int((envs.feeder.written - written0).min()) > 64    # the rings went round
+
+
+def test_lattice_data_agrees_on_both_overlap_paths():
+    """irbpp_config::tuning = IRBPP_TUNE_NO_BLOCK_PATH plays BlockOut through the generic overlap test (and the
+    unconstrained transition kernel): every observation equals the block path's."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload("blockout")
+    n = 128
+    a = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, **kw)
+    b = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, tuning=_lib.TUNE_NO_BLOCK_PATH, **kw)
+    assert "wide" not in a.kernel_info()[1] and "wide" in b.kernel_info()[1]
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    for t in range(140):
+        act = a.policy_minz(oa)
+        oa, ra, da = a.step(act)
+        ob, rb, db = b.step(act)
+        assert torch.equal(oa, ob), f"step {t}"
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+    ids = torch.arange(n, dtype=torch.int32, device=DEV) % shapes.n_shapes
+    pa, ma = a.possible_position(ids)
+    pb, mb = b.possible_position(ids)
+    assert torch.equal(pa, pb) and torch.equal(ma, mb)
+    a.check_device_error()
+    b.check_device_error()
+    a.close()
+    b.close()
+
+
+def test_registered_buffer_lifetime_calls():
+    """irbpp_unregister_obs_buffer / irbpp_invalidate_obs_buffer / registering an address again: a buffer
+    the caller scribbled over, or a new allocation at an old address, delivers complete observations again."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload("blockout")
+    n = 64
+    a = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, **kw)
+    b = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, **kw)
+    buf = torch.zeros((n, a.loc_obs_len), dtype=torch.float32, device=DEV)
+    a.register_obs_buffer(buf)
+    oa, ob = a.reset(), b.reset()
+    act = b.policy_minz(ob)
+    for t in range(40):
+        if t % 10 == 5:
+            buf.fill_(3.25)                              # the caller writes into the registered buffer ...
+            a.invalidate_obs_buffers(buf)                # ... and says so
+        if t == 20:
+            a.unregister_obs_buffer(buf)
+            buf.fill_(-1.0)                              # unregistered: plain full writes
+        if t == 30:
+            buf.fill_(9.0)
+            a.register_obs_buffer(buf)                   # the same address registered again: contents unknown
+        oa, _, _ = a.step(act, obs_out=buf)
+        ob, _, _ = b.step(act)
+        assert torch.equal(oa, ob), f"step {t}"
+        act = b.policy_minz(ob)
+    lib = a.lib
+    import ctypes as C
+    assert lib.irbpp_unregister_obs_buffer(a._h, C.c_void_p(ob.data_ptr())) == -1      # never registered
+    a.close()
+    b.close()

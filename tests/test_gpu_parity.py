@@ -231,14 +231,16 @@ def test_convex_hull_actions_golden_and_random(golden_dir):
         env.close()
 
 
-@pytest.mark.parametrize("n,parts", [(4096, 2), (8192, 4)])
-def test_full_size_properties_and_sharding_invariance(n, parts):
-    """BASELINE config 2 at full width (4096 bins) and at north_star's 8192 bins on one GPU:
-    size-independent properties instead of an oracle run, and the same bins as `parts` shards."""
-    sh = synthetic.blockout_shapes(n_shapes=64, n_rot=4, seed=0)
-    seqs = synthetic.make_sequences(sh.n_shapes, 10000, 160, seed=123)
-    env = GpuPackingEnv(sh, seqs, n, device=DEV)
-    half = [GpuPackingEnv(sh, seqs, n // parts, device=DEV, global_offset=o, global_bins=n)
+@pytest.mark.parametrize("workload,n,parts,steps", [("blockout", 4096, 2, 110), ("blockout", 8192, 4, 110),
+                                                    ("general", 4096, 2, 60), ("abc_fine", 2048, 2, 60)])
+def test_full_size_properties_and_sharding_invariance(workload, n, parts, steps):
+    """BASELINE config 2 at full width (4096 bins) and at north_star's 8192 bins on one GPU, config 3 at its 4096 bins
+    and config 5 at its 2048 bins per GPU: size-independent properties instead of an oracle run, the C oracle on 64
+    sampled bins, and the same bins as `parts` shards."""
+    from bench import make_workload
+    sh, seqs, kw = make_workload(workload)
+    env = GpuPackingEnv(sh, seqs, n, device=DEV, **kw)
+    half = [GpuPackingEnv(sh, seqs, n // parts, device=DEV, global_offset=o, global_bins=n, **kw)
             for o in range(0, n, n // parts)]
     obs = env.reset()
     hobs = [h.reset() for h in half]
@@ -249,10 +251,10 @@ def test_full_size_properties_and_sharding_invariance(n, parts):
     from oracle.c_oracle import COracleVecEnv
     starts = [0, n // 3, n // 2 - 8, n - 16]
     sample = np.concatenate([np.arange(o, o + 16) for o in starts])
-    cenvs = [COracleVecEnv(16, sh, seqs, global_offset=o, global_num=n) for o in starts]
+    cenvs = [COracleVecEnv(16, sh, seqs, global_offset=o, global_num=n, **kw) for o in starts]
     np.testing.assert_array_equal(obs[sample].cpu().numpy(), _f32(np.concatenate([c.reset() for c in cenvs])))
     ndone = 0
-    for t in range(110):
+    for t in range(steps):
         act = env.policy_minz(obs)
         item = obs[:, 5 * S].to(torch.int64)
         obs, rew, done = env.step(act)
@@ -628,7 +630,7 @@ def test_tooling_hooks_time_and_locate_every_bin():
 
 
 @pytest.mark.parametrize("workload,n,steps", [("blockout", 192, 130), ("general", 96, 45), ("cube", 128, 60),
-                                              ("blockout_k10", 128, 120), ("abc_fine", 48, 40),
+                                              ("blockout_k10", 128, 120), ("abc_fine", 256, 80),
                                               ("blockout_r8", 96, 150)])
 def test_many_bins_full_episodes_vs_c_oracle(workload, n, steps):
     """Scale check made possible by the C oracle: the bench workloads themselves (every BASELINE config:
@@ -681,15 +683,29 @@ def test_bench_gpus2_spawns_two_real_ranks():
     env = dict(os.environ)
     for var in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(var, None)
-    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--bins", "256",
-                          "--steps", "5", "--warmup", "2", "--prefill", "120", "--no-cpu-baseline"],
-                         capture_output=True, text=True, timeout=600, env=env)
-    assert res.returncode == 0, res.stderr[-2000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
-    out = json.loads(lines[0])
+    def run(*flags):
+        res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+                              "--warmup", "2", "--no-cpu-baseline", *flags],
+                             capture_output=True, text=True, timeout=600, env=env)
+        assert res.returncode == 0, res.stderr[-2000:]
+        lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, res.stdout[-2000:]
+        return json.loads(lines[0])
+
+    # strong scaling of north_star's config 4: 8192 buffered (k = 10) bins divided over the two ranks
+    strong = run("--config", "cfg4", "--steps", "4", "--min-seconds", "0", "--prefill", "30")
+    assert strong["scaling"] == "strong" and strong["n_gpus"] == 2 and strong["config"]["baseline_config"] == "cfg4"
+    assert strong["config"]["bins_per_gpu"] == 4096 and strong["config"]["global_bins"] == 8192 and strong["steps"] == 4
+    assert strong["ranks"]["ms_per_step_min"] <= strong["ranks"]["ms_per_step_max"] == strong["ms_per_step"]
+    assert abs(strong["value"] - 8192 * 4 / (strong["ms_per_step"] * 4e-3)) < 1e-3 * strong["value"]
+    # the timed region repeats in blocks until --min-seconds: `steps` reports what really ran
+    timed = run("--bins", "256", "--steps", "5", "--min-seconds", "0.2", "--prefill", "20")
+    assert timed["steps"] % 5 == 0 and timed["steps"] >= 10 and timed["steps_per_block"] == 5
+    assert timed["steps"] * timed["ms_per_step"] >= 200.0
+
+    out = run("--bins", "256", "--steps", "5", "--min-seconds", "0", "--prefill", "120")
     assert out["n_gpus"] == 2 and out["ranks"]["world_size"] == 2 and len(out["ranks"]["devices"]) == 2
-    assert out["config"]["global_bins"] == 512 and out["scaling"] == "weak"
+    assert out["config"]["global_bins"] == 512 and out["scaling"] == "weak" and out["steps"] == 5
     assert abs(out["value"] - 512 * 5 / (out["ms_per_step"] * 5e-3)) < 1e-3 * out["value"]
     # the reduced totals cover both shards: with 120 prefill steps most of the 512 bins finished an episode
     assert out["episodes"]["finished_since_reset"] > 256
