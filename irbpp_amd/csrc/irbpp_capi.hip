@@ -78,15 +78,16 @@ void layout_lds(Params& P) {
     P.mg_ax = div_magic(P.Ax);
     P.mg_ac = div_magic(P.AC);
     P.mg_mbw = div_magic(P.mb_w);
-    // heightmap tile: phase planes of period 2*step, one entry per 2 x 2 block of action cells (= per lane of the
-    // generic overlap test)
-    P.pp = 2 * P.step;
-    P.LX = (P.Ax + 1) / 2;
-    P.LY = (P.Ay + 1) / 2;
+    // heightmap tile: phase planes of period step, one entry per action cell (= per lane of the generic overlap test)
+    P.pp = P.step;
+    P.LX = P.Ax;
+    P.LY = P.Ay;
     P.PL = P.LX * P.LY;
-    P.tile_words = P.pp * P.pp * P.PL;
+    P.tile_words = P.pp * P.pp * P.PL;                                 // == Hc: no padding entries
     P.mg_pp = div_magic(P.pp);
     P.mg_ly = div_magic(P.LY);
+    P.g_ysh = 0;
+    while ((1 << P.g_ysh) < P.Ay) ++P.g_ysh;                           // Ay <= 16: at least four rows of action cells per wave
     P.nslot = 64;                                                     // candidate starts traced per pass (16 per wave)
     P.slot_cap = 64;                                                  // points of a border: one lane each in the segmented Douglas-Peucker
     P.slot_bytes = P.slot_cap + 4;                                    // 68 B = 17 dwords: odd stride, lanes hit distinct LDS banks
@@ -104,6 +105,8 @@ void layout_lds(Params& P) {
     if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
+    P.o_vbits = off;     off += align16(P.R * 16 * 4);
+    P.o_m1 = off;        off += P.box ? align16(P.Hx * P.Ay * 8) : 0; // box path: row maxima of the tile, [Hx][Ay]
     P.o_red = off;       off += 256;                                  // reductions, flags, queue copy
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour stage (border
     // slots, the arg-max words of the segmented Douglas-Peucker, and at its end the 256 candidate starts of
@@ -241,6 +244,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(order, N);
     ALLOC(err, 1);
     ALLOC(w_posz, N * P.R * P.AC);
+    ALLOC(w_valid, N * P.R * 16);
     ALLOC(w_vmask, N * P.R * 16);
     ALLOC(w_meta, N * WMETA);
     ALLOC(w_img, N * P.wimg * 16);
@@ -283,8 +287,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     const int R = P.R;
     std::vector<ShapeRot> sr((size_t)n_shapes * R);
     std::vector<Cell> bcell, tcell, blkcell;
-    std::vector<Pos4> pos_b;
-    std::vector<int32_t> pos_off;
+    std::vector<GCell> gcell;
     for (int64_t i = 0; i < (int64_t)n_shapes * R; ++i) {               // table shapes and offsets first: the scans below trust them
         const int64_t fx = dims[i * 2], fy = dims[i * 2 + 1];
         if (fx < 1 || fy < 1 || fx > 4096 || fy > 4096 || offsets[i] < 0 || offsets[i] + fx * fy > pool_len) return IRBPP_ERR_ARG;
@@ -313,6 +316,24 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             }
             if (ok) block_b = b;
         }
+    }
+    // Box path: every footprint of the dataset is a solid box -- maskB the rectangle [0,bx) x [0,by), one bottom height
+    // over it (the Cube dataset: bottom 0, the ceil-fuzz row of space.py:105 masked out).  max over the window of (H - c)
+    // is (max H) - c exactly, and the max over a rectangle is separable: row maxima first, then column maxima.
+    bool box = block_b == 0 && !(env->cfg.tuning & IRBPP_TUNE_NO_BOX_PATH);
+    for (int64_t i = 0; i < (int64_t)n_shapes * R && box; ++i) {
+        const int fx = dims[i * 2], fy = dims[i * 2 + 1];
+        const double* mb = mask_bottom + offsets[i];
+        const double* hb = height_bottom + offsets[i];
+        int bx = 0, by = 0;
+        while (bx < fx && mb[(int64_t)bx * fy] != 0.0) ++bx;
+        while (by < fy && mb[by] != 0.0) ++by;
+        if (bx == 0 || by == 0) { box = false; break; }
+        for (int ci = 0; ci < fx && box; ++ci)
+            for (int cj = 0; cj < fy && box; ++cj) {
+                const bool in = ci < bx && cj < by;
+                if ((mb[(int64_t)ci * fy + cj] != 0.0) != in || (in && hb[(int64_t)ci * fy + cj] != hb[0])) box = false;
+            }
     }
     const int mb_h = block_b ? (P.Hx - block_b) / P.step + 1 : 0, mb_w = block_b ? (P.Hy - block_b) / P.step + 1 : 0;
     for (int k = 0; k < n_shapes; ++k) {
@@ -371,51 +392,44 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                             blkcell.push_back(Cell{height_bottom[e0], (ti * block_b / P.step) * mb_w + tj * block_b / P.step, 0});
                     }
             s.nblk = (int32_t)blkcell.size() - s.oblk;
-            // generic path: the positions (u, v) relative to the corner of a 2 x 2 block of action cells at which
-            // at least one of the four cells has a masked-in footprint cell (u - a*step, v - b*step)
-            s.opos = (int32_t)pos_b.size();
-            if (!block_b)
-                for (int u = 0; u < s.fx + P.step; ++u)
-                    for (int v = 0; v < s.fy + P.step; ++v) {
-                        Pos4 q;
-                        bool any = false;
-                        for (int a = 0; a < 2; ++a)
-                            for (int bb = 0; bb < 2; ++bb) {
-                                const int ci = u - a * P.step, cj = v - bb * P.step;
-                                double val = INFINITY;
-                                if (ci >= 0 && ci < s.fx && cj >= 0 && cj < s.fy && mask_bottom[off + (int64_t)ci * s.fy + cj] != 0.0) {
-                                    val = height_bottom[off + (int64_t)ci * s.fy + cj];
-                                    any = true;
-                                }
-                                q.b[a * 2 + bb] = val;
-                            }
-                        if (!any) continue;
-                        pos_b.push_back(q);
-                        pos_off.push_back(((u % P.pp) * P.pp + (v % P.pp)) * P.PL + (u / P.pp) * P.LY + v / P.pp);
-                    }
-            s.npos = (int32_t)pos_b.size() - s.opos;
+            // generic path: the masked-in bottom cells again, as (height, byte offset in the LDS tile relative to the
+            // action cell's own entry): cell (ci, cj) of an item on action cell (X, Y) is heightmap cell
+            // (X*step + ci, Y*step + cj) = plane (ci % step, cj % step), entry (X + ci / step) * Ay + Y + cj / step
+            if (!block_b && !box)
+                for (int e = 0; e < s.nb; ++e) {
+                    const Cell& c = bcell[s.ob + e];
+                    const int ci = c.ij & 0xFFFF, cj = c.ij >> 16;
+                    const int off = ((ci % P.step) * P.step + cj % P.step) * P.AC + (ci / P.step) * P.Ay + cj / P.step;
+                    gcell.push_back(GCell{c.v, off * 8, 0});
+                }
+            if (box) {
+                while (s.bx < s.fx && mask_bottom[off + (int64_t)s.bx * s.fy] != 0.0) ++s.bx;
+                while (s.by < s.fy && mask_bottom[off + s.by] != 0.0) ++s.by;
+                s.bc = height_bottom[off];
+            }
             if (s.nb == 0 && !s.has_out) return IRBPP_ERR_ARG;
         }
     }
     if (bcell.empty()) bcell.push_back(Cell{0.0, 0, 0});
     if (tcell.empty()) tcell.push_back(Cell{0.0, 0, 0});
     if (blkcell.empty()) blkcell.push_back(Cell{0.0, 0, 0});
-    if (pos_b.empty()) { pos_b.push_back(Pos4{{0.0, 0.0, 0.0, 0.0}}); pos_off.push_back(0); }
+    // gcell mirrors bcell index for index; on the block / box paths nobody reads it
+    if (gcell.empty()) gcell.push_back(GCell{0.0, 0, 0});
     Tables& T = env->T;
     int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.bcell, (const Cell*)bcell.data(), bcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.tcell, (const Cell*)tcell.data(), tcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.blkcell, (const Cell*)blkcell.data(), blkcell.size());
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.pos_b, (const Pos4*)pos_b.data(), pos_b.size());
-    if (rc == IRBPP_OK) rc = dev_upload(env, &T.pos_off, (const int32_t*)pos_off.data(), pos_off.size());
+    if (rc == IRBPP_OK) rc = dev_upload(env, &T.gcell, (const GCell*)gcell.data(), gcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
     if (rc == IRBPP_OK) rc = dev_alloc(env, &env->S.item_cost, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
     T.n_shapes = n_shapes;
-    if (block_b) {                               // switch the overlap test to the block path
+    if (block_b || box) {                        // switch the overlap test to the block / box path
         env->P.block_b = block_b;
         env->P.mb_h = mb_h;
         env->P.mb_w = mb_w;
+        env->P.box = box ? 1 : 0;
         layout_lds(env->P);
         if (env->P.lds_bytes_full > 160 * 1024) return IRBPP_ERR_ARG;
         if (raise_lds_limits() != IRBPP_OK) return IRBPP_ERR_HIP;
@@ -497,7 +511,9 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
-        const int tgrid = n, pgrid = 2 * n;      // (half / a third of either grid with striding measured -4 ... -9 %)
+        // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
+        // beyond (half / a third of either grid with striding measured -4 ... -9 %)
+        const int tgrid = n * (64 / TRACE_CPW), pgrid = 2 * n;
         hipLaunchKernelGGL(irbpp_trace_kernel, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
         hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);

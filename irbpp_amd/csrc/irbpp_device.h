@@ -41,7 +41,8 @@ struct ShapeRot {
     int32_t has_out;       // 1 iff some maskB==0 cell exists: the window max then includes (H-B)*0 = 0
     int32_t pad;
     int32_t nblk, oblk;    // block list (Params.block_b > 0): uniform-bottom b x b tiles of the footprint
-    int32_t npos, opos;    // position list of the generic overlap test (Pos4 / pos_off)
+    int32_t bx, by;        // box path (Params.box): maskB is the solid rectangle [0,bx) x [0,by) with one bottom height bc
+    double bc;
     double ext_x, ext_y, ext_z;   // raw mesh.extents (prejudge, simulateHeight)
     double ext_z_r;               // round(extents,6)[2] (space.py:104,120)
     double com_x, com_y;          // centre of mass of the column solid between the two tables, in heightmap cells from the
@@ -57,19 +58,17 @@ struct Cell {              // 16 B
     int32_t pad;           // row-major index i*fy+j of the cell in its [fx][fy] table
 };
 
-// Generic overlap test, one entry per heightmap position (u, v) relative to the corner of a 2 x 2 block of action
-// cells: the four action cells (a, b) of the block see position (u, v) as their footprint cell (u - a*step,
-// v - b*step); b[a*2+b] is that cell's heightMapB, +inf where the cell is outside the table or masked out.  One
-// LDS read of the heightmap then serves up to four (action cell, footprint cell) pairs.  Read with scalar loads.
-struct alignas(32) Pos4 { double b[4]; };
+// Generic overlap test: the masked-in bottom cells of a footprint once more, in the order of the bottom list (entry e of
+// a (shape, rotation) is cell bcell[ob + e]), as what the inner loop consumes with ONE scalar load: the cell's heightMapB
+// and the BYTE offset of heightmap cell (i, j) relative to an action cell's own entry in the LDS tile.
+struct alignas(16) GCell { double b; int32_t off; int32_t pad; };
 
 struct Tables {
     const ShapeRot* sr;    // [n_shapes][R]
     const Cell* bcell;     // bottom cells (maskB == 1)
     const Cell* tcell;     // top cells    (maskH == 1)
     const Cell* blkcell;   // bottom tiles (block path): v = the tile's heightMapB, ij = offset into the block-max grid
-    const Pos4* pos_b;     // generic path: bottom heights of the four action cells at each listed position
-    const int32_t* pos_off; //              LDS tile offset of the position relative to the lane's own entry
+    const GCell* gcell;    // generic path: [same indexing as bcell] bottom height + LDS byte offset of every masked-in cell
     const double* volume;  // [n_shapes]
     const int32_t* seq;    // [n_traj][seq_len]
     int32_t n_shapes, n_traj, seq_len;
@@ -107,7 +106,8 @@ struct State {
     int32_t* order;        // [N] launch order of the bins: most expensive first
     int32_t* err;          // [1] device error word
     // split pipeline: per-bin hand-over between the transition, trace and emit kernels (L2 / Infinity Cache resident)
-    double* w_posz;        // [N][R*AC] posZValid of the observed item
+    double* w_posz;        // [N][R*AC] posZmap of the observed item, written only where naiveMask is set (w_valid says where)
+    uint32_t* w_valid;     // [N][R*16] naiveMask of the observed item as bit rows: bit Y of word r*16 + X
     uint32_t* w_vmask;     // [N][R*16] vertex bits: isolated pixels from the transition kernel, the rest from the trace kernel
     int32_t* w_meta;       // [N][WMETA]: level images handed over, candidates handed over, np.sum(naiveMask), observed item
     uint16_t* w_img;       // [N][wimg][16] level images: 16 row words (bit x of word y = pixel (x, y))
@@ -129,9 +129,12 @@ struct Params {
     int32_t traj_start, goff, gbins;
     int32_t obs_len0, obs_len1;
     // dynamic-LDS carve-up (byte offsets, all multiples of 16)
-    // heightmap tile in LDS ("phase planes" of period pp = 2*step, see irbpp_kernels.hip): LX x LY entries per plane
+    // heightmap tile in LDS ("phase planes" of period pp = step, see irbpp_kernels.hip): LX x LY = Ax x Ay entries per plane
     int32_t pp, LX, LY, PL, tile_words;
     uint32_t mg_pp, mg_ly;
+    int32_t g_ysh;            // generic overlap test: a wave's 64 lanes are (64 >> g_ysh) rows of (1 << g_ysh) >= Ay action cells
+    int32_t box, o_m1;        // box path (every footprint a solid box): LDS offset of the row-maxima grid [Hx][Ay]
+    int32_t o_vbits;          // naiveMask bit rows [R][16] of the observation being built
     int32_t o_sr;             // the R ShapeRots of the observed item
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red, o_dps;
     int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;   // lds_bytes: transition kernel (no posZValid region)

@@ -15,12 +15,12 @@
 // -ffp-contract=off), so results are bit-identical to the numpy code.  No MFMA: this is subtract/max/compare and
 // integer border following, not a contraction.
 //
-// LDS heightmap tile layout ("phase planes" of period pp = 2*step): heightmap cell (row, col) with
-// row = Lx*pp + u, col = Ly*pp + v (u, v < pp) lives at plane (u*pp + v), entry Lx*LY + Ly; a plane has
-// LX x LY = ceil(Ax/2) x ceil(Ay/2) <= 64 entries.  In the overlap test lane l = Lx*LY + Ly owns the 2 x 2 block of
-// action cells whose corner is heightmap cell (Lx*pp, Ly*pp): for a fixed position relative to that corner all lanes
-// of a wave read ONE plane at consecutive entries, so the per-lane ds_read_b64 is bank-conflict-free and the
-// position's tile offset is a wave-uniform scalar; and one value read serves the four action cells of the block.
+// LDS heightmap tile layout ("phase planes" of period pp = step): heightmap cell (row, col) with
+// row = X*step + u, col = Y*step + v (u, v < step) lives at plane (u*step + v), entry X*Ay + Y; a plane has one entry per
+// action cell.  In the generic overlap test a lane owns ONE action cell (X, Y): for a fixed footprint cell all lanes of
+// a wave read ONE plane at their own entries plus a wave-uniform offset -- the lanes of a half-wave are two (or more)
+// whole rows of the action grid, i.e. 32 distinct bank pairs: the per-lane ds_read_b64 is bank-conflict-free and the
+// footprint cell's tile offset is a scalar.
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
@@ -225,6 +225,7 @@ struct Lds {
     int* sr;                // the R ShapeRots of the observed item, as dwords
     double* hm;
     double* mb;             // block-max grid of the tile (block path of the overlap test)
+    double* m1;             // row maxima of the tile, [Hx][Ay] (box path of the overlap test)
     double* posz;
     uint8_t* lev;
     unsigned long long* present;
@@ -234,6 +235,7 @@ struct Lds {
     uint16_t* clist;        // [256] candidate starts of the image (sub-)batch: image | x0<<6 | y0<<10
     uint32_t* dps;          // [WAVES][64] arg-max words of the segmented Douglas-Peucker, one set per wave
     uint32_t* vmask;
+    uint32_t* vbits;        // [R][16] naiveMask as bit rows (bit Y of word r*16 + X)
     unsigned char* scratch;
     double* redd;
     int* redi;
@@ -244,6 +246,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.sr = (int*)(smem + P.o_sr);
     L.hm = (double*)(smem + P.o_hm);
     L.mb = (double*)(smem + P.o_mb);
+    L.m1 = (double*)(smem + P.o_m1);
     L.posz = (double*)(smem + P.o_posz);
     L.lev = smem + P.o_lev;
     L.present = (unsigned long long*)(smem + P.o_present);
@@ -253,6 +256,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.clist = (uint16_t*)(smem + P.o_clist);
     L.dps = (uint32_t*)(smem + P.o_dps);
     L.vmask = (uint32_t*)(smem + P.o_vmask);
+    L.vbits = (uint32_t*)(smem + P.o_vbits);
     L.scratch = smem + P.o_scratch;
     L.redd = (double*)(smem + P.o_red);
     L.redi = (int*)(L.redd + 8);
@@ -555,15 +559,17 @@ __device__ __forceinline__ uint32_t wave_or_to_lane63(uint32_t x) {
     return (uint32_t)v;
 }
 
-typedef const __attribute__((address_space(4))) double* ConstF64Ptr;
-typedef const __attribute__((address_space(4))) int32_t* ConstIntPtr;
+// a GCell as ONE 16-byte scalar load (the struct's fields would be fetched one s_load_dword(x2) each)
+typedef int32_t gcell_words __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) gcell_words* ConstGCellPtr;
+__device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloint2double(c.y, c.x); }
 
-// Space.get_possible_position (space.py:98-129) for `item` on the tile in LDS: fills L.posz
-// (posZValid), L.lev (height-level codes), L.present and returns np.sum(naiveMask).
-// posZValid goes to `zdst` ([R][AC]): global memory in the transition kernel (the emit kernel reads it from there; the
-// transition kernel's own LDS layout has no room for it, which is worth two more workgroups per CU), LDS elsewhere.
+// Space.get_possible_position (space.py:98-129) for `item` on the tile in LDS: posZmap where naiveMask is set goes to
+// `zdst` ([R][AC]; global memory in the transition kernel, where the emit kernel reads the rows it needs, LDS in the
+// heuristic kernel, which asks for `dense`: 1e3 everywhere else), naiveMask itself to L.vbits (bit rows), height-level
+// codes to L.lev, the levels present to L.present; returns np.sum(naiveMask).
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                   const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged) {
+                                   const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged, bool dense) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
@@ -571,7 +577,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
-    for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = 0u;
+    for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
+    for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
+    if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
     if (P.block_b > 0) {                         // block-max grid of the current tile
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
@@ -590,14 +598,51 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     }
     __syncthreads();
 
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int my_valid = 0;
-    if (P.block_b > 0) {
-    // ---- block path: one action cell per lane, all rotations; footprint = list of uniform b x b blocks ----------
+    if (P.block_b > 0 || P.box) {
+    // ---- one action cell per thread, all rotations: block path (footprint = list of uniform b x b blocks over the
+    // block-max grid) or box path (footprint = one solid box: separable rectangle maximum) ---------------------------
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     double zs[8];
     bool vs[8];
-    int level_code[8];
+    if (P.box) {
+        // max over the bx x by window of the heightmap, rows first: m1[i][Y] = max_j H[i][Y*step + j], j < by, then
+        // z[X][Y] = max_i m1[X*step + i][Y] - bc, i < bx: (bx + by) reads per cell where the pair loop has bx * by
+        double* const m1 = L.m1;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            zs[r] = 1e3;
+            vs[r] = false;
+            if (r >= R || item < 0) continue;
+            const ShapeRot* sp = (const ShapeRot*)srw + r;
+            const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
+            const int bx = __builtin_amdgcn_readfirstlane(sp->bx), by = __builtin_amdgcn_readfirstlane(sp->by);
+            const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
+            const double ext_z_r = sp->ext_z_r, bc = sp->bc;
+            for (int idx = tid; idx < P.Hx * Ay; idx += BLOCK) {
+                const int i = fdiv(idx, Ay, P.mg_ay), yy = idx - i * Ay;
+                if (yy <= Ay - s_ay) {
+                    const double* rowp = L.hm + tile_row_part(P, i);
+                    double m = -1e300;
+                    for (int j = 0; j < by; ++j) m = fmax(m, rowp[tile_col_part(P, yy * P.step + j)]);
+                    m1[idx] = m;
+                }
+            }
+            __syncthreads();
+            const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+            if (in_range) {
+                const double* colp = m1 + X * P.step * Ay + Y;
+                double m = -1e300;
+                for (int i = 0; i < bx; ++i) m = fmax(m, colp[i * Ay]);
+                m = m - bc;                                      // max(H - c) == max(H) - c: rounding is monotone
+                if (has_out) m = fmax(m, 0.0);                   // masked-out cells of the table: (H - B) * 0
+                zs[r] = m;
+                vs[r] = round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+            }
+            __syncthreads();                                     // the next rotation rewrites m1
+        }
+    } else {
     int ncell_next = 0, off_next = 0;
     Cell pre = {};                                           // first cell chunk of the next rotation, in flight
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
@@ -612,7 +657,6 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int r = 0; r < 8; ++r) {
         zs[r] = 1e3;
         vs[r] = false;
-        level_code[r] = 255;
         if (r >= R || item < 0) continue;
         const ShapeRot* sp = (const ShapeRot*)srw + r;
         const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
@@ -673,8 +717,12 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         }
     }
     }
+    }
+    int level_code[8];
+    const bool rows_align = (1 << P.g_ysh) == Ay;            // a wave's 64 consecutive cells are whole rows of the action grid
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
+        level_code[r] = 255;
         if (r >= R) continue;
         const double z = zs[r];
         const bool valid = vs[r];
@@ -684,9 +732,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 ka->io.posz_out[((size_t)b * R + r) * AC + tid] = z;
                 ka->io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
             }
-            zdst[r * AC + tid] = valid ? z : 1e3;
             int code = 255;
             if (valid) {
+                zdst[r * AC + tid] = z;
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
                 if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                     const int idx = li + 32;
@@ -694,9 +742,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                     else code = idx;
                 }
                 ++my_valid;
+                L.lev[r * AC + tid] = (uint8_t)code;
+                if (!rows_align) atomicOr(&L.vbits[r * 16 + X], 1u << Y);
             }
-            L.lev[r * AC + tid] = (uint8_t)code;
             level_code[r] = code;
+        }
+        if (rows_align) {                                    // naiveMask bit rows straight from the ballot
+            const unsigned long long bal = __ballot(valid && tid < AC);
+            if (Y == 0 && tid < AC) L.vbits[r * 16 + X] = (uint32_t)(bal >> (lane & ~(Ay - 1))) & ((1u << Ay) - 1u);
         }
     }
     // presence masks: one LDS atomic per distinct level per wave (64 lanes ORing into one word would
@@ -714,117 +767,125 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
     }
     } else {
-    // ---- generic path: wave w takes the rotations w, w + 4; lane l = Lx*LY + Ly owns the 2 x 2 block of action
-    // cells (2Lx + a, 2Ly + b).  The footprint is walked position by position (Pos4): one LDS read of the
-    // heightmap per position, four subtract/max pairs with the bottom heights as SCALAR operands (s_load from
-    // the wave-uniform list), no cross-lane traffic at all.  A position outside a lane's part of the heightmap
-    // reads some other float64 of the workgroup's LDS: it can only belong to action cells that are out of
-    // range for this rotation (discarded below), while the in-range cells of the lane see +inf there, i.e.
-    // -inf or NaN, which max() drops.
-    const int Lx = fdiv(lane, P.LY, P.mg_ly), Ly = lane - Lx * P.LY;
-    const double* hbase = L.hm + lane;
-    double zq[2][4];
-    bool vq[2][4];
-    // The position lists (a few KB per rotation, tens of MB per dataset: beyond L2, and what is in L2 is flushed by
-    // every step's observation stores) are consumed by scalar loads, of which a wave has only one chunk in flight.
-    // One vector load per 128-byte line, issued up front for this wave's FIRST rotation, brings that list into the
-    // XCD's L2 so that the scalar loads wait for L2 instead of HBM (cube, R = 2: +10 %).  Prefetching the second
-    // rotation too only doubled the lists' memory-side traffic (general -2.5 %, abc_fine -2 %).
-    int pref = 0;
-    if (item >= 0 && wave < R) {
-        const ShapeRot* sp = (const ShapeRot*)srw + wave;
-        const int npos = __builtin_amdgcn_readfirstlane(sp->npos), opos = __builtin_amdgcn_readfirstlane(sp->opos);
-        const char* pbv = (const char*)(T.pos_b + opos);
-        const char* pov = (const char*)(T.pos_off + opos);
-        for (int o = lane * 128; o < npos * 32; o += 64 * 128) pref |= *(const int*)(pbv + o);
-        for (int o = lane * 128; o < npos * 4; o += 64 * 128) pref |= *(const int*)(pov + o);
+    // ---- generic path: ONE action cell per lane, and only cells that can be in range.  A wave task is (rotation r,
+    // row group q): the wave's lanes are 64 >> ysh consecutive rows X of the action grid times 1 << ysh >= Ay
+    // columns Y, and only the rows X <= Ax - ax_r get a task at all.  The lane walks the rotation's masked-in bottom
+    // cells: per cell one scalar load (bottom height + byte offset in the tile, wave-uniform), one LDS read of the
+    // heightmap at lane base + offset, one subtract, one max -- the pairs (action cell, footprint cell) that
+    // np.max((H - B) * mask) ranges over, nothing else.  In the tile (phase planes of period step) lane (X, Y) sits
+    // at entry X*Ay + Y of every plane, so the 32 lanes of a half-wave read 32 consecutive-or-disjoint bank pairs:
+    // conflict-free ds_read_b64.  A lane outside the grid or outside the rotation's range reads some float64 of the
+    // workgroup's LDS (or nothing: beyond the allocation reads return 0) and is discarded.
+    const int ysh = P.g_ysh, rpw = 64 >> ysh;
+    const int rs = lane >> ysh, Y = lane & ((1 << ysh) - 1);
+    int first[9];                                            // tasks before rotation r
+    first[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int n = 0;
+        if (r < R && item >= 0) {
+            const ShapeRot* sp = (const ShapeRot*)srw + r;
+            const int wx = Ax - __builtin_amdgcn_readfirstlane(sp->ax) + 1, wy = Ay - __builtin_amdgcn_readfirstlane(sp->ay) + 1;
+            if (wx > 0 && wy > 0) n = (wx + rpw - 1) >> (6 - ysh);
+        }
+        first[r + 1] = first[r] + n;
     }
+    const int ntask = first[8];
+    int pref = 0;
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
+    for (int t = wave; t < ntask; t += WAVES) {
+        int r = 0;
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int r = wave + k * WAVES;
+        for (int q = 1; q < 8; ++q) r += t >= first[q] ? 1 : 0;
+        int tq = t;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) { zq[k][q] = 1e3; vq[k][q] = false; }
-        if (r >= R || item < 0) continue;
+        for (int q = 0; q < 8; ++q) if (q == r) tq = t - first[q];
+        const int X = tq * rpw + rs;
         const ShapeRot* sp = (const ShapeRot*)srw + r;
         const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
         const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
-        const int npos = __builtin_amdgcn_readfirstlane(sp->npos), opos = __builtin_amdgcn_readfirstlane(sp->opos);
+        const int nb = __builtin_amdgcn_readfirstlane(sp->nb), ob = __builtin_amdgcn_readfirstlane(sp->ob);
         const double ext_z_r = sp->ext_z_r;
-        const ConstF64Ptr pb = (ConstF64Ptr)(unsigned long long)(T.pos_b + opos);      // [npos][4]
-        const ConstIntPtr po = (ConstIntPtr)(unsigned long long)(T.pos_off + opos);
+        const ConstGCellPtr gc = (ConstGCellPtr)(unsigned long long)(T.gcell + ob);
+        // The lists (tens of MB per dataset: beyond L2, and what is in L2 is flushed by every step's observation
+        // stores) are consumed by scalar loads, of which a wave has only one chunk in flight: one vector load per
+        // 128-byte line, issued up front for the wave's FIRST task, brings that list into the XCD's L2 so that the
+        // scalar loads wait for L2 instead of HBM (the later tasks of a rotation find it there anyway).
+        if (t == wave) {
+            const char* lv = (const char*)(T.gcell + ob);
+            for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
+        }
+        const int xc = X < Ax ? X : Ax - 1, yc = Y < Ay ? Y : Ay - 1;
+        const char* hb = (const char*)(L.hm + xc * Ay + yc);
         const double init = has_out ? 0.0 : -1e300;
-        double a0 = init, a1 = init, a2 = init, a3 = init;
-        int p = 0;
-        for (; p + 4 <= npos; p += 4) {                      // four LDS reads in flight per trip
-            const int o0 = po[p], o1 = po[p + 1], o2 = po[p + 2], o3 = po[p + 3];
-            const double h0 = hbase[o0], h1 = hbase[o1], h2 = hbase[o2], h3 = hbase[o3];
-            const ConstF64Ptr q = pb + 4 * p;
-            a0 = fmax(a0, h0 - q[0]);  a1 = fmax(a1, h0 - q[1]);  a2 = fmax(a2, h0 - q[2]);  a3 = fmax(a3, h0 - q[3]);
-            a0 = fmax(a0, h1 - q[4]);  a1 = fmax(a1, h1 - q[5]);  a2 = fmax(a2, h1 - q[6]);  a3 = fmax(a3, h1 - q[7]);
-            a0 = fmax(a0, h2 - q[8]);  a1 = fmax(a1, h2 - q[9]);  a2 = fmax(a2, h2 - q[10]); a3 = fmax(a3, h2 - q[11]);
-            a0 = fmax(a0, h3 - q[12]); a1 = fmax(a1, h3 - q[13]); a2 = fmax(a2, h3 - q[14]); a3 = fmax(a3, h3 - q[15]);
+        double a0 = init, a1 = init;
+        int e = 0;
+        for (; e + 4 <= nb; e += 4) {                        // four LDS reads in flight per trip, two max chains
+            const gcell_words c0 = gc[e], c1 = gc[e + 1], c2 = gc[e + 2], c3 = gc[e + 3];
+            const double h0 = *(const double*)(hb + c0.z), h1 = *(const double*)(hb + c1.z);
+            const double h2 = *(const double*)(hb + c2.z), h3 = *(const double*)(hb + c3.z);
+            a0 = fmax(a0, h0 - gcell_b(c0));
+            a1 = fmax(a1, h1 - gcell_b(c1));
+            a0 = fmax(a0, h2 - gcell_b(c2));
+            a1 = fmax(a1, h3 - gcell_b(c3));
         }
-        for (; p < npos; ++p) {
-            const double h0 = hbase[po[p]];
-            const ConstF64Ptr q = pb + 4 * p;
-            a0 = fmax(a0, h0 - q[0]); a1 = fmax(a1, h0 - q[1]); a2 = fmax(a2, h0 - q[2]); a3 = fmax(a3, h0 - q[3]);
+        for (; e < nb; ++e) {
+            const gcell_words c0 = gc[e];
+            a0 = fmax(a0, *(const double*)(hb + c0.z) - gcell_b(c0));
         }
-        const double acc[4] = {a0, a1, a2, a3};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int X = 2 * Lx + (q >> 1), Y = 2 * Ly + (q & 1);
-            if (lane < P.PL && X <= Ax - s_ax && Y <= Ay - s_ay) {
-                zq[k][q] = acc[q];
-                vq[k][q] = round6_scaled(acc[q] + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+        const double z = fmax(a0, a1);
+        const bool in_range = X <= Ax - s_ax && Y <= Ay - s_ay;
+        const bool valid = in_range && round6_scaled(z + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+        const int cell = X * Ay + Y;
+        if (debug_out && in_range) {
+            const KernArgsPtr ka = cold_args();
+            ka->io.posz_out[((size_t)b * R + r) * AC + cell] = z;
+            ka->io.mask_out[((size_t)b * R + r) * AC + cell] = valid ? 1 : 0;
+        }
+        uint32_t bits_lo = 0u, bits_hi = 0u;                 // my level code as a bit
+        if (valid) {
+            zdst[r * AC + cell] = z;
+            const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
+            if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
+                const int idx = li + 32;
+                if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                else {
+                    L.lev[r * AC + cell] = (uint8_t)idx;
+                    if (idx < 32) bits_lo = 1u << idx; else bits_hi = 1u << (idx - 32);
+                }
             }
+            ++my_valid;
+        }
+        // naiveMask bit rows from the ballot: lane (row slot rs, Y == 0) stores its row's word
+        const unsigned long long bal = __ballot(valid);
+        if (Y == 0 && X < Ax) L.vbits[r * 16 + X] = (uint32_t)(bal >> (rs << ysh)) & ((1u << Ay) - 1u);
+        // presence mask of the rotation: OR over the wave on the DPP network, LDS atomics by its last lane (a rotation
+        // has several tasks)
+        bits_lo = wave_or_to_lane63(bits_lo);
+        bits_hi = wave_or_to_lane63(bits_hi);
+        if (lane == 63) {
+            uint32_t* pw = (uint32_t*)&L.present[r];
+            if (bits_lo) atomicOr(pw, bits_lo);
+            if (bits_hi) atomicOr(pw + 1, bits_hi);
         }
     }
     asm volatile("" :: "v"(pref));                           // the prefetch loads are complete by now; nothing uses their data
-#pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int r = wave + k * WAVES;
-        if (r >= R) continue;
-        uint32_t bits_lo = 0u, bits_hi = 0u;                 // level codes present among my four cells
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int X = 2 * Lx + (q >> 1), Y = 2 * Ly + (q & 1);
-            if (lane < P.PL && X < Ax && Y < Ay) {
-                const int cell = X * Ay + Y;
-                const double z = zq[k][q];
-                const bool valid = vq[k][q];
-                if (debug_out) {
-                    const KernArgsPtr ka = cold_args();
-                    ka->io.posz_out[((size_t)b * R + r) * AC + cell] = z;
-                    ka->io.mask_out[((size_t)b * R + r) * AC + cell] = valid ? 1 : 0;
-                }
-                zdst[r * AC + cell] = valid ? z : 1e3;
-                int code = 255;
-                if (valid) {
-                    const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
-                    if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
-                        const int idx = li + 32;
-                        if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
-                        else code = idx;
-                    }
-                    ++my_valid;
-                }
-                L.lev[r * AC + cell] = (uint8_t)code;
-                if (code < 32) bits_lo |= 1u << code;
-                else if (code < 64) bits_hi |= 1u << (code - 32);
+    if (debug_out)                                           // posZmap / naiveMask outside every rotation's range
+        for (int i = tid; i < R * AC; i += BLOCK) {
+            const int r = fdiv(i, AC, P.mg_ac), cell = i - r * AC, X = fdiv(cell, Ay, P.mg_ay), Y = cell - X * Ay;
+            const ShapeRot* sp = (const ShapeRot*)srw + r;
+            if (item < 0 || X > Ax - sp->ax || Y > Ay - sp->ay) {
+                const KernArgsPtr ka = cold_args();
+                ka->io.posz_out[((size_t)b * R + r) * AC + cell] = 1e3;
+                ka->io.mask_out[((size_t)b * R + r) * AC + cell] = 0;
             }
         }
-        // presence mask of the rotation: OR over the wave on the DPP network, one LDS store by its last lane
-        bits_lo = wave_or_to_lane63(bits_lo);
-        bits_hi = wave_or_to_lane63(bits_hi);
-        if (lane == 63) L.present[r] = ((unsigned long long)bits_hi << 32) | bits_lo;
-    }
     }
     return block_sum_int(my_valid, L.redi);                  // np.sum(naiveMask) for prejudge
 }
 
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
-                                        int nvalid, float* obs, const double* zsrc);
+                                        int nvalid, float* obs, const double* zsrc, const uint32_t* gvalid);
 __device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid);
 
 // ---------------------------------------------------------------------------------------
@@ -836,7 +897,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
-    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged);
+    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged, false);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
@@ -871,10 +932,16 @@ __device__ __forceinline__ unsigned long long sortable_f64(double v) {
 constexpr int SEL_PER_THREAD = (8 * 256 + BLOCK - 1) / BLOCK;           // R*AC <= 2048 elements
 
 template <typename KEY>
-__device__ inline void select_smallest(const Params& P, const Lds& L, const double* zsrc, int n, int want, const KEY& key,
-                                       uint32_t* out, uint32_t* sel, uint32_t* hist) {
+__device__ inline void select_smallest(const Params& P, const Lds& L, const double* zsrc, const uint32_t* vbits, int n, int want,
+                                       const KEY& key, uint32_t* out, uint32_t* sel, uint32_t* hist) {
     const int tid = threadIdx.x;
-    auto value = [&](uint32_t k) { return zsrc[(k >> 16) * P.AC + ((k >> 8) & 255u) * P.Ay + (k & 255u)]; };
+    // posZValid of element k: posZmap where naiveMask is set (only there has the transition kernel written it), 1e3
+    // elsewhere (space.py:123-125).  vbits == nullptr: every element is a candidate, i.e. a valid cell.
+    auto value = [&](uint32_t k) {
+        const uint32_t r = k >> 16, x = (k >> 8) & 255u, y = k & 255u;
+        if (vbits != nullptr && !((vbits[r * 16 + x] >> y) & 1u)) return 1e3;
+        return zsrc[r * P.AC + x * P.Ay + y];
+    };
     unsigned long long sk[SEL_PER_THREAD];
     uint32_t ky[SEL_PER_THREAD];
 #pragma unroll
@@ -970,11 +1037,12 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, const doub
 }
 
 // ---------------------------------------------------------------------------------------
-// Candidate rows, selection / padding and the float32 observation (binPhy.py:204-227) from L.vmask and
-// L.posz; also records the candidate keys for the next step's action_to_position.
+// Candidate rows, selection / padding and the float32 observation (binPhy.py:204-227) from L.vmask, the posZmap values
+// in `zsrc` (global memory, written where naiveMask is set) and naiveMask's bit rows `gvalid`; also records the
+// candidate keys for the next step's action_to_position.
 // ---------------------------------------------------------------------------------------
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
-                                        int nvalid, float* obs, const double* zsrc) {
+                                        int nvalid, float* obs, const double* zsrc, const uint32_t* gvalid) {
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
@@ -1002,7 +1070,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         rows = keys;
     } else if (n > P.S) {
         // np.argsort(candidates[:,3])[:S] (binPhy.py:209-212), ties by ascending index
-        select_smallest(P, L, zsrc, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist);
+        select_smallest(P, L, zsrc, nullptr, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist);
         nrows = P.S;
         rows = okey;
         __syncthreads();
@@ -1019,7 +1087,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
             for (int e = tid; e < want; e += BLOCK) okey[e] = cell_key(e);
             __syncthreads();
         } else {
-            select_smallest(P, L, zsrc, total_cells, want, cell_key, okey, keys, hist);
+            select_smallest(P, L, zsrc, gvalid, total_cells, want, cell_key, okey, keys, hist);
         }
         nrows = total_cells < P.S ? total_cells : P.S;
         rows = okey;
@@ -1032,8 +1100,8 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     float* rowval = (float*)hist;                   // [S]: the radix counters / sort keys are done with
     for (int i = tid; i < nrows; i += BLOCK) {
         const uint32_t k = rows[i];
-        const double z = zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];
-        rowval[i] = fallback ? (z < 1e3 ? 1.0f : 0.0f) : (float)z;
+        if (fallback) rowval[i] = (float)((gvalid[(k >> 16) * 16 + ((k >> 8) & 255u)] >> (k & 255u)) & 1u);
+        else rowval[i] = (float)zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];     // a candidate is a valid cell
     }
     __syncthreads();
     // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last
@@ -1165,7 +1233,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         __syncthreads();                             // the next batch rebuilds the images and the list
     }
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
-    for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
+    uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
+    for (int i = tid; i < P.R * 16; i += BLOCK) { gv[i] = L.vmask[i]; gb[i] = L.vbits[i]; }
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
         m[0] = ntasks;
@@ -1203,7 +1272,7 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
     __syncthreads();
     stamp(io, b, 3);
-    emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC);
+    emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1263,8 +1332,8 @@ constexpr int TRACE_CPW = IRBPP_TRACE_CPW;                            // candida
 extern "C" __global__ void __launch_bounds__(64)
 irbpp_trace_kernel(const Params P, const State S, long long* prof) {
     constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
-    __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];            // one border per lane
-    __shared__ __attribute__((aligned(16))) uint16_t simg[64 * TRACE_ISTRIDE];   // one level image per lane
+    __shared__ __attribute__((aligned(16))) uint8_t slots[TRACE_CPW * SLOT];            // one border per tracing lane
+    __shared__ __attribute__((aligned(16))) uint16_t simg[TRACE_CPW * TRACE_ISTRIDE];   // one level image per tracing lane
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
     const int lane = threadIdx.x;
@@ -1291,8 +1360,8 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
         const size_t g = (size_t)seg * seg_cap + gi;
         // ---- my candidate, its level image into LDS
         int my_n = 0, rk = 0, x0 = 0, y0 = 0;
-        uint16_t* const im = simg + lane * TRACE_ISTRIDE;
-        uint8_t* const my_slot = slots + lane * SLOT;
+        uint16_t* const im = simg + (lane < TRACE_CPW ? lane : 0) * TRACE_ISTRIDE;
+        uint8_t* const my_slot = slots + (lane < TRACE_CPW ? lane : 0) * SLOT;
         if (have) {
             const uint2 ce = S.w_cand[g];
             const uint32_t e = ce.y;
@@ -1871,7 +1940,7 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(S.bs[b].cur_item);
-    overlap_test(P, T, S, io, L, b, item, false, L.posz, false);
+    overlap_test(P, T, S, io, L, b, item, false, L.posz, false, true);
     __syncthreads();
     double best = 1e300;
     int best_i = 0x7fffffff;

@@ -26,7 +26,7 @@ def _check_infos(ginfo, cinfo, cdone, lo=0):
         assert gi["episode"]["r"] == ci["episode"]["r"] and gi["episode"]["l"] == ci["episode"]["l"]
 
 
-@pytest.mark.parametrize("workload,n,steps", [("blockout", 64, 150), ("general", 32, 50), ("blockout_k10", 32, 70)])
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 64, 150), ("general", 32, 50), ("blockout_k10", 32, 150)])
 def test_grouped_stepping_matches_c_oracle(workload, n, steps):
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
@@ -103,7 +103,9 @@ def test_grouped_stepping_matches_c_oracle(workload, n, steps):
     hm_g = grouped.env.get_heightmaps().cpu().numpy()
     hm_s = single.env.get_heightmaps().cpu().numpy()
     np.testing.assert_array_equal(hm_g, hm_s)
-    np.testing.assert_array_equal(grouped.env.episode_totals().cpu().numpy(), single.env.episode_totals().cpu().numpy())
+    tg, ts = grouped.env.episode_totals().cpu().numpy(), single.env.episode_totals().cpu().numpy()
+    assert tg[0] == ts[0] and tg[2] == ts[2]                 # episodes and items exactly; the float sums are added up in
+    np.testing.assert_allclose(tg, ts, rtol=1e-13, atol=0)   # another order (per group, then over the groups)
     grouped.env.check_device_error()
     single.env.check_device_error()
     grouped.close()
