@@ -378,6 +378,7 @@ def main():
                     help="weak: --bins per GPU; strong: the global bins (of --config, else --bins) divided over the GPUs")
     ap.add_argument("--groups", type=int, default=0,
                     help="independent groups of bins, each stepped on its own stream (0 = one group)")
+    ap.add_argument("--tuning", type=int, default=0, help="irbpp_config::tuning bit flags (A/B measurements; results never change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other configs, 8192 bins, grouped, VecEnv)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl is RCCL on ROCm "
@@ -419,6 +420,8 @@ def main():
 
     from irbpp_amd.vec_env import GroupedPackingEnv
     shapes, seqs, kw = make_workload(workload)
+    if a.tuning:
+        kw["tuning"] = a.tuning
     groups = a.groups if a.groups > 0 else 1               # `value`: ONE group = one launch per kernel over all bins
     env = GroupedPackingEnv(shapes, seqs, bins, groups, device=dev, **D.shard(rank, world, bins), **kw)
     hc = env.Hx * env.Hy

@@ -311,9 +311,9 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
  * irbpp_debug_kernel_times waits for the recorded launches and writes the durations of the latest
  * min(max_count, recorded) of them in ms to ms_host, oldest first; *count says how many; the ring
  * is then empty again. */
-/* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and which build
- * of it launches: 0 = irbpp_env_kernel (80 VGPRs, six workgroups per CU), 1 = irbpp_env_kernel_wide. */
-int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide);
+/* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and the name of the build of it that
+ * launches (one per overlap path, with and without the 64-VGPR cap; a static string).  Valid after irbpp_load_shapes. */
+int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name);
 int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);
 /* events around every `every`-th transition only (default 1): two event packets per step cost the stream ~5 % at
  * 0.15 ms per step, so bench.py samples every fourth step of its timed region */

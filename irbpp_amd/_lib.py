@@ -81,7 +81,7 @@ SIGNATURES = {
     "irbpp_masked_argmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "irbpp_debug_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "irbpp_debug_kernel_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_char_p)]),
     "irbpp_debug_kernel_timing": (C.c_int, [C.c_void_p, C.c_int32]),
     "irbpp_debug_kernel_timing_every": (C.c_int, [C.c_void_p, C.c_int32]),
     "irbpp_debug_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int32, C.POINTER(C.c_int32)]),

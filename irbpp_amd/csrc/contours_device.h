@@ -149,9 +149,19 @@ __device__ inline int trace_init(TraceState& t, const uint16_t* img, int x0, int
     return iso ? 1 : TRACE_RUNNING;
 }
 
+// The 3 x 3 neighbourhood seen in the TRANSPOSED image (rows = columns of the image) back in image orientation: a
+// neighbour at offset (dx, dy) there is the neighbour at (dy, dx) here, i.e. direction s becomes (6 - s) & 7
+// (E <-> S, NE <-> SW, N <-> W; NW and SE stay): bits 0..6 reversed, bit 7 kept.
+__device__ __forceinline__ uint32_t nb_untranspose(uint32_t m) { return (__brev(m & 0x7Fu) >> 25) | (m & 0x80u); }
+
 // One step of the walk.  Returns TRACE_RUNNING, or the final number of points: 0 if the walk met a pixel
 // that precedes (x0,y0) in raster order, i.e. (x0,y0) is not the first pixel of its component and the
 // border belongs to another start (or is a hole border).
+// A step costs ONE round of LDS reads: three 16-bit words around the pixel just entered -- rows (y-1, y, y+1) after a
+// horizontal or diagonal move, columns (x-1, x, x+1) of the transposed copy after a vertical one.  The same three
+// words serve the jump to the end of an axis-aligned run (the line walked and the line beside it) and the
+// neighbour mask of the pixel where the jump ends (in the transposed frame for a vertical move, mapped back with
+// nb_untranspose).
 __device__ inline int trace_step(TraceState& t, const uint16_t* img, const uint16_t* imgT, uint8_t* pts, int cap) {
     IRBPP_TRACE_ITER();
     // counter-clockwise search cur_s+1, cur_s+2, ... for the next border pixel
@@ -165,33 +175,35 @@ __device__ inline int trace_step(TraceState& t, const uint16_t* img, const uint1
     }
     t.prev_s = s2;
     if (x4 == t.x0 && y4 == t.y0 && t.x3 == t.x1 && t.y3 == t.y1) return t.n;
-    // now standing on (x4,y4), arrived by s2: jump to the end of an axis-aligned run.
-    // Branch-free on purpose: the lanes of a wave walk different borders in lockstep.
+    // now standing on (x4,y4), arrived by s2.  Branch-free on purpose: the lanes of a wave walk different borders in
+    // lockstep.
+    const bool vert = (s2 & 3) == 2;                              // N or S: work in the transposed image
+    const bool axis = (s2 & 1) == 0;                              // E, N, W, S: a straight run may follow
+    const bool fwd = s2 == 0 || s2 == 6;                          // E or S: towards higher bits
+    const uint16_t* base = vert ? imgT : img;
+    const int li = vert ? x4 : y4;                                // the line walked (row, or column of the image)
+    int p = vert ? y4 : x4;                                       // position along it
+    const uint32_t wm = base[li];
+    const uint32_t wa_raw = base[(li - 1) & 15], wb_raw = base[(li + 1) & 15];
+    const uint32_t wa = li > 0 ? wa_raw : 0u, wb = li < 15 ? wb_raw : 0u;
     {
-        const bool horiz = (s2 & 3) == 0;                         // E or W: walk a row, else a column
-        const bool fwd = s2 == 0 || s2 == 6;                      // E or S: towards higher bits
-        const uint16_t* base = horiz ? img : imgT;
-        const int li = horiz ? y4 : x4;
-        const int si = (horiz == fwd) ? li + 1 : li - 1;          // E: row below, W: row above, S: column left, N: column right
-        int p = horiz ? x4 : y4;
-        const uint32_t line = base[li];
-        const uint32_t side = base[si & 15];
-        const uint32_t side_ok = (unsigned)si < 16u ? side : 0u;
-        const int lf = run_forward(line, side_ok, p), lb = run_backward(line, side_ok, p);
-        const int L = (s2 & 1) ? 0 : (fwd ? lf : -lb);
-        p += L;
-        x4 = horiz ? p : x4;
-        y4 = horiz ? y4 : p;
+        // straight run: E looks at the row below, W at the row above, S at the column to the left, N at the column to
+        // the right (the three neighbours probed before the walking direction)
+        const uint32_t side = (vert != fwd) ? wb : wa;
+        const int lf = run_forward(wm, side, p), lb = run_backward(wm, side, p);
+        p += axis ? (fwd ? lf : -lb) : 0;
     }
+    x4 = vert ? x4 : p;
+    y4 = vert ? p : y4;
     // a run that ends on the start pixel, moving opposite to the first step, closes the border
     if (x4 == t.x0 && y4 == t.y0 && s2 == (t.s ^ 4)) return t.n;
     // run interiors lie between their end points in raster order, so testing end points suffices
     if (y4 * 16 + x4 < t.y0 * 16 + t.x0) return 0;
-    const uint32_t a = img[(y4 - 1) & 15], b = img[y4], c = img[(y4 + 1) & 15];
+    const uint32_t nb_local = nb_mask(wa, wm, wb, p);
     t.x3 = x4;
     t.y3 = y4;
     t.cur_s = (s2 + 4) & 7;
-    t.nb = nb_mask(y4 > 0 ? a : 0u, b, y4 < 15 ? c : 0u, x4);
+    t.nb = vert ? nb_untranspose(nb_local) : nb_local;
     return TRACE_RUNNING;
 }
 

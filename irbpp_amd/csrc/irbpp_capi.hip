@@ -105,7 +105,7 @@ void layout_lds(Params& P) {
     if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
-    P.o_vbits = off;     off += align16(P.R * 16 * 4);
+    P.o_vbits = P.o_taskidx;                           // naiveMask bit rows: handed over before the task index is built (split_handover)
     P.o_m1 = off;        off += P.box ? align16(P.Hx * P.Ay * 8) : 0; // box path: row maxima of the tile, [Hx][Ay]
     P.o_red = off;       off += 256;                                  // reductions, flags, queue copy
     // one region serves, in turn, the heightmap tile (apply + overlap test), the contour stage (border
@@ -146,7 +146,9 @@ void layout_lds(Params& P) {
 // The dynamic-LDS limit is an attribute of the kernel on the device, not of an environment: always raise it to the
 // CU's 160 KiB, so that a later, smaller environment cannot lower it under one that is still alive.
 int raise_lds_limits() {
-    const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_hull_kernel,
+    const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_env_kernel_box,
+                             (const void*)irbpp_env_kernel_box8, (const void*)irbpp_env_kernel_generic,
+                             (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_hull_kernel,
                              (const void*)irbpp_emit_kernel, (const void*)irbpp_heuristic_kernel};
     for (const void* k : kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return IRBPP_ERR_HIP;
@@ -476,14 +478,26 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
     return which == 0 ? env->P.obs_len0 : env->P.obs_len1;
 }
 
-// Two register budgets of the transition kernel.  The block path (lattice data) is short on work per bin and wants
-// residency: 64 VGPRs, eight workgroups per CU (4096 bins are exactly two rounds of the chip).  The generic and box
-// paths run on the unconstrained build, whose larger LDS layouts cap residency anyway.
-static bool use_wide_kernel(const irbpp_env* env) {
+// The transition kernel is compiled once per overlap path (lattice blocks, solid boxes, generic cell lists), with and
+// without the 64-VGPR cap that makes eight workgroups per CU resident, plus one build that decides at run time.
+typedef void (*env_kernel_fn)(const Params, const Tables, const State, const StepIO, const int);
+struct EnvKernel { env_kernel_fn fn; const char* name; };
+static EnvKernel pick_env_kernel(const irbpp_env* env) {
     const Params& P = env->P;
-    if (env->cfg.tuning & IRBPP_TUNE_WIDE_KERNEL) return true;      // A/B measurements (irbpp_config::tuning)
-    if (env->cfg.tuning & IRBPP_TUNE_NARROW_KERNEL) return false;
-    return P.block_b == 0 || 6 * P.lds_bytes > 150 * 1024;
+    const int t = env->cfg.tuning;
+    const bool lds_allows_8 = 8 * P.lds_bytes <= 160 * 1024;
+    if (P.block_b > 0) {
+        if ((t & IRBPP_TUNE_WIDE_KERNEL) || 6 * P.lds_bytes > 150 * 1024) return {irbpp_env_kernel_wide, "irbpp_env_kernel_wide"};
+        return {irbpp_env_kernel, "irbpp_env_kernel"};
+    }
+    if (P.box) {
+        if (t & IRBPP_TUNE_WIDE_KERNEL) return {irbpp_env_kernel_box, "irbpp_env_kernel_box"};
+        if ((t & IRBPP_TUNE_NARROW_KERNEL) || lds_allows_8) return {irbpp_env_kernel_box8, "irbpp_env_kernel_box8"};
+        return {irbpp_env_kernel_box, "irbpp_env_kernel_box"};
+    }
+    // generic path: seven waves per SIMD (72 VGPRs) beat eight under the 64-VGPR cap: general 12.9 vs 12.2 M steps/s
+    if (t & IRBPP_TUNE_NARROW_KERNEL) return {irbpp_env_kernel_generic8, "irbpp_env_kernel_generic8"};
+    return {irbpp_env_kernel_generic, "irbpp_env_kernel_generic"};
 }
 
 // One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the
@@ -504,11 +518,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
     // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
     const bool split = env->P.split && observes;
-    StepIO io_env = io;
-    if (!use_wide_kernel(env))
-        hipLaunchKernelGGL(irbpp_env_kernel, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
-    else
-        hipLaunchKernelGGL(irbpp_env_kernel_wide, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io_env, mode);
+    hipLaunchKernelGGL(pick_env_kernel(env).fn, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
@@ -794,10 +804,10 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     return IRBPP_OK;
 }
 
-int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, int32_t* wide) {
-    if (!env || !lds_bytes || !wide) return IRBPP_ERR_ARG;
+int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name) {
+    if (!env || !lds_bytes || !kernel_name) return IRBPP_ERR_ARG;
     *lds_bytes = env->P.lds_bytes;
-    *wide = use_wide_kernel(env) ? 1 : 0;
+    *kernel_name = pick_env_kernel(env).name;
     return IRBPP_OK;
 }
 

@@ -268,8 +268,13 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
 // invalid), `valid` given per thread/rotation through L.lev (255 = masked).  On return
 // L.vmask[r*16 + row] has bit col set for every candidate (row, col) of rotation r.
 // ---------------------------------------------------------------------------------------
-constexpr int CONTOUR_IMGS = CONTOUR_IPT * (BLOCK / 16);         // level images per batch
+constexpr int CONTOUR_IMGS = CONTOUR_IPT * (BLOCK / 16);         // level images per batch (contour stage of the hull kernel)
 constexpr int CONTOUR_CLIST = 256;                               // candidate starts listed at a time
+// The split hand-over builds its images in the bytes of the heightmap tile, which is done with by then: the block and
+// box paths (R <= 4 rotations, a few dozen level images) keep batches of 32, the generic path (R = 8, speckled
+// levels: ~100 images, hundreds of candidate starts) takes 128 images and 1024 listed candidates per batch --
+// one batch instead of four, each of which costs ten workgroup barriers.
+constexpr int HANDOVER_IPT_GENERIC = 8, HANDOVER_CLIST_GENERIC = 1024;
 
 // task list: one task (level image) per (rotation, present level), in (rotation, level) order
 __device__ inline int contour_tasks(const Params& P, const Lds& L) {
@@ -293,13 +298,13 @@ __device__ inline int contour_tasks(const Params& P, const Lds& L) {
 // level images of the batch starting at task `base`: 16-bit row words and, for the in-kernel trace of the hull
 // kernel only, the transposed copy (the trace kernel of the split pipeline transposes the images it follows itself:
 // 86 k traced images per step instead of 32 slots of every bin)
-__device__ inline void contour_images(const Params& P, const Lds& L, int base, bool with_cols) {
+template <int IPT>
+__device__ inline void contour_images(const Params& P, const Lds& L, uint16_t* const rows, int base, bool with_cols) {
     const int tid = threadIdx.x, R = P.R, AC = P.AC;
-    constexpr int IPT = CONTOUR_IPT, IMGS = CONTOUR_IMGS;
+    constexpr int IMGS = IPT * (BLOCK / 16);
     const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
-    uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
-    uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
+    uint16_t* const cols = rows + IMGS * 16;         // [IMGS][16] column words (bit y of word x), after the row words
     for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
     __syncthreads();
     // Image rows: thread tid holds action cell (X, Y), bit Y of row word X of the image its level belongs to.  One
@@ -326,47 +331,58 @@ __device__ inline void contour_images(const Params& P, const Lds& L, int base, b
     __syncthreads();
 }
 
-// candidate starts of the batch: one thread per (image, row), pure bit operations; isolated pixels are
-// marked as vertices on the spot.  Returns the number of candidates of the whole batch.
-__device__ inline int contour_candidates(const Params& P, const Lds& L, int base, int ntasks, uint32_t (&my_cand)[CONTOUR_IPT]) {
+// candidate starts of row y of batch image gg (pure bit operations on three row words) and, among them, the isolated
+// pixels: no foreground neighbour at all, i.e. a one-point border -- approxPolyDP returns the point and
+// find_convex_vetex keeps every vertex of a polygon with <= 3 of them (cvTools.py:42-43), so it is marked as a vertex
+// directly and never needs a trace lane
+__device__ __forceinline__ uint32_t row_candidates(const uint16_t* rows, int gg, int y, bool live, uint32_t& iso) {
+    const uint32_t row_bits = live ? (uint32_t)rows[gg * 16 + y] : 0u;
+    const uint32_t up_bits = (live && y > 0) ? (uint32_t)rows[gg * 16 + y - 1] : 0u;
+    const uint32_t down_bits = (live && y < 15) ? (uint32_t)rows[gg * 16 + y + 1] : 0u;
+    const uint32_t cand = start_candidates(row_bits, up_bits);
+    iso = cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
+    return cand & ~iso;
+}
+
+// first pass over the batch, one thread per (image, row): isolated pixels are marked as vertices on the spot; returns
+// the number of candidate starts of the whole batch.  (The candidates are recomputed by contour_list rather than kept:
+// IPT words per thread would be IPT more live registers through two barriers.)
+template <int IPT>
+__device__ inline int contour_candidates(const Params& P, const Lds& L, const uint16_t* const rows, int base, int ntasks) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, y = tid & 15;
-    const uint16_t* const rows = L.img;
     int my_count = 0;
-    for (int h = 0; h < CONTOUR_IPT; ++h) {
+#pragma unroll 1
+    for (int h = 0; h < IPT; ++h) {
         const int gg = g + h * (BLOCK / 16);
-        const bool live = base + gg < ntasks;
-        const uint32_t row_bits = live ? (uint32_t)rows[gg * 16 + y] : 0u;
-        const uint32_t up_bits = (live && y > 0) ? (uint32_t)rows[gg * 16 + y - 1] : 0u;
-        const uint32_t down_bits = (live && y < 15) ? (uint32_t)rows[gg * 16 + y + 1] : 0u;
-        uint32_t cand = start_candidates(row_bits, up_bits);
-        // An isolated pixel (no foreground neighbour at all) is a one-point border: approxPolyDP
-        // returns the point and find_convex_vetex keeps every vertex of a polygon with <= 3 of
-        // them (cvTools.py:42-43).  Mark it directly; it never needs a trace lane.
-        const uint32_t iso = cand & ~(row_bits >> 1) & ~down_bits & ~(down_bits << 1) & ~(down_bits >> 1);
+        uint32_t iso;
+        const uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
         if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
-        cand &= ~iso;
-        my_cand[h] = cand;
         my_count += __popc(cand);
     }
     return block_sum_int(my_count, L.redi);
 }
 
-// the candidates of the batch (nsub == 1) or of its image `sub` into L.clist; returns their number
-__device__ inline int contour_list(const Lds& L, const uint32_t (&my_cand)[CONTOUR_IPT], int nsub, int sub) {
+// the candidates of the batch (nsub == 1) or of its image `sub` into `clist` (image in batch | x0 << 7 | y0 << 11);
+// returns their number
+template <int IPT>
+__device__ inline int contour_list(const Lds& L, const uint16_t* const rows, uint16_t* const clist, int base, int ntasks,
+                                   int nsub, int sub) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, y = tid & 15;
     __syncthreads();
     if (tid == 0) L.redi[10] = 0;
     __syncthreads();
-    for (int h = 0; h < CONTOUR_IPT; ++h) {
+#pragma unroll 1
+    for (int h = 0; h < IPT; ++h) {
         const int gg = g + h * (BLOCK / 16);
         if (nsub == 1 || gg == sub) {
-            uint32_t cand = my_cand[h];
+            uint32_t iso;
+            uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
             while (cand) {
                 const int x = __ffs((int)cand) - 1;
                 cand &= cand - 1u;
-                L.clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(gg | (x << 6) | (y << 10));
+                clist[atomicAdd(&L.redi[10], 1)] = (uint16_t)(gg | (x << 7) | (y << 11));
             }
         }
     }
@@ -382,14 +398,13 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
         const long long t_img = prof ? (long long)clock64() : 0;
-        contour_images(P, L, base, true);
+        contour_images<CONTOUR_IPT>(P, L, L.img, base, true);
         // (a) candidate starts.  The list holds CLIST entries; a batch with more candidates (pathological
         // speckle) is walked one image at a time (an image has at most 64: every other pixel of every other row).
-        uint32_t my_cand[CONTOUR_IPT];
-        const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
+        const int batch_total = contour_candidates<CONTOUR_IPT>(P, L, L.img, base, ntasks);
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
-        const int total = contour_list(L, my_cand, nsub, sub);
+        const int total = contour_list<CONTOUR_IPT>(L, L.img, L.clist, base, ntasks, nsub, sub);
         if (prof && tid == 0) prof[5] += (long long)clock64() - t_img;       // images, transposes, candidate list
         // (b) 64 candidates per pass, spread over the four waves: candidate c is traced by lane c / 4 of wave
         // c % 4, and each wave then runs approxPolyDP + convexity on the borders it traced itself, one
@@ -407,11 +422,11 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
             int my_n = 0, my_r = 0;
             if (lane < PER_WAVE && c < count) {
                 const uint32_t e = L.clist[c0 + c];
-                const int gi = e & 63u;
+                const int gi = e & 127u;
                 my_r = L.tasklist[base + gi] >> 8;
                 int n = 0;
                 for (int rep = 0; rep < IRBPP_REPS(0); ++rep)
-                    n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u,
+                    n = trace_border(rows + gi * 16, cols + gi * 16, (e >> 7) & 15u, (e >> 11) & 15u,
                                      L.scratch + c * P.slot_bytes, P.slot_cap);
                 if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                 else if (n > P.slot_cap) atomicOr(&L.redi[8 + (c >> 5)], 1 << (c & 31));
@@ -462,9 +477,9 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
                         for (int cc = 0; cc < count; ++cc) {
                             if (!((redo >> cc) & 1ull)) continue;
                             const uint32_t e = L.clist[c0 + cc];
-                            const int gi = e & 63u;
+                            const int gi = e & 127u;
                             const int r = L.tasklist[base + gi] >> 8;
-                            if (contour_vertices(rows + gi * 16, cols + gi * 16, (e >> 6) & 15u, (e >> 10) & 15u, m,
+                            if (contour_vertices(rows + gi * 16, cols + gi * 16, (e >> 7) & 15u, (e >> 11) & 15u, m,
                                                  L.vmask + r * 16) != 0)
                                 atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);          // never silently drop a border
                         }
@@ -568,8 +583,14 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 // `zdst` ([R][AC]; global memory in the transition kernel, where the emit kernel reads the rows it needs, LDS in the
 // heuristic kernel, which asks for `dense`: 1e3 everywhere else), naiveMask itself to L.vbits (bit rows), height-level
 // codes to L.lev, the levels present to L.present; returns np.sum(naiveMask).
+// PATH: the overlap path compiled in -- one of the three, so that a transition kernel carries (and allocates registers
+// for) only the path its data set takes, or PATH_ANY: decided at run time from Params (heuristic kernel, fallback build).
+enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
+template <int PATH>
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                    const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged, bool dense) {
+    const bool use_block = PATH == PATH_BLOCK || (PATH == PATH_ANY && P.block_b > 0);
+    const bool use_box = PATH == PATH_BOX || (PATH == PATH_ANY && P.box != 0);
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
@@ -580,7 +601,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
-    if (P.block_b > 0) {                         // block-max grid of the current tile
+    if (use_block) {                             // block-max grid of the current tile
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
             double m = -1e300;
@@ -600,13 +621,13 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int my_valid = 0;
-    if (P.block_b > 0 || P.box) {
+    if (use_block || use_box) {
     // ---- one action cell per thread, all rotations: block path (footprint = list of uniform b x b blocks over the
     // block-max grid) or box path (footprint = one solid box: separable rectangle maximum) ---------------------------
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     double zs[8];
     bool vs[8];
-    if (P.box) {
+    if (use_box) {
         // max over the bx x by window of the heightmap, rows first: m1[i][Y] = max_j H[i][Y*step + j], j < by, then
         // z[X][Y] = max_i m1[X*step + i][Y] - bc, i < bx: (bx + by) reads per cell where the pair loop has bx * by
         double* const m1 = L.m1;
@@ -820,6 +841,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const double init = has_out ? 0.0 : -1e300;
         double a0 = init, a1 = init;
         int e = 0;
+        // (requesting the next four cells while the reads of the current four are in flight -- scalar loads and LDS
+        // reads share one counter -- was measured and lost: the compiler turns it into a reload at the loop head,
+        // general 12.7 -> 11.9 M steps/s)
         for (; e + 4 <= nb; e += 4) {                        // four LDS reads in flight per trip, two max chains
             const gcell_words c0 = gc[e], c1 = gc[e + 1], c2 = gc[e + 2], c3 = gc[e + 3];
             const double h0 = *(const double*)(hb + c0.z), h1 = *(const double*)(hb + c1.z);
@@ -886,18 +910,20 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
 
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
                                         int nvalid, float* obs, const double* zsrc, const uint32_t* gvalid);
+template <int IPT>
 __device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid);
 
 // ---------------------------------------------------------------------------------------
 // Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
 // ---------------------------------------------------------------------------------------
+template <int PATH>
 __device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                         const Lds& L, int b, int item, float* obs, bool debug_out, bool sr_staged) {
     item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
-    const int nvalid = overlap_test(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged, false);
+    const int nvalid = overlap_test<PATH>(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged, false);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
@@ -910,7 +936,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
     // the trace and emit kernels take it from here
-    split_handover(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
+    split_handover<PATH == PATH_GENERIC ? HANDOVER_IPT_GENERIC : CONTOUR_IPT>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
     if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
         io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
 }
@@ -956,11 +982,24 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, const doub
     for (int d = 7; d >= 0; --d) {
         hist[tid] = 0u;                                                  // BLOCK == 256 bins
         __syncthreads();
+        // posZ values of one bin share their high bytes, so in most rounds every lane of a wave counts into the SAME bin:
+        // plain LDS atomics would be serialised lane by lane (2048 of them on one address, ~8 k cycles per round,
+        // which made this path set the emit kernel's duration).  A wave whose lanes agree on the digit adds its count
+        // once; a few distinct digits per wave are conflicts the LDS takes in its stride.
 #pragma unroll
         for (int k = 0; k < SEL_PER_THREAD; ++k) {
+            if (k * BLOCK >= n) continue;                                    // block-uniform
             const int e = tid + k * BLOCK;
             const bool in = e < n && (d == 7 || (sk[k] >> (8 * (d + 1))) == prefix);
-            if (in) atomicAdd(&hist[(uint32_t)(sk[k] >> (8 * d)) & 255u], 1u);
+            const int digit = (int)((uint32_t)(sk[k] >> (8 * d)) & 255u);
+            const unsigned long long act = __ballot(in);
+            if (act == 0ull) continue;
+            const int c0 = __builtin_amdgcn_readlane(digit, __ffsll((long long)act) - 1);
+            if (__ballot(in && digit != c0) == 0ull) {
+                if ((tid & 63) == __ffsll((long long)act) - 1) atomicAdd(&hist[c0], (uint32_t)__popcll(act));
+            } else if (in) {
+                atomicAdd(&hist[digit], 1u);
+            }
         }
         __syncthreads();
         if (tid < 64) {                                                   // one wave scans the 256 counts
@@ -1177,21 +1216,31 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
 // most R*64 images and R*AC candidates; an XCD's candidate list holds twice the worst case of its share of the bins
 // (IRBPP_DEVERR_CAPACITY if the dispatcher ever gave one die more than twice its share of such bins).
 // ---------------------------------------------------------------------------------------
+template <int IPT>
 __device__ inline void split_handover(const Params& P, const State& S, const Lds& L, int b, int slot, int item, int nvalid) {
     const int tid = threadIdx.x;
     const KernArgsPtr ka = cold_args();
+    constexpr int IMGS = IPT * (BLOCK / 16);
+    // the batch's row words and the candidate list live in the bytes of the heightmap tile (its float32 copy is out)
+    constexpr int CLIST = IPT == CONTOUR_IPT ? CONTOUR_CLIST : HANDOVER_CLIST_GENERIC;
+    uint16_t* const rows = (uint16_t*)L.scratch;
+    uint16_t* const clist = IPT == CONTOUR_IPT ? L.clist : rows + IMGS * 16;
+    {   // naiveMask's bit rows first: they share their LDS bytes with the task index built next
+        uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
+        for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
+        __syncthreads();
+    }
     const int ntasks = contour_tasks(P, L);
     int ncand = 0;
     uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 16);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
     const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
-    for (int base = 0; base < ntasks; base += CONTOUR_IMGS) {                // one batch of level images at a time
-        contour_images(P, L, base, false);
-        uint32_t my_cand[CONTOUR_IPT];
-        const int batch_total = contour_candidates(P, L, base, ntasks, my_cand);
-        const int nb = ntasks - base < CONTOUR_IMGS ? ntasks - base : CONTOUR_IMGS;
+    for (int base = 0; base < ntasks; base += IMGS) {                        // one batch of level images at a time
+        contour_images<IPT>(P, L, rows, base, false);
+        const int batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks);
+        const int nb = ntasks - base < IMGS ? ntasks - base : IMGS;
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
-        const uint32_t* lr = (const uint32_t*)L.img;
+        const uint32_t* lr = (const uint32_t*)rows;
         for (int i = tid; i < nb * 8; i += BLOCK) gi[(size_t)base * 8 + i] = lr[i];
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
         // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
@@ -1199,9 +1248,9 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
         // between the eight L2s with every allocation (measured: +22 us per launch).  The LDS list holds CLIST
         // entries; a batch with more candidates (speckle) goes image by image (an image has at most 64).
-        const int nsub = batch_total <= CONTOUR_CLIST ? 1 : CONTOUR_IMGS;
+        const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
-            const int total = contour_list(L, my_cand, nsub, sub);
+            const int total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub);
             if (tid == 0) {
                 // This die's list; should it be full (the dispatcher gave this die far more than its share of speckled
                 // bins, or the device runs in a partition mode where XCC_ID does not spread the workgroups over eight
@@ -1224,8 +1273,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
             if (L.redi[11] >= 0) {
                 uint2* flat = ka->S.w_cand + (size_t)L.redi[12] * P.seg_cap + L.redi[11];
                 for (int i = tid; i < total; i += BLOCK) {
-                    const uint32_t e = L.clist[i];
-                    flat[i] = make_uint2((uint32_t)b, ((uint32_t)(base + (e & 63u)) << 8) | (((e >> 10) & 15u) << 4) | ((e >> 6) & 15u));
+                    const uint32_t e = clist[i];
+                    flat[i] = make_uint2((uint32_t)b, ((uint32_t)(base + (e & 127u)) << 8) | (((e >> 11) & 15u) << 4) | ((e >> 7) & 15u));
                 }
             }
             ncand += total;
@@ -1233,8 +1282,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         __syncthreads();                             // the next batch rebuilds the images and the list
     }
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
-    uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
-    for (int i = tid; i < P.R * 16; i += BLOCK) { gv[i] = L.vmask[i]; gb[i] = L.vbits[i]; }
+    for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
         m[0] = ntasks;
@@ -1247,7 +1295,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // ---------------------------------------------------------------------------------------
 // Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(BLOCK)
+extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
 irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
@@ -1571,29 +1619,34 @@ irbpp_polygon_kernel(const Params P, const State S) {
 // ---------------------------------------------------------------------------------------
 // The environment transition kernel: one workgroup per bin.
 // ---------------------------------------------------------------------------------------
-// Two builds of one body.  irbpp_env_kernel is held to 64 VGPRs (eight waves per SIMD, eight workgroups per CU:
-// 4096 bins are exactly two rounds of the chip): the block path of lattice data, whose per-bin work is short and
-// latency-bound (measured 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups per CU).  irbpp_env_kernel_wide lets
-// the register allocator have what it wants: the generic path, whose inner loop keeps eight float64 accumulators
-// and a chunk of scalar operands live (see use_wide_kernel in irbpp_capi.hip).
+// One body, one build per overlap path.  irbpp_env_kernel (block path of lattice data, whose per-bin work is short and
+// latency-bound) and the *8 builds are held to 64 VGPRs: eight waves per SIMD, eight workgroups per CU, i.e. 4096 bins
+// are exactly two rounds of the chip (measured on the block path: 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups
+// per CU).  irbpp_env_kernel_wide decides the path at run time and lets the register allocator have what it wants: the
+// fallback that irbpp_config::tuning can force for A/B measurements (see pick_env_kernel in irbpp_capi.hip).
+template <int PATH>
 __device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
 #ifndef IRBPP_ENV_WAVES
 #define IRBPP_ENV_WAVES 8
 #endif
-extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(IRBPP_ENV_WAVES, IRBPP_ENV_WAVES)))
-irbpp_env_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    env_transition(P, T, S, io, mode, smem);
-}
+#define IRBPP_ENV_KERNEL(NAME, PATH, ATTR)                                                                              \
+    extern "C" __global__ void __launch_bounds__(BLOCK) ATTR                                                           \
+    NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                             \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                           \
+        env_transition<PATH>(P, T, S, io, mode, smem);                                                                 \
+    }
+// (eight waves per SIMD need <= 64 VGPRs AND <= 96 SGPRs of the SIMD's 800: the cap is on both)
+#define IRBPP_CAPPED __attribute__((amdgpu_waves_per_eu(IRBPP_ENV_WAVES, IRBPP_ENV_WAVES)))
+IRBPP_ENV_KERNEL(irbpp_env_kernel, PATH_BLOCK, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_box8, PATH_BOX, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_box, PATH_BOX, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, __attribute__((amdgpu_waves_per_eu(7, 7))))    // measured: 7 beats 8 (general 12.9 vs 12.2 M)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, )
 
-extern "C" __global__ void __launch_bounds__(BLOCK)
-irbpp_env_kernel_wide(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    env_transition(P, T, S, io, mode, smem);
-}
-
+template <int PATH>
 __device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem) {
     const Lds L = carve_lds(smem, P);
@@ -1862,7 +1915,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
         }
     }
-    if (do_observe) observe_location(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
+    if (do_observe) observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
     if (tid == 0 && mode != MODE_POSSIBLE) {
         // Scheduling hint for the next launch.  A bin's cycle count is nearly uncorrelated with its
         // own previous step (r = -0.1 on the blockout workload) but a third of its variance is
@@ -1940,7 +1993,7 @@ irbpp_heuristic_kernel(const Params P, const Tables T, const State S, const Step
     for (int i = tid; i < P.Hc; i += BLOCK) L.hm[tile_of_linear(P, i)] = ghm[i];
     __syncthreads();
     const int item = __builtin_amdgcn_readfirstlane(S.bs[b].cur_item);
-    overlap_test(P, T, S, io, L, b, item, false, L.posz, false, true);
+    overlap_test<PATH_ANY>(P, T, S, io, L, b, item, false, L.posz, false, true);
     __syncthreads();
     double best = 1e300;
     int best_i = 0x7fffffff;

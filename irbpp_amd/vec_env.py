@@ -262,10 +262,9 @@ class GpuPackingEnv(object):
 
     def kernel_info(self):
         """Tooling: (LDS bytes per workgroup, name of the transition-kernel build that launches)."""
-        lds, wide = C.c_int32(0), C.c_int32(0)
-        _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(wide)), "irbpp_debug_kernel_info")
-        name = "irbpp_env_kernel_wide" if wide.value else "irbpp_env_kernel"
-        return lds.value, name + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
+        lds, name = C.c_int32(0), C.c_char_p()
+        _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(name)), "irbpp_debug_kernel_info")
+        return lds.value, name.value.decode() + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
 
     def enable_kernel_timing(self, capacity: int, every: int = 1) -> None:
         """Tooling: bracket the kernels of the next transitions with HIP events on their stream, ``capacity`` pairs

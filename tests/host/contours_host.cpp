@@ -10,6 +10,7 @@
 #define __forceinline__ inline
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline unsigned atomicOr(uint32_t* p, uint32_t v) { const unsigned o = *p; *p |= v; return o; }
 // cross-lane builtins appear only in the cooperative routine, which is compiled but never called here
 struct { unsigned x; } threadIdx = {0};

@@ -14,6 +14,7 @@
 #define __forceinline__ inline
 static inline int __ffs(int v) { return __builtin_ffs(v); }
 static inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+static inline unsigned __brev(unsigned v) { unsigned r = 0; for (int i = 0; i < 32; ++i) r |= ((v >> i) & 1u) << (31 - i); return r; }
 static inline unsigned atomicOr(uint32_t* p, uint32_t v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 
 static thread_local struct { unsigned x; } threadIdx;
