@@ -270,11 +270,9 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
 // ---------------------------------------------------------------------------------------
 constexpr int CONTOUR_IMGS = CONTOUR_IPT * (BLOCK / 16);         // level images per batch (contour stage of the hull kernel)
 constexpr int CONTOUR_CLIST = 256;                               // candidate starts listed at a time
-// The split hand-over builds its images in the bytes of the heightmap tile, which is done with by then: the block and
-// box paths (R <= 4 rotations, a few dozen level images) keep batches of 32, the generic path (R = 8, speckled
-// levels: ~100 images, hundreds of candidate starts) takes 128 images and 1024 listed candidates per batch --
-// one batch instead of four, each of which costs ten workgroup barriers.
-constexpr int HANDOVER_IPT_GENERIC = 8, HANDOVER_CLIST_GENERIC = 1024;
+// (A hand-over batch of 128 images and 1024 listed candidates for the generic path, R = 8 with ~100 speckled level
+// images per bin -- one batch instead of four -- was measured and lost: the wider per-thread loops cost the kernel its
+// register allocation, general 12.8 -> 11.1 M steps/s.)
 
 // task list: one task (level image) per (rotation, present level), in (rotation, level) order
 __device__ inline int contour_tasks(const Params& P, const Lds& L) {
@@ -664,6 +662,8 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             __syncthreads();                                     // the next rotation rewrites m1
         }
     } else {
+    // (One coalesced load of all R rotations' block lists -- they are contiguous and total a few dozen entries -- ahead of
+    // the block-max grid, instead of this chain of prefetches, was measured: 28.25 vs 28.42 M steps/s, not taken.)
     int ncell_next = 0, off_next = 0;
     Cell pre = {};                                           // first cell chunk of the next rotation, in flight
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
@@ -936,7 +936,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
     // the trace and emit kernels take it from here
-    split_handover<PATH == PATH_GENERIC ? HANDOVER_IPT_GENERIC : CONTOUR_IPT>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
+    split_handover<CONTOUR_IPT>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
     if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
         io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
 }
@@ -1222,9 +1222,9 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     const KernArgsPtr ka = cold_args();
     constexpr int IMGS = IPT * (BLOCK / 16);
     // the batch's row words and the candidate list live in the bytes of the heightmap tile (its float32 copy is out)
-    constexpr int CLIST = IPT == CONTOUR_IPT ? CONTOUR_CLIST : HANDOVER_CLIST_GENERIC;
+    constexpr int CLIST = CONTOUR_CLIST;
     uint16_t* const rows = (uint16_t*)L.scratch;
-    uint16_t* const clist = IPT == CONTOUR_IPT ? L.clist : rows + IMGS * 16;
+    uint16_t* const clist = L.clist;
     {   // naiveMask's bit rows first: they share their LDS bytes with the task index built next
         uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
         for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
@@ -1643,7 +1643,9 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel, PATH_BLOCK, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_box8, PATH_BOX, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_box, PATH_BOX, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, IRBPP_CAPPED)
-IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, __attribute__((amdgpu_waves_per_eu(7, 7))))    // measured: 7 beats 8 (general 12.9 vs 12.2 M)
+// (pinning the generic build to seven waves per SIMD with amdgpu_waves_per_eu(7, 7) -- it asks for 71 VGPRs of its own
+// accord -- changes the compiler's scheduling for the worse: general 12.8 -> 11.7, abc_fine 5.2 -> 3.8 M steps/s)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, )
 
 template <int PATH>
