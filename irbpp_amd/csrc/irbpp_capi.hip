@@ -242,7 +242,6 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(cand, N * P.S);
     ALLOC(bs, N);
     ALLOC(totals, N * 4);
-    ALLOC(cost, N);
     ALLOC(order, N);
     ALLOC(err, 1);
     ALLOC(w_posz, N * P.R * P.AC);
@@ -424,7 +423,6 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.blkcell, (const Cell*)blkcell.data(), blkcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.gcell, (const GCell*)gcell.data(), gcell.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.volume, volumes, (size_t)n_shapes);
-    if (rc == IRBPP_OK) rc = dev_alloc(env, &env->S.item_cost, (size_t)n_shapes);
     if (rc != IRBPP_OK) return rc;
     T.n_shapes = n_shapes;
     if (block_b || box) {                        // switch the overlap test to the block / box path
@@ -436,6 +434,10 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         if (env->P.lds_bytes_full > 160 * 1024) return IRBPP_ERR_ARG;
         if (raise_lds_limits() != IRBPP_OK) return IRBPP_ERR_HIP;
     }
+    // generic path on a data set whose footprint lists do not fit a die's L2: online steps launch the bins grouped by
+    // observed item per die (irbpp_item_order_kernel)
+    env->item_order = !block_b && !box && gcell.size() * sizeof(GCell) > (size_t)8 << 20 && env->P.N % NXCD == 0 &&
+                      env->P.N >= 64 * NXCD && env->P.K == 1 && !(env->cfg.tuning & IRBPP_TUNE_NO_ITEM_ORDER);
     env->shapes_loaded = true;
     return IRBPP_OK;
 }
@@ -506,6 +508,10 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     io.block_off = first;
     io.auto_action = env->auto_actions;
     io.use_order = 0;
+    if (mode == MODE_STEP && env->item_order && first == 0 && n == env->P.N) {
+        hipLaunchKernelGGL(irbpp_item_order_kernel, dim3(1), dim3(1024), 0, st, env->T, env->S, n);
+        io.use_order = 1;
+    }
     io.obs_rows = nullptr;
     const bool observes = mode == MODE_CANDS || ((mode == MODE_RESET || mode == MODE_STEP) && env->P.K == 1);
     for (auto& rb : env->obs_buffers)

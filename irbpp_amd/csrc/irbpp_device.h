@@ -101,9 +101,7 @@ struct State {
     uint32_t* log_meta;    // optional [N][log_cap]: item | rot<<16 | lx<<20 | ly<<24 of the episode's placements
     double* log_z;         // optional [N][log_cap]: drop height of each placement
     int32_t log_cap;
-    int32_t* cost;         // [N] predicted shader cycles of the bin's next transition (scheduling hint)
-    int32_t* item_cost;    // [n_shapes] running mean of the cycles a transition observing that item took
-    int32_t* order;        // [N] launch order of the bins: most expensive first
+    int32_t* order;        // [N] launch order of the bins (irbpp_item_order_kernel); identity until it has run
     int32_t* err;          // [1] device error word
     // split pipeline: per-bin hand-over between the transition, trace and emit kernels (L2 / Infinity Cache resident)
     double* w_posz;        // [N][R*AC] posZmap of the observed item, written only where naiveMask is set (w_valid says where)
@@ -191,7 +189,7 @@ struct StepIO {
     int32_t* auto_action;       // optional [N]: the scripted MINZ policy's choice for the observation just emitted (row with the
                                 // lowest H among V == 1, first on ties; 0 if none) -- irbpp_set_auto_policy
     int32_t* err_out;           // optional [1]: copy of the device error word, written by the emit kernel (split pipeline)
-    int32_t use_order;          // 1: launch slot -> bin through State::order (most-expensive-first launches); 0: identity
+    int32_t use_order;          // 1: launch slot -> bin through State::order (bins grouped by observed item per die); 0: identity
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
 };
 

@@ -1652,9 +1652,8 @@ template <int PATH>
 __device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem) {
     const Lds L = carve_lds(smem, P);
-    // Bins are launched most-expensive-first (S.order, refreshed by irbpp_order_kernel from the
-    // cycle counts of the previous transition): with ~2.7 bins per resident workgroup slot the
-    // stragglers would otherwise decide the kernel's duration.
+    // Launch slot -> bin: identity, the caller's list (reset_specific), or -- online steps on large generic data sets --
+    // S.order, which irbpp_item_order_kernel groups by observed item per die.
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;          // reset_specific
     const int slot = (int)blockIdx.x + io.block_off;
     const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
@@ -1918,68 +1917,53 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         }
     }
     if (do_observe) observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
-    if (tid == 0 && mode != MODE_POSSIBLE) {
-        // Scheduling hint for the next launch.  A bin's cycle count is nearly uncorrelated with its
-        // own previous step (r = -0.1 on the blockout workload) but a third of its variance is
-        // explained by WHICH item gets observed, and the pre-drawn trajectory tells that one
-        // step ahead: keep a running mean per item and predict with it.
-        const long long dt = (long long)clock64() - t_begin;
-        const int c = dt > 0x7fffffffLL ? 0x7fffffff : (int)dt;
-        int hint = c;
-        const KernArgsPtr ka = cold_args();
-        if (P.K == 1 && (mode == MODE_STEP || mode == MODE_RESET)) {
-            int32_t* item_cost = ka->S.item_cost;
-            if (do_observe && obs_item >= 0) {
-                const int old = item_cost[obs_item];                 // racy read-modify-write: a hint only
-                item_cost[obs_item] = old ? old + ((c - old) >> 3) : c;
-            }
-            const int nxt = fetch_item(T, S, S.bs[b].traj_row, S.bs[b].cursor);
-            const int m = nxt >= 0 ? item_cost[nxt] : 0;
-            if (m) hint = m;
-        }
-        ka->S.cost[b] = hint;
-    }
 }
 
-// Counting sort of the bins by descending cost (256 buckets between the smallest and the largest
-// hint) -> S.order.  One workgroup; runs before every transition launch (a few microseconds).
+// Launch order of an online step on the generic path: bins that are about to observe the SAME item run on the same
+// die, one after the other.  The item a bin observes next is known before the step (the next entry of its trajectory;
+// wrong only where the step ends the episode, which costs nothing but the hint), the footprint lists of an item are
+// what the overlap test reads with scalar loads, and a data set's lists (tens of MB at fine resolutions) do not fit a
+// die's 4 MB L2: grouped like this a list is fetched from memory once per die and step instead of once per bin.
+// Counting sort by item (1024 buckets, monotone in the id), then sorted position s goes to launch slot
+// 8 * (s mod N/8) + s div (N/8): workgroup p runs on die p mod 8, so die x gets the contiguous sorted range x.
+// One workgroup; a few microseconds.
 extern "C" __global__ void __launch_bounds__(1024)
-irbpp_order_kernel(const int32_t* cost_all, int32_t* order_all, int base, int N) {
-    const int32_t* cost = cost_all + base;           // grouped stepping: bins base .. base + N - 1 are one launch group
-    int32_t* order = order_all + base;
-    __shared__ int hist[256];
-    __shared__ int start[256];
-    __shared__ int lo_hi[2];
+irbpp_item_order_kernel(const Tables T, const State S, int N) {
+    __shared__ int hist[1024];
+    __shared__ int start[1024];
     const int tid = threadIdx.x;
-    if (tid < 256) hist[tid] = 0;
-    if (tid == 0) { lo_hi[0] = 0x7fffffff; lo_hi[1] = 0; }
+    hist[tid] = 0;
     __syncthreads();
-    int lo = 0x7fffffff, hi = 0;
-    for (int b = tid; b < N; b += 1024) { const int c = cost[b]; lo = c < lo ? c : lo; hi = c > hi ? c : hi; }
-    for (int o = 32; o > 0; o >>= 1) {
-        const int l2 = __shfl_xor(lo, o), h2 = __shfl_xor(hi, o);
-        lo = l2 < lo ? l2 : lo; hi = h2 > hi ? h2 : hi;
-    }
-    if ((tid & 63) == 0) { atomicMin(&lo_hi[0], lo); atomicMax(&lo_hi[1], hi); }
-    __syncthreads();
-    lo = lo_hi[0];
-    const float scale = 255.0f / ((float)lo_hi[1] - (float)lo + 1.0f);       // in float: hi - lo + 1 may not fit an int
-    auto bucket = [&](int c) {                       // bucket 0 = most expensive
-        const int k = 255 - (int)(((float)c - (float)lo) * scale);
-        return k < 0 ? 0 : (k > 255 ? 255 : k);
+    auto bucket_of = [&](int b) {
+        const BinState* ps = S.bs + b;
+        int c = ps->cursor;
+        if (T.stream) c = (int)((uint32_t)c % (uint32_t)T.seq_len);
+        int item = c < T.seq_len ? T.seq[(long long)ps->traj_row * T.seq_len + c] : 0;
+        item = item < 0 ? 0 : (item >= T.n_shapes ? T.n_shapes - 1 : item);
+        return (int)(((long long)item * 1024) / T.n_shapes);
     };
-    for (int b = tid; b < N; b += 1024) atomicAdd(&hist[bucket(cost[b])], 1);
+    int mine[4];                                     // N <= 4096 bins per launch group use registers; beyond, recompute
+    for (int k = 0, b = tid; b < N; b += 1024, ++k) {
+        const int bk = bucket_of(b);
+        if (k < 4) mine[k] = bk;
+        atomicAdd(&hist[bk], 1);
+    }
     __syncthreads();
-    if (tid < 64) {                                  // exclusive scan of the 256 counts by one wave
-        int v[4], sum = 0;
-        for (int i = 0; i < 4; ++i) { v[i] = hist[tid * 4 + i]; sum += v[i]; }
+    if (tid < 64) {                                  // exclusive scan of the 1024 counts by one wave
+        int v[16], sum = 0;
+        for (int i = 0; i < 16; ++i) { v[i] = hist[tid * 16 + i]; sum += v[i]; }
         int inc = sum;
         for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
         int acc = inc - sum;
-        for (int i = 0; i < 4; ++i) { start[tid * 4 + i] = acc; acc += v[i]; }
+        for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = acc; acc += v[i]; }
     }
     __syncthreads();
-    for (int b = tid; b < N; b += 1024) order[atomicAdd(&start[bucket(cost[b])], 1)] = base + b;
+    const int chunk = N / NXCD;                      // N is a multiple of 8 (irbpp_capi.hip)
+    for (int k = 0, b = tid; b < N; b += 1024, ++k) {
+        const int bk = k < 4 ? mine[k] : bucket_of(b);
+        const int s_pos = atomicAdd(&start[bk], 1);
+        S.order[NXCD * (s_pos % chunk) + s_pos / chunk] = b;
+    }
 }
 
 // Space.get_heuristic_action (space.py:162-218) for the item of the last observation: its own

@@ -166,3 +166,29 @@ def test_registered_buffer_lifetime_calls():
     assert lib.irbpp_unregister_obs_buffer(a._h, C.c_void_p(ob.data_ptr())) == -1      # never registered
     a.close()
     b.close()
+
+
+def test_item_grouped_launch_order_changes_nothing():
+    """Online steps of a large generic data set launch the bins grouped by observed item per die
+    (irbpp_item_order_kernel; irbpp_config::tuning = IRBPP_TUNE_NO_ITEM_ORDER keeps the index order): every
+    observation, reward and done flag is the same either way, through auto-resets."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload("abc_fine")
+    n = 512
+    a = GpuPackingEnv(shapes, seqs[:700], n, device=DEV, **kw)
+    b = GpuPackingEnv(shapes, seqs[:700], n, device=DEV, tuning=_lib.TUNE_NO_ITEM_ORDER, **kw)
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    done_total = 0
+    for t in range(45):
+        act = a.policy_minz(oa)
+        oa, ra, da = a.step(act)
+        ob, rb, db = b.step(act)
+        assert torch.equal(oa, ob), f"step {t}"
+        assert torch.equal(ra, rb) and torch.equal(da, db)
+        done_total += int(da.sum())
+    assert done_total > n
+    a.check_device_error()
+    b.check_device_error()
+    a.close()
+    b.close()
