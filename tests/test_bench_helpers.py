@@ -43,9 +43,15 @@ def test_usable_cores_is_bounded_by_affinity():
     assert 1 <= n <= len(os.sched_getaffinity(0))
 
 
-@pytest.mark.parametrize("which", ["r01_final", os.path.join("r02", "final")])
+@pytest.mark.parametrize("which", ["r01_final", os.path.join("r02", "final"), os.path.join("r03", "final")])
 def test_committed_bench_line_keeps_the_contract(which):
     line = json.load(open(os.path.join(ROOT, "profiles", which, "bench_default.json")))
+    if which.startswith("r03"):                       # round 3: load-independent timing, per-config extras, VecEnv rates
+        assert line["steps"] % line["steps_per_block"] == 0 and line["steps"] * line["ms_per_step"] >= 1e3 * line["min_seconds"]
+        for key in ("cfg3_general_4096", "cfg4_blockout_k10_1024_per_gpu", "cfg5_abc_fine_2048_per_gpu", "cfg1_cube_4096"):
+            assert 0 < line["extra"][key]["roofline_frac"] < 1 and line["extra"][key]["value"] > 1e6
+        assert line["extra"]["vecenv_step"]["with_trainer_per_env_loop"] > 1e6
+        assert line["ranks"]["ms_per_step_min"] <= line["ranks"]["ms_per_step_max"] and line["scaling"] == "weak"
     if which != "r01_final":                          # round 2: north_star's 8192-bin figure, steady-state mix, ranks
         assert line["extra"]["bins8192_one_gpu"]["value"] > line["value"] * 0.5
         assert line["prefill_steps"] > 0 and line["episodes"]["finished_in_timed_region"] > 0
