@@ -584,6 +584,43 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 // PATH: the overlap path compiled in -- one of the three, so that a transition kernel carries (and allocates registers
 // for) only the path its data set takes, or PATH_ANY: decided at run time from Params (heuristic kernel, fallback build).
 enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
+// One footprint cell list walked for G row groups at once (overlap_test's generic path): per cell one 16-byte scalar
+// load (bottom height, byte offset in the tile), per row group one LDS read at lane base + offset, one subtract and
+// one max.  Four cells per trip, two max chains per row group.
+template <int G>
+__device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&hb)[G], double init, double (&z)[G]) {
+    double a0[G], a1[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) a0[g] = a1[g] = init;
+    int e = 0;
+    for (; e + 4 <= nb; e += 4) {
+        const gcell_words c0 = gc[e], c1 = gc[e + 1], c2 = gc[e + 2], c3 = gc[e + 3];
+        double h0[G], h1[G], h2[G], h3[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            h0[g] = *(const double*)(hb[g] + c0.z); h1[g] = *(const double*)(hb[g] + c1.z);
+            h2[g] = *(const double*)(hb[g] + c2.z); h3[g] = *(const double*)(hb[g] + c3.z);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            a0[g] = fmax(a0[g], h0[g] - gcell_b(c0));
+            a1[g] = fmax(a1[g], h1[g] - gcell_b(c1));
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            a0[g] = fmax(a0[g], h2[g] - gcell_b(c2));
+            a1[g] = fmax(a1[g], h3[g] - gcell_b(c3));
+        }
+    }
+    for (; e < nb; ++e) {
+        const gcell_words c0 = gc[e];
+#pragma unroll
+        for (int g = 0; g < G; ++g) a0[g] = fmax(a0[g], *(const double*)(hb[g] + c0.z) - gcell_b(c0));
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) z[g] = fmax(a0[g], a1[g]);
+}
+
 template <int PATH>
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                    const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged, bool dense) {
@@ -799,8 +836,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // workgroup's LDS (or nothing: beyond the allocation reads return 0) and is discarded.
     const int ysh = P.g_ysh, rpw = 64 >> ysh;
     const int rs = lane >> ysh, Y = lane & ((1 << ysh) - 1);
-    int first[9];                                            // tasks before rotation r
-    first[0] = 0;
+    // Register blocking over row groups: a task is up to three consecutive row groups of one rotation, walked
+    // together, so that one scalar load of a footprint cell (16 bytes, the wave-uniform operand) serves up to 192
+    // action cells instead of 64 and the loop's scalar work is shared.  (The loop was measured to be bound by the
+    // scalar side -- walking two INDEPENDENT lists in one loop for latency changed nothing: abc_fine 5.4 -> 5.1 M --
+    // while the LDS reads and the float64 add/max per (action cell, footprint cell) pair are what they are.)
+    // A rotation's groups are split evenly over ceil(groups / gmax) tasks; gmax drops when that would leave waves
+    // without a task.
+    int ngrp[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         int n = 0;
@@ -809,55 +852,21 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             const int wx = Ax - __builtin_amdgcn_readfirstlane(sp->ax) + 1, wy = Ay - __builtin_amdgcn_readfirstlane(sp->ay) + 1;
             if (wx > 0 && wy > 0) n = (wx + rpw - 1) >> (6 - ysh);
         }
-        first[r + 1] = first[r] + n;
+        ngrp[r] = n;
     }
+    int first[9];                                            // tasks before rotation r
+    // (ngrp <= 4 -- an action grid is at most 256 cells, four waves' worth -- so the ceilings are spelled out)
+    int n3 = 0, n2 = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { n3 += ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0); n2 += (ngrp[r] + 1) >> 1; }
+    const int gmax = n3 >= WAVES ? 3 : (n2 >= WAVES ? 2 : 1);
+    first[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        first[r + 1] = first[r] + (gmax == 3 ? (ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0)) : (gmax == 2 ? (ngrp[r] + 1) >> 1 : ngrp[r]));
     const int ntask = first[8];
     int pref = 0;
-    for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
-    for (int t = wave; t < ntask; t += WAVES) {
-        int r = 0;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) r += t >= first[q] ? 1 : 0;
-        int tq = t;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (q == r) tq = t - first[q];
-        const int X = tq * rpw + rs;
-        const ShapeRot* sp = (const ShapeRot*)srw + r;
-        const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
-        const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
-        const int nb = __builtin_amdgcn_readfirstlane(sp->nb), ob = __builtin_amdgcn_readfirstlane(sp->ob);
-        const double ext_z_r = sp->ext_z_r;
-        const ConstGCellPtr gc = (ConstGCellPtr)(unsigned long long)(T.gcell + ob);
-        // The lists (tens of MB per dataset: beyond L2, and what is in L2 is flushed by every step's observation
-        // stores) are consumed by scalar loads, of which a wave has only one chunk in flight: one vector load per
-        // 128-byte line, issued up front for the wave's FIRST task, brings that list into the XCD's L2 so that the
-        // scalar loads wait for L2 instead of HBM (the later tasks of a rotation find it there anyway).
-        if (t == wave) {
-            const char* lv = (const char*)(T.gcell + ob);
-            for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
-        }
-        const int xc = X < Ax ? X : Ax - 1, yc = Y < Ay ? Y : Ay - 1;
-        const char* hb = (const char*)(L.hm + xc * Ay + yc);
-        const double init = has_out ? 0.0 : -1e300;
-        double a0 = init, a1 = init;
-        int e = 0;
-        // (requesting the next four cells while the reads of the current four are in flight -- scalar loads and LDS
-        // reads share one counter -- was measured and lost: the compiler turns it into a reload at the loop head,
-        // general 12.7 -> 11.9 M steps/s)
-        for (; e + 4 <= nb; e += 4) {                        // four LDS reads in flight per trip, two max chains
-            const gcell_words c0 = gc[e], c1 = gc[e + 1], c2 = gc[e + 2], c3 = gc[e + 3];
-            const double h0 = *(const double*)(hb + c0.z), h1 = *(const double*)(hb + c1.z);
-            const double h2 = *(const double*)(hb + c2.z), h3 = *(const double*)(hb + c3.z);
-            a0 = fmax(a0, h0 - gcell_b(c0));
-            a1 = fmax(a1, h1 - gcell_b(c1));
-            a0 = fmax(a0, h2 - gcell_b(c2));
-            a1 = fmax(a1, h3 - gcell_b(c3));
-        }
-        for (; e < nb; ++e) {
-            const gcell_words c0 = gc[e];
-            a0 = fmax(a0, *(const double*)(hb + c0.z) - gcell_b(c0));
-        }
-        const double z = fmax(a0, a1);
+    auto task_finish = [&](int r, int X, int s_ax, int s_ay, double ext_z_r, double z) {
         const bool in_range = X <= Ax - s_ax && Y <= Ay - s_ay;
         const bool valid = in_range && round6_scaled(z + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
         const int cell = X * Ay + Y;
@@ -884,13 +893,65 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const unsigned long long bal = __ballot(valid);
         if (Y == 0 && X < Ax) L.vbits[r * 16 + X] = (uint32_t)(bal >> (rs << ysh)) & ((1u << Ay) - 1u);
         // presence mask of the rotation: OR over the wave on the DPP network, LDS atomics by its last lane (a rotation
-        // has several tasks)
+        // can have several tasks)
         bits_lo = wave_or_to_lane63(bits_lo);
         bits_hi = wave_or_to_lane63(bits_hi);
         if (lane == 63) {
             uint32_t* pw = (uint32_t*)&L.present[r];
             if (bits_lo) atomicOr(pw, bits_lo);
             if (bits_hi) atomicOr(pw + 1, bits_hi);
+        }
+    };
+    for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
+    for (int t = wave; t < ntask; t += WAVES) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r += t >= first[q] ? 1 : 0;
+        int tq = t, ng = 0, nt = 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q == r) { tq = t - first[q]; ng = ngrp[q]; nt = first[q + 1] - first[q]; }
+        // even split of ng groups over nt tasks: the first ng % nt tasks take one more
+        const int base = nt == 1 ? ng : (nt == ng ? 1 : ng >> 1), rem = ng - base * nt;   // (nt is 1, 2 or ng)
+        const int G = base + (tq < rem ? 1 : 0), g0 = tq * base + (tq < rem ? tq : rem);
+        const ShapeRot* sp = (const ShapeRot*)srw + r;
+        const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
+        const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
+        const int nb = __builtin_amdgcn_readfirstlane(sp->nb), ob = __builtin_amdgcn_readfirstlane(sp->ob);
+        const double ext_z_r = sp->ext_z_r;
+        const ConstGCellPtr gc = (ConstGCellPtr)(unsigned long long)(T.gcell + ob);
+        // The lists (tens of MB per dataset: beyond L2, and what is in L2 is flushed by every step's observation
+        // stores) are consumed by scalar loads, of which a wave has only one chunk in flight: one vector load per
+        // 128-byte line, issued up front for the wave's FIRST task, brings that list into the XCD's L2 so that the
+        // scalar loads wait for L2 instead of HBM (the later tasks of a rotation find it there anyway).
+        if (t == wave) {
+            const char* lv = (const char*)(T.gcell + ob);
+            for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
+        }
+        const double init = has_out ? 0.0 : -1e300;
+        const int yc = Y < Ay ? Y : Ay - 1;
+        const int X0 = g0 * rpw + rs;
+        auto lane_base = [&](int X) { return (const char*)(L.hm + (X < Ax ? X : Ax - 1) * Ay + yc); };
+        // (requesting the next four cells while the reads of the current four are in flight -- scalar loads and LDS
+        // reads share one counter -- was measured and lost: the compiler turns it into a reload at the loop head,
+        // general 12.7 -> 11.9 M steps/s)
+        if (G == 1) {
+            double z[1];
+            const char* hb[1] = {lane_base(X0)};
+            gcell_walk<1>(gc, nb, hb, init, z);
+            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
+        } else if (G == 2) {
+            double z[2];
+            const char* hb[2] = {lane_base(X0), lane_base(X0 + rpw)};
+            gcell_walk<2>(gc, nb, hb, init, z);
+            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
+            task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
+        } else {
+            double z[3];
+            const char* hb[3] = {lane_base(X0), lane_base(X0 + rpw), lane_base(X0 + 2 * rpw)};
+            gcell_walk<3>(gc, nb, hb, init, z);
+            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
+            task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
+            task_finish(r, X0 + 2 * rpw, s_ax, s_ay, ext_z_r, z[2]);
         }
     }
     asm volatile("" :: "v"(pref));                           // the prefetch loads are complete by now; nothing uses their data
