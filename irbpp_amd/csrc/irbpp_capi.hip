@@ -416,6 +416,9 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     if (blkcell.empty()) blkcell.push_back(Cell{0.0, 0, 0});
     // gcell mirrors bcell index for index; on the block / box paths nobody reads it
     if (gcell.empty()) gcell.push_back(GCell{0.0, 0, 0});
+    // (the walk requests the next four cells while it works on the current four: up to seven cells past a list's end
+    // are loaded and ignored)
+    for (int i = 0; i < 8; ++i) gcell.push_back(GCell{0.0, 0, 0});
     Tables& T = env->T;
     int rc = dev_upload(env, &T.sr, sr.data(), sr.size());
     if (rc == IRBPP_OK) rc = dev_upload(env, &T.bcell, (const Cell*)bcell.data(), bcell.size());

@@ -586,36 +586,78 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
 // One footprint cell list walked for G row groups at once (overlap_test's generic path): per cell one 16-byte scalar
 // load (bottom height, byte offset in the tile), per row group one LDS read at lane base + offset, one subtract and
-// one max.  Four cells per trip, two max chains per row group.
+// one max; four cells (one 64-byte scalar load) per trip, two max chains per row group.
+// The scalar load of the NEXT four cells is requested before the LDS reads of the current four and awaited after their
+// max chains, so that its latency (about 300 cycles from L2, tools/microbench_issue.hip) runs beside the trip's own
+// LDS and VALU work instead of in front of it.  The compiler cannot be talked into this order (it moves the request
+// back to the head of the trip: scalar loads return out of order with LDS reads on one counter), hence the two
+// asm statements: the request is invisible to the compiler's wait-count bookkeeping, which stays correct -- one more
+// operation in flight than it knows of makes each of its LDS waits stricter, never looser -- and the explicit wait for
+// everything precedes the first use of the requested cells.  The list storage is padded for the reads past the end.
+typedef int32_t gcell_quad __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ gcell_quad gcell_request(ConstGCellPtr p) {
+    gcell_quad q;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(q) : "s"(p));
+    return q;
+}
+template <int G>
+__device__ __forceinline__ void gcell_await(gcell_quad& q, double (&a0)[G], double (&a1)[G]) {
+    // (the accumulators ride along so that the trip's arithmetic stays in front of the wait)
+    if (G == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(a0[0]), "+v"(a1[0]));
+    else if (G == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[G > 1 ? 1 : 0]), "+v"(a1[G > 1 ? 1 : 0]));
+    else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[G > 1 ? 1 : 0]), "+v"(a1[G > 1 ? 1 : 0]),
+                      "+v"(a0[G > 2 ? 2 : 0]), "+v"(a1[G > 2 ? 2 : 0]));
+}
+template <int G>
+__device__ __forceinline__ void gcell_quad_apply(const gcell_quad& q, const char* const (&hb)[G], double (&a0)[G], double (&a1)[G]) {
+    double h0[G], h1[G], h2[G], h3[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        h0[g] = *(const double*)(hb[g] + q[2]); h1[g] = *(const double*)(hb[g] + q[6]);
+        h2[g] = *(const double*)(hb[g] + q[10]); h3[g] = *(const double*)(hb[g] + q[14]);
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        a0[g] = fmax(a0[g], h0[g] - __hiloint2double(q[1], q[0]));
+        a1[g] = fmax(a1[g], h1[g] - __hiloint2double(q[5], q[4]));
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        a0[g] = fmax(a0[g], h2[g] - __hiloint2double(q[9], q[8]));
+        a1[g] = fmax(a1[g], h3[g] - __hiloint2double(q[13], q[12]));
+    }
+}
 template <int G>
 __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&hb)[G], double init, double (&z)[G]) {
     double a0[G], a1[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) a0[g] = a1[g] = init;
-    int e = 0;
-    for (; e + 4 <= nb; e += 4) {
-        const gcell_words c0 = gc[e], c1 = gc[e + 1], c2 = gc[e + 2], c3 = gc[e + 3];
-        double h0[G], h1[G], h2[G], h3[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            h0[g] = *(const double*)(hb[g] + c0.z); h1[g] = *(const double*)(hb[g] + c1.z);
-            h2[g] = *(const double*)(hb[g] + c2.z); h3[g] = *(const double*)(hb[g] + c3.z);
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            a0[g] = fmax(a0[g], h0[g] - gcell_b(c0));
-            a1[g] = fmax(a1[g], h1[g] - gcell_b(c1));
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            a0[g] = fmax(a0[g], h2[g] - gcell_b(c2));
-            a1[g] = fmax(a1[g], h3[g] - gcell_b(c3));
-        }
+    gcell_quad A = gcell_request(gc), B;
+    gcell_await<G>(A, a0, a1);
+    int e = 0;                                               // A holds cells e .. e + 3
+    bool in_a = true;
+    while (e + 4 <= nb) {
+        B = gcell_request(gc + e + 4);
+        gcell_quad_apply<G>(A, hb, a0, a1);
+        gcell_await<G>(B, a0, a1);
+        e += 4;
+        in_a = false;
+        if (e + 4 > nb) break;
+        A = gcell_request(gc + e + 4);
+        gcell_quad_apply<G>(B, hb, a0, a1);
+        gcell_await<G>(A, a0, a1);
+        e += 4;
+        in_a = true;
     }
-    for (; e < nb; ++e) {
-        const gcell_words c0 = gc[e];
+    if (e < nb) {                                            // the last one to three cells are in the quad already here
+        const gcell_quad q = in_a ? A : B;
+        const int left = nb - e;
 #pragma unroll
-        for (int g = 0; g < G; ++g) a0[g] = fmax(a0[g], *(const double*)(hb[g] + c0.z) - gcell_b(c0));
+        for (int g = 0; g < G; ++g) {
+            a0[g] = fmax(a0[g], *(const double*)(hb[g] + q[2]) - __hiloint2double(q[1], q[0]));
+            if (left > 1) a1[g] = fmax(a1[g], *(const double*)(hb[g] + q[6]) - __hiloint2double(q[5], q[4]));
+            if (left > 2) a0[g] = fmax(a0[g], *(const double*)(hb[g] + q[10]) - __hiloint2double(q[9], q[8]));
+        }
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) z[g] = fmax(a0[g], a1[g]);
@@ -838,9 +880,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     const int rs = lane >> ysh, Y = lane & ((1 << ysh) - 1);
     // Register blocking over row groups: a task is up to three consecutive row groups of one rotation, walked
     // together, so that one scalar load of a footprint cell (16 bytes, the wave-uniform operand) serves up to 192
-    // action cells instead of 64 and the loop's scalar work is shared.  (The loop was measured to be bound by the
-    // scalar side -- walking two INDEPENDENT lists in one loop for latency changed nothing: abc_fine 5.4 -> 5.1 M --
-    // while the LDS reads and the float64 add/max per (action cell, footprint cell) pair are what they are.)
+    // action cells instead of 64.  The scalar side was the loop's bound: a CU gets one 64-byte scalar load per 14-18
+    // cycles (tools/microbench_issue.hip: 3.5-4.6 bytes per cycle per CU, cache hit or L2), i.e. 4 cycles per cell
+    // and wave, against 2.2 for the LDS read and 3.3 for the three VALU instructions.  Blocked three deep the VALU
+    // work is the largest term.  (Walking two INDEPENDENT lists in one loop instead -- same scalar traffic, twice the
+    // work per wait -- changed nothing: abc_fine 5.4 -> 5.1 M.  One address add per cell with the other row groups
+    // at immediate offsets, 512 bytes apart on a 16-wide grid, removes 8 of a trip's 36 VALU instructions and was
+    // 10% SLOWER in an A/B on one box, abc_fine 6.67 -> 6.0 M, general 13.96 -> 13.44 M; the LDS microbenchmark shows no
+    // difference between the two forms, the cause was not found.)
     // A rotation's groups are split evenly over ceil(groups / gmax) tasks; gmax drops when that would leave waves
     // without a task.
     int ngrp[8];
@@ -902,6 +949,10 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             if (bits_hi) atomicOr(pw + 1, bits_hi);
         }
     };
+    auto prefetch_list = [&](int ob, int nb) {
+        const char* lv = (const char*)(T.gcell + ob);
+        for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
+    };
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
     for (int t = wave; t < ntask; t += WAVES) {
         int r = 0;
@@ -921,19 +972,26 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const ConstGCellPtr gc = (ConstGCellPtr)(unsigned long long)(T.gcell + ob);
         // The lists (tens of MB per dataset: beyond L2, and what is in L2 is flushed by every step's observation
         // stores) are consumed by scalar loads, of which a wave has only one chunk in flight: one vector load per
-        // 128-byte line, issued up front for the wave's FIRST task, brings that list into the XCD's L2 so that the
-        // scalar loads wait for L2 instead of HBM (the later tasks of a rotation find it there anyway).
-        if (t == wave) {
-            const char* lv = (const char*)(T.gcell + ob);
-            for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
+        // 128-byte line, issued a task ahead (the wave's first task: up front), brings a list into the XCD's L2 so that
+        // the scalar loads wait for L2 instead of HBM.  (Requesting all of the next item's lists earlier still -- beside
+        // its ShapeRots, before the placement is applied -- was measured and is worse: abc_fine 7.1 -> 6.9 M, general
+        // 14.6 -> 14.1 M; the lines do not survive in L2 until they are needed, and the kept-alive register costs the
+        // kernel its seventh wave per SIMD.)
+        if (t == wave) prefetch_list(ob, nb);
+        if (t + WAVES < ntask) {
+            const int tn = t + WAVES;
+            int rn = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) rn += tn >= first[q] ? 1 : 0;
+            if (rn != r) {
+                const ShapeRot* sn = (const ShapeRot*)srw + rn;
+                prefetch_list(__builtin_amdgcn_readfirstlane(sn->ob), __builtin_amdgcn_readfirstlane(sn->nb));
+            }
         }
         const double init = has_out ? 0.0 : -1e300;
         const int yc = Y < Ay ? Y : Ay - 1;
         const int X0 = g0 * rpw + rs;
         auto lane_base = [&](int X) { return (const char*)(L.hm + (X < Ax ? X : Ax - 1) * Ay + yc); };
-        // (requesting the next four cells while the reads of the current four are in flight -- scalar loads and LDS
-        // reads share one counter -- was measured and lost: the compiler turns it into a reload at the loop head,
-        // general 12.7 -> 11.9 M steps/s)
         if (G == 1) {
             double z[1];
             const char* hb[1] = {lane_base(X0)};
