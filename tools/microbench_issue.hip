@@ -11,11 +11,13 @@
 #define ITER 4096
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum Op { ADD_U32, ADD_F64, MAX_F64, FMA_F64, SUBMAX_F64, LDS_B64_DISTINCT, LDS_B64_OFFSETS, LDS_B64_SAMEADDR, SMEM_X16_K, SMEM_X16_L2, NOPS };
+enum Op { ADD_U32, ADD_F64, MAX_F64, FMA_F64, SUBMAX_F64, LDS_B64_DISTINCT, LDS_B64_OFFSETS, LDS_B64_SAMEADDR, SMEM_X16_K, SMEM_X16_L2, SMEM_X1_HOT, SMEM_X2_HOT, SMEM_X4_HOT, SMEM_X8_HOT, SMEM_X16_HOT, NOPS };
 static const char* NAMES[] = {"v_add_u32", "v_add_f64", "v_max_f64", "v_fma_f64", "v_add_f64+v_max_f64 (per pair)",
                               "ds_read_b64, 12 address VGPRs", "ds_read_b64, 4 address VGPRs x 3 immediate offsets",
                               "ds_read_b64, one address VGPR", "s_load_dwordx16, 4 KB per wave (scalar cache)",
-                              "s_load_dwordx16, 256 KB per wave (L2)"};
+                              "s_load_dwordx16, 256 KB per wave (L2)", "s_load_dword, one hot 1 KB block (kernarg-like)",
+                              "s_load_dwordx2, hot block", "s_load_dwordx4, hot block", "s_load_dwordx8, hot block",
+                              "s_load_dwordx16, hot block"};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k(double* out, int seed, const char* cells, int span) {
@@ -50,6 +52,47 @@ __global__ void __launch_bounds__(1024) k(double* out, int seed, const char* cel
             for (int j = 0; j < 12; ++j) asm volatile("v_add_f64 %0, %1, -%2" : "=v"(t[j]) : "v"(a[(j + 1) % 12]), "s"(s));
 #pragma unroll
             for (int j = 0; j < 12; ++j) asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[j]) : "v"(t[j]));
+        } else if (OP >= SMEM_X1_HOT && OP <= SMEM_X16_HOT) {
+            // every wave of the chip reads the same 1 KB (what Params / ShapeRot reads of a transition kernel look like)
+#pragma unroll
+            for (int j = 0; j < 12; j += 2) {
+                const char* q = cells + (((it * 12 + j) * 64) & 1023);
+                if (OP == SMEM_X1_HOT) {
+                    int x, y;
+                    asm volatile("s_load_dword %0, %1, 0x0" : "=&s"(x) : "s"(q));
+                    asm volatile("s_load_dword %0, %1, 0x20" : "=&s"(y) : "s"(q));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+                    u[j] += x + y;
+                } else if (OP == SMEM_X2_HOT) {
+                    typedef int v2 __attribute__((ext_vector_type(2)));
+                    v2 x, y;
+                    asm volatile("s_load_dwordx2 %0, %1, 0x0" : "=&s"(x) : "s"(q));
+                    asm volatile("s_load_dwordx2 %0, %1, 0x20" : "=&s"(y) : "s"(q));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+                    u[j] += x[1] + y[0];
+                } else if (OP == SMEM_X4_HOT) {
+                    typedef int v4 __attribute__((ext_vector_type(4)));
+                    v4 x, y;
+                    asm volatile("s_load_dwordx4 %0, %1, 0x0" : "=&s"(x) : "s"(q));
+                    asm volatile("s_load_dwordx4 %0, %1, 0x20" : "=&s"(y) : "s"(q));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+                    u[j] += x[3] + y[1];
+                } else if (OP == SMEM_X8_HOT) {
+                    typedef int v8 __attribute__((ext_vector_type(8)));
+                    v8 x, y;
+                    asm volatile("s_load_dwordx8 %0, %1, 0x0" : "=&s"(x) : "s"(q));
+                    asm volatile("s_load_dwordx8 %0, %1, 0x20" : "=&s"(y) : "s"(q));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+                    u[j] += x[3] + y[5];
+                } else {
+                    typedef int v16 __attribute__((ext_vector_type(16)));
+                    v16 x, y;
+                    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(x) : "s"(q));
+                    asm volatile("s_load_dwordx16 %0, %1, 0x40" : "=&s"(y) : "s"(q));
+                    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(x), "+s"(y));
+                    u[j] += x[3] + y[5];
+                }
+            }
         } else if (OP == SMEM_X16_K || OP == SMEM_X16_L2) {
             typedef int v16 __attribute__((ext_vector_type(16)));
             const int wv = __builtin_amdgcn_readfirstlane((blockIdx.x * blockDim.x + threadIdx.x) >> 6);
@@ -128,6 +171,8 @@ int main() {
     if (run<ADD_U32>(out, cells, mhz, cus) || run<ADD_F64>(out, cells, mhz, cus) || run<MAX_F64>(out, cells, mhz, cus) ||
         run<FMA_F64>(out, cells, mhz, cus) || run<SUBMAX_F64>(out, cells, mhz, cus) || run<LDS_B64_DISTINCT>(out, cells, mhz, cus) ||
         run<LDS_B64_OFFSETS>(out, cells, mhz, cus) || run<LDS_B64_SAMEADDR>(out, cells, mhz, cus) ||
-        run<SMEM_X16_K>(out, cells, mhz, cus) || run<SMEM_X16_L2>(out, cells, mhz, cus)) return 1;
+        run<SMEM_X16_K>(out, cells, mhz, cus) || run<SMEM_X16_L2>(out, cells, mhz, cus) ||
+        run<SMEM_X1_HOT>(out, cells, mhz, cus) || run<SMEM_X2_HOT>(out, cells, mhz, cus) || run<SMEM_X4_HOT>(out, cells, mhz, cus) ||
+        run<SMEM_X8_HOT>(out, cells, mhz, cus) || run<SMEM_X16_HOT>(out, cells, mhz, cus)) return 1;
     return 0;
 }
