@@ -102,6 +102,16 @@ def test_online_odd_action_grid_matches_oracle(shapes_kind):
     assert _run_online(sh, seqs, 5, 40, bin_dimension=(0.30, 0.26, 0.30), selectedAction=150) >= 1
 
 
+@pytest.mark.parametrize("n_rot,fmin,fmax,min_done", [(1, 4, 8, 0), (1, 8, 16, 5), (2, 4, 8, 0), (2, 8, 16, 5), (3, 4, 14, 2)])
+def test_online_generic_path_blocking_depths_match_oracle(n_rot, fmin, fmax, min_done):
+    """The generic overlap path deals (rotation, row-group block) tasks to four waves and blocks up to three row
+    groups on registers; with few rotations the blocks shrink so that no wave idles (R = 2: two groups, R = 1: one),
+    and footprints of up to 8 cells have four row groups in range, which split 2 + 2.  Every depth against the oracle."""
+    sh = synthetic.general_shapes(n_shapes=16, n_rot=n_rot, fmin=fmin, fmax=fmax, seed=50 + n_rot)
+    seqs = synthetic.make_sequences(sh.n_shapes, 48, 80, seed=60 + fmin)
+    assert _run_online(sh, seqs, 5, 36) >= min_done          # (the small items do not fill a bin in 36 steps)
+
+
 def test_online_fine_heightmap_matches_oracle():
     sh = synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=4)
     assert _run_online(sh, synthetic.make_sequences(sh.n_shapes, 32, 60, seed=2), 3, 14, resolutionH=0.005) >= 1
