@@ -11,13 +11,15 @@
 #define ITER 4096
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum Op { ADD_U32, ADD_F64, MAX_F64, FMA_F64, SUBMAX_F64, LDS_B64_DISTINCT, LDS_B64_OFFSETS, LDS_B64_SAMEADDR, SMEM_X16_K, SMEM_X16_L2, SMEM_X1_HOT, SMEM_X2_HOT, SMEM_X4_HOT, SMEM_X8_HOT, SMEM_X16_HOT, NOPS };
+enum Op { ADD_U32, ADD_F64, MAX_F64, FMA_F64, SUBMAX_F64, LDS_B64_DISTINCT, LDS_B64_OFFSETS, LDS_B64_SAMEADDR, SMEM_X16_K, SMEM_X16_L2, SMEM_X1_HOT, SMEM_X2_HOT, SMEM_X4_HOT, SMEM_X8_HOT, SMEM_X16_HOT, LDS_OFFS_DEST_OVERLAPS_ADDR, LDS_OFFS_DEST_APART, NOPS };
 static const char* NAMES[] = {"v_add_u32", "v_add_f64", "v_max_f64", "v_fma_f64", "v_add_f64+v_max_f64 (per pair)",
                               "ds_read_b64, 12 address VGPRs", "ds_read_b64, 4 address VGPRs x 3 immediate offsets",
                               "ds_read_b64, one address VGPR", "s_load_dwordx16, 4 KB per wave (scalar cache)",
                               "s_load_dwordx16, 256 KB per wave (L2)", "s_load_dword, one hot 1 KB block (kernarg-like)",
                               "s_load_dwordx2, hot block", "s_load_dwordx4, hot block", "s_load_dwordx8, hot block",
-                              "s_load_dwordx16, hot block"};
+                              "s_load_dwordx16, hot block",
+                              "ds_read_b64 x3 on one address VGPR, last destination overlaps it",
+                              "ds_read_b64 x3 on one address VGPR, destinations apart"};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k(double* out, int seed, const char* cells, int span) {
@@ -52,6 +54,19 @@ __global__ void __launch_bounds__(1024) k(double* out, int seed, const char* cel
             for (int j = 0; j < 12; ++j) asm volatile("v_add_f64 %0, %1, -%2" : "=v"(t[j]) : "v"(a[(j + 1) % 12]), "s"(s));
 #pragma unroll
             for (int j = 0; j < 12; ++j) asm volatile("v_max_f64 %0, %0, %1" : "+v"(a[j]) : "v"(t[j]));
+        } else if (OP == LDS_OFFS_DEST_OVERLAPS_ADDR || OP == LDS_OFFS_DEST_APART) {
+            // does a destination that overlaps the address register of reads still in flight cost anything?
+            // (fixed registers; 12 reads per trip as four blocks of three, one wait per trip)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (OP == LDS_OFFS_DEST_OVERLAPS_ADDR)
+                    asm volatile("v_mov_b32 v40, %0\n ds_read_b64 v[42:43], v40\n ds_read_b64 v[44:45], v40 offset:512\n"
+                                 "ds_read_b64 v[40:41], v40 offset:1024" :: "v"(ad[j]) : "v40", "v41", "v42", "v43", "v44", "v45");
+                else
+                    asm volatile("v_mov_b32 v40, %0\n ds_read_b64 v[42:43], v40\n ds_read_b64 v[44:45], v40 offset:512\n"
+                                 "ds_read_b64 v[46:47], v40 offset:1024" :: "v"(ad[j]) : "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47");
         } else if (OP >= SMEM_X1_HOT && OP <= SMEM_X16_HOT) {
             // every wave of the chip reads the same 1 KB (what Params / ShapeRot reads of a transition kernel look like)
 #pragma unroll
@@ -173,6 +188,7 @@ int main() {
         run<LDS_B64_OFFSETS>(out, cells, mhz, cus) || run<LDS_B64_SAMEADDR>(out, cells, mhz, cus) ||
         run<SMEM_X16_K>(out, cells, mhz, cus) || run<SMEM_X16_L2>(out, cells, mhz, cus) ||
         run<SMEM_X1_HOT>(out, cells, mhz, cus) || run<SMEM_X2_HOT>(out, cells, mhz, cus) || run<SMEM_X4_HOT>(out, cells, mhz, cus) ||
-        run<SMEM_X8_HOT>(out, cells, mhz, cus) || run<SMEM_X16_HOT>(out, cells, mhz, cus)) return 1;
+        run<SMEM_X8_HOT>(out, cells, mhz, cus) || run<SMEM_X16_HOT>(out, cells, mhz, cus) ||
+        run<LDS_OFFS_DEST_OVERLAPS_ADDR>(out, cells, mhz, cus) || run<LDS_OFFS_DEST_APART>(out, cells, mhz, cus)) return 1;
     return 0;
 }
