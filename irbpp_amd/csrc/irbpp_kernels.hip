@@ -608,13 +608,29 @@ __device__ __forceinline__ void gcell_await(gcell_quad& q, double (&a0)[G], doub
     else asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(q), "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[G > 1 ? 1 : 0]), "+v"(a1[G > 1 ? 1 : 0]),
                       "+v"(a0[G > 2 ? 2 : 0]), "+v"(a1[G > 2 ? 2 : 0]));
 }
-template <int G>
+// One heightmap read of row group g at byte offset `off`.  STRIDE > 0: the row groups' lane bases are STRIDE bytes apart
+// (an action grid whose rows are a power of two wide: a row group is 64 consecutive doubles of a plane), so a trip adds
+// each cell's offset to ONE base and the groups differ by the instruction's immediate offset: 4 + 24 VALU instructions
+// per trip of four cells and three groups instead of 12 + 24.  (volatile: left alone, the compiler pairs two groups'
+// reads into ds_read2st64_b64, which takes 8 LDS cycles where two ds_read_b64 take 4 -- MI355X_MICROARCH.md, LDS table.
+// The low word of a generic pointer into the LDS is its LDS byte address.)
+template <int G, int STRIDE>
+__device__ __forceinline__ double gcell_height(const char* const (&hb)[G], int g, int off) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (STRIDE > 0) {
+        typedef const volatile __attribute__((address_space(3))) double* LdsF64;
+        return *(LdsF64)((uint32_t)(uintptr_t)hb[0] + off + g * STRIDE);
+    }
+#endif
+    return *(const double*)(hb[STRIDE > 0 ? 0 : g] + off + (STRIDE > 0 ? g * STRIDE : 0));
+}
+template <int G, int STRIDE>
 __device__ __forceinline__ void gcell_quad_apply(const gcell_quad& q, const char* const (&hb)[G], double (&a0)[G], double (&a1)[G]) {
     double h0[G], h1[G], h2[G], h3[G];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-        h0[g] = *(const double*)(hb[g] + q[2]); h1[g] = *(const double*)(hb[g] + q[6]);
-        h2[g] = *(const double*)(hb[g] + q[10]); h3[g] = *(const double*)(hb[g] + q[14]);
+        h0[g] = gcell_height<G, STRIDE>(hb, g, q[2]); h1[g] = gcell_height<G, STRIDE>(hb, g, q[6]);
+        h2[g] = gcell_height<G, STRIDE>(hb, g, q[10]); h3[g] = gcell_height<G, STRIDE>(hb, g, q[14]);
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -627,7 +643,7 @@ __device__ __forceinline__ void gcell_quad_apply(const gcell_quad& q, const char
         a1[g] = fmax(a1[g], h3[g] - __hiloint2double(q[13], q[12]));
     }
 }
-template <int G>
+template <int G, int STRIDE>
 __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&hb)[G], double init, double (&z)[G]) {
     double a0[G], a1[G];
 #pragma unroll
@@ -638,13 +654,13 @@ __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&
     bool in_a = true;
     while (e + 4 <= nb) {
         B = gcell_request(gc + e + 4);
-        gcell_quad_apply<G>(A, hb, a0, a1);
+        gcell_quad_apply<G, STRIDE>(A, hb, a0, a1);
         gcell_await<G>(B, a0, a1);
         e += 4;
         in_a = false;
         if (e + 4 > nb) break;
         A = gcell_request(gc + e + 4);
-        gcell_quad_apply<G>(B, hb, a0, a1);
+        gcell_quad_apply<G, STRIDE>(B, hb, a0, a1);
         gcell_await<G>(A, a0, a1);
         e += 4;
         in_a = true;
@@ -654,9 +670,9 @@ __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&
         const int left = nb - e;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            a0[g] = fmax(a0[g], *(const double*)(hb[g] + q[2]) - __hiloint2double(q[1], q[0]));
-            if (left > 1) a1[g] = fmax(a1[g], *(const double*)(hb[g] + q[6]) - __hiloint2double(q[5], q[4]));
-            if (left > 2) a0[g] = fmax(a0[g], *(const double*)(hb[g] + q[10]) - __hiloint2double(q[9], q[8]));
+            a0[g] = fmax(a0[g], gcell_height<G, STRIDE>(hb, g, q[2]) - __hiloint2double(q[1], q[0]));
+            if (left > 1) a1[g] = fmax(a1[g], gcell_height<G, STRIDE>(hb, g, q[6]) - __hiloint2double(q[5], q[4]));
+            if (left > 2) a0[g] = fmax(a0[g], gcell_height<G, STRIDE>(hb, g, q[10]) - __hiloint2double(q[9], q[8]));
         }
     }
 #pragma unroll
@@ -878,16 +894,18 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // workgroup's LDS (or nothing: beyond the allocation reads return 0) and is discarded.
     const int ysh = P.g_ysh, rpw = 64 >> ysh;
     const int rs = lane >> ysh, Y = lane & ((1 << ysh) - 1);
+    const bool rows_whole = (1 << ysh) == Ay;                // wave-uniform
     // Register blocking over row groups: a task is up to three consecutive row groups of one rotation, walked
     // together, so that one scalar load of a footprint cell (16 bytes, the wave-uniform operand) serves up to 192
     // action cells instead of 64.  The scalar side was the loop's bound: a CU gets one 64-byte scalar load per 14-18
     // cycles (tools/microbench_issue.hip: 3.5-4.6 bytes per cycle per CU, cache hit or L2), i.e. 4 cycles per cell
     // and wave, against 2.2 for the LDS read and 3.3 for the three VALU instructions.  Blocked three deep the VALU
     // work is the largest term.  (Walking two INDEPENDENT lists in one loop instead -- same scalar traffic, twice the
-    // work per wait -- changed nothing: abc_fine 5.4 -> 5.1 M.  One address add per cell with the other row groups
-    // at immediate offsets, 512 bytes apart on a 16-wide grid, removes 8 of a trip's 36 VALU instructions and was
-    // 10% SLOWER in an A/B on one box, abc_fine 6.67 -> 6.0 M, general 13.96 -> 13.44 M; the LDS microbenchmark shows no
-    // difference between the two forms, the cause was not found.)
+    // work per wait -- changed nothing: abc_fine 5.4 -> 5.1 M.)  On grids whose rows are a power of two wide the row
+    // groups share one address add per cell (gcell_height): 28 instead of 36 VALU instructions per trip.  That form
+    // LOST 10 % while the loop still waited for its scalar loads one trip at a time (abc_fine 6.67 -> 6.0 M, cause not
+    // found: neither LDS cycles nor conflicts differ) and wins 2-3 % now that the loads are pipelined (7.12 -> 7.34 M,
+    // general 14.6 -> 14.9 M; SQ_INSTS_VALU of the kernel -14 %).
     // A rotation's groups are split evenly over ceil(groups / gmax) tasks; gmax drops when that would leave waves
     // without a task.
     int ngrp[8];
@@ -992,25 +1010,27 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const int yc = Y < Ay ? Y : Ay - 1;
         const int X0 = g0 * rpw + rs;
         auto lane_base = [&](int X) { return (const char*)(L.hm + (X < Ax ? X : Ax - 1) * Ay + yc); };
-        if (G == 1) {
-            double z[1];
-            const char* hb[1] = {lane_base(X0)};
-            gcell_walk<1>(gc, nb, hb, init, z);
-            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
-        } else if (G == 2) {
-            double z[2];
-            const char* hb[2] = {lane_base(X0), lane_base(X0 + rpw)};
-            gcell_walk<2>(gc, nb, hb, init, z);
-            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
-            task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
+        // whole rows per wave (Ay a power of two): the row groups' bases are 512 bytes apart and need no clamp -- a lane
+        // outside the grid reads some float64 of the workgroup's LDS, or 0 beyond its allocation, and is discarded
+        double z[3];
+        if (rows_whole) {
+            const char* h1[1] = {(const char*)(L.hm + X0 * Ay + Y)};
+            const char* h2[2] = {h1[0], nullptr};
+            const char* h3[3] = {h1[0], nullptr, nullptr};
+            if (G == 1) gcell_walk<1, 512>(gc, nb, h1, init, (double(&)[1])z[0]);
+            else if (G == 2) gcell_walk<2, 512>(gc, nb, h2, init, (double(&)[2])z[0]);
+            else gcell_walk<3, 512>(gc, nb, h3, init, z);
         } else {
-            double z[3];
-            const char* hb[3] = {lane_base(X0), lane_base(X0 + rpw), lane_base(X0 + 2 * rpw)};
-            gcell_walk<3>(gc, nb, hb, init, z);
-            task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
-            task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
-            task_finish(r, X0 + 2 * rpw, s_ax, s_ay, ext_z_r, z[2]);
+            const char* h1[1] = {lane_base(X0)};
+            const char* h2[2] = {h1[0], lane_base(X0 + rpw)};
+            const char* h3[3] = {h1[0], h2[1], lane_base(X0 + 2 * rpw)};
+            if (G == 1) gcell_walk<1, 0>(gc, nb, h1, init, (double(&)[1])z[0]);
+            else if (G == 2) gcell_walk<2, 0>(gc, nb, h2, init, (double(&)[2])z[0]);
+            else gcell_walk<3, 0>(gc, nb, h3, init, z);
         }
+        task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
+        if (G > 1) task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
+        if (G > 2) task_finish(r, X0 + 2 * rpw, s_ax, s_ay, ext_z_r, z[2]);
     }
     asm volatile("" :: "v"(pref));                           // the prefetch loads are complete by now; nothing uses their data
     if (debug_out)                                           // posZmap / naiveMask outside every rotation's range
