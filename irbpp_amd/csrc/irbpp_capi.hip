@@ -500,8 +500,11 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
         if ((t & IRBPP_TUNE_NARROW_KERNEL) || lds_allows_8) return {irbpp_env_kernel_box8, "irbpp_env_kernel_box8"};
         return {irbpp_env_kernel_box, "irbpp_env_kernel_box"};
     }
-    // generic path: seven waves per SIMD (72 VGPRs) beat eight under the 64-VGPR cap: general 12.9 vs 12.2 M steps/s
-    if (t & IRBPP_TUNE_NARROW_KERNEL) return {irbpp_env_kernel_generic8, "irbpp_env_kernel_generic8"};
+    // generic path: the build under the 64-VGPR cap where the LDS lets an eighth workgroup onto the CU (general 15.1 vs
+    // 14.9 M steps/s, blockout at R = 8 20.4 vs 20.1 M with the blocked and pipelined loop; before it the seven-wave
+    // build was ahead, 12.9 vs 12.2 M); a 64 x 64 heightmap (40 KB, four workgroups) gains nothing from the cap
+    if (t & IRBPP_TUNE_WIDE_KERNEL) return {irbpp_env_kernel_generic, "irbpp_env_kernel_generic"};
+    if ((t & IRBPP_TUNE_NARROW_KERNEL) || lds_allows_8) return {irbpp_env_kernel_generic8, "irbpp_env_kernel_generic8"};
     return {irbpp_env_kernel_generic, "irbpp_env_kernel_generic"};
 }
 
