@@ -81,6 +81,9 @@ typedef struct {
 #define IRBPP_TUNE_NARROW_KERNEL  4   /* transition kernel under the 64-VGPR cap even on the generic path           */
 #define IRBPP_TUNE_NO_BOX_PATH    8   /* box data (Cube) through the generic overlap test too                       */
 #define IRBPP_TUNE_NO_ITEM_ORDER 16   /* launch the bins in index order instead of grouped by observed item per XCD */
+#define IRBPP_TUNE_TRACE_CPW64   32   /* border following with 64 / 32 / 16 candidate starts per wave whatever the number of */
+#define IRBPP_TUNE_TRACE_CPW32   64   /* bins (default: by the number of bins, see launch_group in irbpp_capi.hip)          */
+#define IRBPP_TUNE_TRACE_CPW16  128
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
  * adds on `done` (binPhy.py:299-311,327; monitor.py:58-75).  All device pointers, one entry
@@ -329,6 +332,8 @@ int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
 #define IRBPP_DEVERR_BAD_BIN       8   /* irbpp_reset_bins: bin index outside [0, num_bins)  */
 #define IRBPP_DEVERR_CAPACITY     16   /* a die's candidate list overflowed (it holds twice the worst case of a fair
                                           share of the bins): results of that step are incomplete                */
+#define IRBPP_DEVERR_STREAM_DRY   32   /* item_stream = 1: a bin fetched a ring slot it had consumed already and the host
+                                          had not rewritten (irbpp_stream_write): its episode got no item there  */
 
 #ifdef __cplusplus
 }

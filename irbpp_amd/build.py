@@ -53,4 +53,13 @@ def build(force: bool = False, verbose: bool = False) -> str:
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError("hipcc failed:\n" + res.stdout + res.stderr)
+    # The generic overlap loop waits for its pipelined scalar loads in a second asm statement: refuse a library in
+    # which the compiler put a use of the loaded registers in between (asmcheck.py; disassembly of what was just built)
+    from . import asmcheck
+    chk = asmcheck.check_library(out)
+    if verbose:
+        print(f"asmcheck: {chk['scalar_loads']} scalar loads in {chk['functions']} kernels, {len(chk['problems'])} hazards")
+    if chk["problems"]:
+        os.replace(out, out + ".rejected")
+        raise RuntimeError("scalar-load hazard in the built library (kept as " + out + ".rejected):\n" + "\n".join(chk["problems"]))
     return out

@@ -30,6 +30,7 @@ struct irbpp_env {
     bool item_order = false;               // launch slots grouped by observed item, one contiguous range per XCD (generic path)
     long long* phase_cycles = nullptr;
     int32_t* auto_actions = nullptr;       // irbpp_set_auto_policy
+    int32_t* err_mirror = nullptr;         // irbpp_step_out::err_dev of the last step: every error bit is ORed into it as it is raised
     std::vector<std::pair<const float*, int32_t*>> obs_buffers;   // irbpp_register_obs_buffer: buffer -> rows per bin
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
     size_t timing_next = 0, timing_used = 0;
@@ -66,6 +67,9 @@ int dev_upload(irbpp_env* env, const T** out, const T* host, size_t count) {
 }
 
 inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np.round(x, 6)
+constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
+constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
+constexpr int TRACE_CPW32_BINS = 0;         // ... 32 per wave (0: never; set from the A/B runs in profiles/r04)
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
@@ -157,6 +161,8 @@ int raise_lds_limits() {
 
 }  // namespace
 
+static int trace_grid_cap(int N) { return N > TRACE_SMALL_GRID ? N : TRACE_SMALL_GRID; }
+
 extern "C" {
 
 const char* irbpp_status_string(int status) {
@@ -171,7 +177,7 @@ const char* irbpp_status_string(int status) {
     }
 }
 
-int irbpp_version(void) { return 300; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen
+int irbpp_version(void) { return 400; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
@@ -251,7 +257,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_img, N * P.wimg * 16);
     ALLOC(w_imgrot, N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
-    ALLOC(w_big, N * 6 * TRACE_BIG);                   // one scratch per wave of the trace grid (N waves)
+    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * 6 * TRACE_BIG);   // one scratch per wave of the trace grid
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
@@ -508,6 +514,18 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
     return {irbpp_env_kernel_generic, "irbpp_env_kernel_generic"};
 }
 
+// Border following: candidates per wave and grid of a launch over n bins.  A bin averages a few dozen candidate starts; at
+// full width (thousands of bins) 64 per wave fill every SIMD and fewer, shorter-lived waves only add scheduling overhead
+// (measured at 4096 bins: 28.3 / 26.8 / 24.3 M steps/s for 64 / 32 / 16); a launch over few bins leaves SIMDs idle, and a
+// wave lasts as long as the longest of its borders, so there the candidates are spread over more waves.
+static int pick_trace_cpw(const irbpp_env* env, int n) {
+    const int t = env->cfg.tuning;
+    if (t & IRBPP_TUNE_TRACE_CPW64) return 64;
+    if (t & IRBPP_TUNE_TRACE_CPW32) return 32;
+    if (t & IRBPP_TUNE_TRACE_CPW16) return 16;
+    return n <= TRACE_CPW16_BINS ? 16 : (n <= TRACE_CPW32_BINS ? 32 : 64);
+}
+
 // One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the
 // transition kernel and, in the split pipeline, trace and emit -- on one stream.
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
@@ -535,8 +553,11 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
         // beyond (half / a third of either grid with striding measured -4 ... -9 %)
-        const int tgrid = n * (64 / TRACE_CPW), pgrid = 2 * n;
-        hipLaunchKernelGGL(irbpp_trace_kernel, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
+        const int cpw = pick_trace_cpw(env, n), pgrid = 2 * n;
+        int tgrid = n * (64 / cpw);
+        if (tgrid > trace_grid_cap(env->P.N)) tgrid = trace_grid_cap(env->P.N);      // (w_big holds one scratch per wave of the grid)
+        auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
+        hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
         hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
@@ -605,12 +626,21 @@ int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev, const
         io.ep_reward = out->ep_reward_dev;
         io.ep_len = out->ep_len_dev;
         io.stable = out->stable_dev;
-        if (env->P.K == 1) io.err_out = out->err_dev;      // online: written by the emit kernel, the step's last one
+        // The error word of the outputs.  Online (K == 1): stored by the emit kernel, the step's last one.  Buffered (K > 1):
+        // the transition kernel is the last one and may raise bits itself, so every kernel ORs a bit into S.err AND into
+        // this word as it raises it (raise_error), and the emit kernel of get_action_candidates stores S.err into it; the
+        // word only needs seeding when the caller hands over a new one.  (A 4-byte device-to-device copy per step -- a
+        // 5 us kernel to move one int -- did this before: 3.3 % of the GPU time of a buffered step at 1024 bins.)
+        io.err_out = out->err_dev;
+        if (out->err_dev != env->err_mirror) {
+            if (out->err_dev != nullptr)
+                HIP_TRY(hipMemcpyAsync(out->err_dev, env->S.err, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+            env->err_mirror = out->err_dev;
+        }
+    } else {
+        env->err_mirror = nullptr;
     }
-    const int rc = launch_env(env, io, MODE_STEP, stream);
-    if (rc == IRBPP_OK && env->P.K > 1 && out && out->err_dev)      // buffered: the transition kernel is the last one and may raise bits itself
-        HIP_TRY(hipMemcpyAsync(out->err_dev, env->S.err, sizeof(int32_t), hipMemcpyDeviceToDevice, (hipStream_t)stream));
-    return rc;
+    return launch_env(env, io, MODE_STEP, stream);
 }
 
 int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev, float* loc_obs_dev, void* stream) {
@@ -622,6 +652,7 @@ int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev
     io.actions = order_actions_dev;
     io.obs = loc_obs_dev;
     io.obs_stride = env->P.obs_len1;
+    io.err_out = env->err_mirror;          // the error word of the step outputs follows S.err through this call too
     return launch_env(env, io, MODE_CANDS, stream);
 }
 

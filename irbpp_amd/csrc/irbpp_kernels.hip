@@ -117,11 +117,23 @@ __device__ inline int trajectory_row(const Params& P, const Tables& T, int b, in
     if (row < 0) row += T.n_traj;
     return (int)row;
 }
+// Device error bits are sticky in S.err; a step that has an error word in its outputs (StepIO::err_out) gets every bit
+// there too, at the moment it is raised -- the buffered step (K > 1) ends with the transition kernel, so nobody copies
+// the word afterwards (the online step's emit kernel stores S.err into it once more at the end).  Cold path: the
+// pointer is read from the kernarg segment where it is needed.
+struct KernArgs;
+__device__ __forceinline__ void raise_error(const State& S, int bit);
+constexpr int STREAM_CONSUMED = -3;     // stream mode: a ring slot the bin has read and the host has not rewritten yet
 __device__ inline int fetch_item(const Tables& T, const State& S, int row, int cursor) {
     if (T.stream) cursor = (int)((uint32_t)cursor % (uint32_t)T.seq_len);
     else if (cursor >= T.seq_len) return -1;
-    const int id = T.seq[(long long)row * T.seq_len + cursor];
-    if (id >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); return -1; }
+    int32_t* slot = const_cast<int32_t*>(T.seq) + (long long)row * T.seq_len + cursor;
+    const int id = *slot;
+    if (T.stream) {                                   // the ring ran dry: caught at the fetch, not a refill later
+        if (id == STREAM_CONSUMED) { raise_error(S, IRBPP_DEVERR_STREAM_DRY); return -1; }
+        *slot = STREAM_CONSUMED;
+    }
+    if (id >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); return -1; }
     return id < 0 ? -1 : id;
 }
 
@@ -144,6 +156,12 @@ __device__ __forceinline__ KernArgsPtr cold_args() {
     KernArgsPtr p = (KernArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(p));
     return p;
+}
+
+__device__ __forceinline__ void raise_error(const State& S, int bit) {
+    atomicOr(S.err, bit);
+    int32_t* mirror = cold_args()->io.err_out;
+    if (mirror != nullptr) atomicOr(mirror, bit);
 }
 
 __device__ __forceinline__ uint32_t div_magic_dev(int d) { return d >= 2 ? (uint32_t)(0x100000000ull / (uint64_t)d + 1ull) : 0u; }
@@ -1511,13 +1529,11 @@ static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
 static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
 constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
-#ifndef IRBPP_TRACE_CPW
-#define IRBPP_TRACE_CPW 64
-#endif
-constexpr int TRACE_CPW = IRBPP_TRACE_CPW;                            // candidates per wave (chunk), <= 64
-
-extern "C" __global__ void __launch_bounds__(64)
-irbpp_trace_kernel(const Params P, const State S, long long* prof) {
+// Candidates per wave (chunk) of the trace kernel: 64 at full width; 32 or 16 when the launch has too few candidates to
+// give every SIMD a wave of 64 (a wave lasts as long as its longest border: with fewer borders per wave the mean wave is
+// shorter and the idle SIMDs take the extra waves -- launch_group in irbpp_capi.hip picks by the number of bins).
+template <int TRACE_CPW>
+__device__ __forceinline__ void trace_body(const Params& P, const State& S, long long* prof) {
     constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
     __shared__ __attribute__((aligned(16))) uint8_t slots[TRACE_CPW * SLOT];            // one border per tracing lane
     __shared__ __attribute__((aligned(16))) uint16_t simg[TRACE_CPW * TRACE_ISTRIDE];   // one level image per tracing lane
@@ -1702,6 +1718,10 @@ irbpp_trace_kernel(const Params P, const State S, long long* prof) {
     }
 }
 
+extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel(const Params P, const State S, long long* prof) { trace_body<64>(P, S, prof); }
+extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c32(const Params P, const State S, long long* prof) { trace_body<32>(P, S, prof); }
+extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c16(const Params P, const State S, long long* prof) { trace_body<16>(P, S, prof); }
+
 // Split pipeline, after the trace kernel: approxPolyDP + find_convex_vetex of one round of borders per wave
 // (approx_convex_segmented on the 64 * TRACE_P contour points of a record); vertex bits go to the bins' rows in
 // global memory with one atomic OR each.  The rounds of the eight lists are numbered through like the chunks of
@@ -1798,7 +1818,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
     const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
-        if (tid == 0) atomicOr(S.err, IRBPP_DEVERR_BAD_BIN);
+        if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_BIN);
         return;
     }
     const long long t_begin = (long long)clock64();
@@ -1991,8 +2011,14 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
                 int nxt = st_next;                                    // generate_item (:325): prefetched for K == 1
                 if (nxt == -2) nxt = fetch_item(T, S, st_trow, cursor);
-                else if (nxt >= T.n_shapes) { atomicOr(S.err, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
-                else if (nxt < 0) nxt = -1;
+                else {
+                    if (T.stream) {                                   // the prefetched slot is consumed here (see fetch_item)
+                        if (nxt == STREAM_CONSUMED) raise_error(S, IRBPP_DEVERR_STREAM_DRY);
+                        else const_cast<int32_t*>(T.seq)[(long long)st_trow * T.seq_len + (int)((uint32_t)cursor % (uint32_t)T.seq_len)] = STREAM_CONSUMED;
+                    }
+                    if (nxt >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
+                    else if (nxt < 0) nxt = -1;
+                }
                 q[P.K - 1] = nxt;
                 ps->cursor = cursor + 1;
                 if (ka->io.reward) ka->io.reward[b] = reward;

@@ -91,9 +91,14 @@ def streams_for_args(args, num_envs: int, rank_offset: int = 0) -> List[ItemStre
 
 class StreamFeeder(object):
     """Host side of the item rings of a ``GpuPackingEnv(item_stream=1)``: row b of the environment's sequence table
-    is a ring of ``ring_len`` items that only bin b reads; every ``ring_len // (4 * bufferSize)`` steps the feeder
-    reads the bins' cursors and rewrites what they have consumed, so a bin never meets an item the stream has not
-    produced yet (it would raise here first)."""
+    is a ring of ``ring_len`` items that only bin b reads; every ``ring_len // (4 * bufferSize)`` ticks the feeder
+    reads the bins' cursors and rewrites what they have consumed.  A tick is anything that can cost a bin up to
+    ``bufferSize`` items: a step (one item, or a whole new queue when the step ends the episode), a reset, a
+    reset_specific -- ``GpuVecEnv`` ticks from all three.  Should a ring run dry all the same, the bin notices at the
+    fetch itself: consumed ring slots are poisoned by the kernel, reading one raises IRBPP_DEVERR_STREAM_DRY in the
+    step's error word (and ``refill`` raises when it sees a cursor beyond what it has delivered).
+    Grouped environments (``GroupedPackingEnv``): group g's sub-environment owns rows [g*per, (g+1)*per) of the table
+    and is fed on its own stream."""
 
     def __init__(self, streams: Sequence[ItemStream], ring_len: int = 4096, buffer_size: int = 1):
         self.streams = list(streams)
@@ -107,40 +112,50 @@ class StreamFeeder(object):
         self.every = max(1, self.ring_len // (4 * self.K))
         self.steps = 0
         self.env = None
+        self.parts = []
 
     def attach(self, env) -> None:
-        """``env``: the GpuPackingEnv that was created with ``sequences=self.initial, item_stream=1``."""
+        """``env``: the GpuPackingEnv (or GroupedPackingEnv) that was created with ``sequences=self.initial,
+        item_stream=1``."""
         import torch
         assert env.num_bins == self.n
         self.env = env
-        self._cur = torch.zeros((self.n,), dtype=torch.int32, device=env.device)
+        if hasattr(env, "groups"):                                           # (sub-environment, its rows, its stream)
+            self.parts = [(e, env.rows(g), env.streams[g]) for g, e in enumerate(env.groups)]
+        else:
+            self.parts = [(env, slice(0, self.n), None)]
+        self._cur = [torch.zeros((rows.stop - rows.start,), dtype=torch.int32, device=env.device) for _, rows, _ in self.parts]
 
     def tick(self, steps: int = 1) -> None:
-        """Call once per environment step (or get_action_candidates + step pair)."""
+        """Call once per environment step (or get_action_candidates + step pair), reset or reset_specific."""
         self.steps += steps
         if self.steps >= self.every:
             self.refill()
 
     def refill(self) -> None:
+        import contextlib
         import torch
-        env, L = self.env, self.ring_len
-        _lib.check(env.lib.irbpp_stream_cursors(env._h, C.c_void_p(self._cur.data_ptr()), 0, env._stream()), "irbpp_stream_cursors")
-        cur = self._cur.cpu().numpy().astype(np.int64)                       # synchronises
-        if (cur > self.written).any():
-            raise RuntimeError("an item ring ran dry: a bin consumed items the stream had not delivered (ring_len too small)")
-        count = (cur + L - self.written).astype(np.int32)                    # what each bin has consumed since the last refill
-        width = int(count.max())
+        L = self.ring_len
         self.steps = 0
-        if width <= 0:
-            return
-        ids = np.zeros((self.n, width), dtype=np.int32)
-        for b, s in enumerate(self.streams):
-            if count[b] > 0:
-                ids[b, :count[b]] = s.draw(int(count[b]))
-        first = (self.written % L).astype(np.int32)
-        dev = env.device
-        t_ids, t_first, t_count = (torch.from_numpy(a).to(dev) for a in (ids, first, count))
-        _lib.check(env.lib.irbpp_stream_write(env._h, C.c_void_p(t_ids.data_ptr()), C.c_void_p(t_first.data_ptr()),
-                                              C.c_void_p(t_count.data_ptr()), width, env._stream()), "irbpp_stream_write")
-        torch.cuda.current_stream(dev).synchronize()                         # the staging tensors may go now
-        self.written += count
+        for (env, rows, st), cur_dev in zip(self.parts, self._cur):
+            with (torch.cuda.stream(st) if st is not None else contextlib.nullcontext()):
+                _lib.check(env.lib.irbpp_stream_cursors(env._h, C.c_void_p(cur_dev.data_ptr()), 0, env._stream()), "irbpp_stream_cursors")
+                cur = cur_dev.cpu().numpy().astype(np.int64)                 # synchronises this part's stream
+                written = self.written[rows]
+                if (cur > written).any():
+                    raise RuntimeError("an item ring ran dry: a bin consumed items the stream had not delivered (ring_len too small)")
+                count = (cur + L - written).astype(np.int32)                 # what each bin has consumed since the last refill
+                width = int(count.max())
+                if width <= 0:
+                    continue
+                ids = np.zeros((len(count), width), dtype=np.int32)
+                for i, s in enumerate(self.streams[rows]):
+                    if count[i] > 0:
+                        ids[i, :count[i]] = s.draw(int(count[i]))
+                first = (written % L).astype(np.int32)
+                dev = env.device
+                t_ids, t_first, t_count = (torch.from_numpy(a).to(dev) for a in (ids, first, count))
+                _lib.check(env.lib.irbpp_stream_write(env._h, C.c_void_p(t_ids.data_ptr()), C.c_void_p(t_first.data_ptr()),
+                                                      C.c_void_p(t_count.data_ptr()), width, env._stream()), "irbpp_stream_write")
+                torch.cuda.current_stream(dev).synchronize()                 # the staging tensors may go now
+                self.written[rows] += count

@@ -92,10 +92,9 @@ class GpuPackingEnv(object):
         n = self.num_bins
         off_err = (34 * n + 3) & ~3
         self._out = torch.zeros((off_err + 4,), dtype=torch.uint8, device=self.device)
-        # two pinned host copies, used in turn: the arrays step_info_host returns are views of one of them and stay
-        # valid until the step after the next (the trainer is done with `infos` long before, trainer.py:167-186)
-        self._out_hosts = [torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True) for _ in range(2)]
-        self._out_turn = 0
+        # the pinned landing buffer of that copy; step_info_host hands out an owned copy of it (34 bytes per bin), like
+        # the fresh arrays ShmemVecEnv.step_wait builds every step (shmem_vec_env.py:76-81)
+        self._out_host = torch.empty((off_err + 4,), dtype=torch.uint8, pin_memory=True)
         self._out_f64 = self._out[:24 * n].view(torch.float64).view(3, n)           # reward, ratio, ep_reward
         self._out_i32 = self._out[24 * n:32 * n].view(torch.int32).view(2, n)       # counter, ep_len
         self._out_done = self._out[32 * n:33 * n]
@@ -288,14 +287,14 @@ class GpuPackingEnv(object):
 
     def step_info_host(self):
         """ONE pinned asynchronous D2H copy of the small per-step outputs + the device error word, then one
-        stream synchronisation -> dict of numpy arrays.  Raises if a kernel raised its error word."""
+        stream synchronisation -> dict of numpy arrays that belong to the caller (a copy of the pinned landing buffer:
+        a rollout may keep `done` / `infos` of step t for as long as it likes, as with the reference's fresh arrays).
+        Raises if a kernel raised its error word."""
         n = self.num_bins
         st = torch.cuda.current_stream(self.device)
-        host = self._out_hosts[self._out_turn]
-        self._out_turn ^= 1
-        host.copy_(self._out, non_blocking=True)
+        self._out_host.copy_(self._out, non_blocking=True)
         st.synchronize()
-        h = host.numpy()
+        h = self._out_host.numpy().copy()
         err = int(h[-4:].view(np.int32)[0])
         if err:
             raise _lib.IrbppError(f"device error flags={err}: " + _lib.load().irbpp_status_string(-4).decode())
@@ -341,7 +340,9 @@ class GroupedPackingEnv(object):
         self.device = torch.device(device)
         self.num_bins, self.num_groups, self.per = int(num_bins), int(num_groups), num_bins // num_groups
         total = num_bins if global_bins is None else global_bins
-        self.groups = [GpuPackingEnv(shapes, sequences, self.per, device=device, global_offset=global_offset + g * self.per,
+        # item streams (item_stream=1): row b of the table is bin b's own ring, so group g gets rows [g*per, (g+1)*per)
+        seq_of = (lambda g: sequences[g * self.per:(g + 1) * self.per]) if kw.get("item_stream") else (lambda g: sequences)
+        self.groups = [GpuPackingEnv(shapes, seq_of(g), self.per, device=device, global_offset=global_offset + g * self.per,
                                      global_bins=total, **kw) for g in range(num_groups)]
         # one group: the caller's current stream; several: a stream each
         self.streams = [torch.cuda.Stream(device=self.device) for _ in range(num_groups)] if num_groups > 1 \
@@ -506,12 +507,15 @@ class GpuVecEnv(object):
         self.tstart = time.time()
         self.feeder = feeder
         if feeder is not None:
-            if self.num_groups > 1:
-                raise ValueError("item streams are fed to a single-group environment")
-            feeder.attach(self.env)
-        # persistent action buffers: pinned staging for host actions (no pageable bounce), one device tensor
-        self._act_host = torch.empty((num_envs,), dtype=torch.int32, pin_memory=True)
-        self._act_dev = torch.empty((num_envs,), dtype=torch.int32, device=self.device)
+            feeder.attach(self.env)                                          # one part per group, each fed on its group's stream
+        # persistent action buffers: pinned staging for host actions (no pageable bounce) and one device tensor, a pair
+        # for step() and a pair for get_action_candidates() -- the order actions may still be read by the candidate
+        # kernels (group streams, no synchronisation with candidates_on_device) when step() stages its own
+        self._staging = {}
+        for kind in ("step", "cands"):
+            self._staging[kind] = dict(host=torch.empty((num_envs,), dtype=torch.int32, pin_memory=True),
+                                       dev=torch.empty((num_envs,), dtype=torch.int32, device=self.device), busy=[])
+        self._act_host, self._act_dev = self._staging["step"]["host"], self._staging["step"]["dev"]
         self._ring, self._loc_ring, self._turn, self._loc_turn = [], [], 0, 0
         for _ in range(max(0, int(obs_ring))):
             self._ring.append(self._new_buffer(self.obs_len, register=self.env.K == 1))
@@ -537,7 +541,25 @@ class GpuVecEnv(object):
         self._turn = (self._turn + 1) % len(self._ring)
         return t
 
-    def _actions_to_device(self, actions) -> torch.Tensor:
+    def _staging_idle(self, kind: str) -> dict:
+        """The staging pair of `kind`, once nothing launched earlier still reads it: the previous H2D copy out of the
+        pinned buffer and the kernels (on whatever streams) that consumed the device tensor have recorded events."""
+        sg = self._staging[kind]
+        for ev in sg["busy"]:
+            ev.synchronize()                                                # complete long ago in a stepping loop
+        sg["busy"] = []
+        return sg
+
+    def _staging_release(self, kind: str) -> None:
+        """Call after the consumers of the staging pair have been launched: one event per stream that reads it."""
+        streams = self.env.streams if self.num_groups > 1 else [torch.cuda.current_stream(self.device)]
+        sg = self._staging[kind]
+        for st in streams:
+            ev = torch.cuda.Event()
+            ev.record(st)
+            sg["busy"].append(ev)
+
+    def _actions_to_device(self, actions, kind: str = "step") -> torch.Tensor:
         """int32[N] on the device, in flight on the current stream.  Host actions go through the pinned staging buffer
         (one asynchronous H2D); a device tensor is converted in place of a copy when it already is int32."""
         if isinstance(actions, torch.Tensor) and actions.is_cuda:
@@ -545,19 +567,33 @@ class GpuVecEnv(object):
             assert a.numel() == self.num_envs
             if a.dtype == torch.int32 and a.is_contiguous():
                 return a
-            self._act_dev.copy_(a)
-            return self._act_dev
+            sg = self._staging_idle(kind)
+            sg["dev"].copy_(a)
+            return sg["dev"]
         a = actions.reshape(-1) if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions).reshape(-1))
         assert a.numel() == self.num_envs
-        self._act_host.copy_(a)                                              # dtype conversion on the host
-        self._act_dev.copy_(self._act_host, non_blocking=True)
-        return self._act_dev
+        sg = self._staging_idle(kind)
+        sg["host"].copy_(a)                                                  # dtype conversion on the host
+        sg["dev"].copy_(sg["host"], non_blocking=True)
+        return sg["dev"]
+
+    def _group_staging(self, group: int) -> dict:
+        """Per-group pinned + device staging of step_async(group=g) (idle: step_wait(group=g) synchronised its stream)."""
+        if not hasattr(self, "_gstaging"):
+            self._gstaging = {}
+        if group not in self._gstaging:
+            per = self.env.per
+            self._gstaging[group] = dict(host=torch.empty((per,), dtype=torch.int32, pin_memory=True),
+                                         dev=torch.empty((per,), dtype=torch.int32, device=self.device))
+        return self._gstaging[group]
 
     def reset(self) -> torch.Tensor:
         if self.waiting_step:
             self.step_wait()
         self.tstart = time.time()
         out = self._next_obs()
+        if self.feeder is not None:
+            self.feeder.tick()                                               # a reset draws a whole new queue per bin
         if out is None:
             return self.env.reset()
         if self.num_groups > 1:
@@ -583,20 +619,21 @@ class GpuVecEnv(object):
             else:                                                           # this group's slice of the staging buffers
                 a = actions.reshape(-1) if isinstance(actions, torch.Tensor) else torch.from_numpy(np.asarray(actions).reshape(-1))
                 rows = self.env.rows(group)
-                self._act_host[rows].copy_(a)
-                self._act_dev[rows].copy_(self._act_host[rows], non_blocking=True)
-                a = self._act_dev[rows]
+                sg = self._group_staging(group)
+                sg["host"].copy_(a)
+                sg["dev"].copy_(sg["host"], non_blocking=True)
+                a = sg["dev"]
             assert a.numel() == per
             # the group's stream waits for whatever produced `a` on the current stream, and the allocator learns that
             # `a` (possibly a temporary of the caller) is read there
             obs, _, _ = self.env.step_group(group, a)
             self._group_pending[group] = obs
-            return
+            return                                                          # (step_wait(group) synchronises the group's stream)
         if self.waiting_step:
             raise RuntimeError("already running an async step")          # vec_env.py:7-16
         res = self.env.step(self._actions_to_device(actions), obs_out=self._next_obs())
         self._pending = res if isinstance(res, torch.Tensor) else res[0]
-        self.waiting_step = True
+        self.waiting_step = True                                            # (step_wait synchronises: the staging pair is idle after it)
 
     def step_wait(self, group: Optional[int] = None):
         if group is not None:
@@ -606,6 +643,8 @@ class GpuVecEnv(object):
             with torch.cuda.stream(self.env.streams[group]):
                 h = self.env.groups[group].step_info_host()
             self._group_pending[group] = None
+            if self.feeder is not None:
+                self.feeder.tick()          # (conservative: a caller may step one group more often than the others)
             reward = torch.from_numpy(h["reward"]).unsqueeze(dim=1).float()
             return obs, reward, h["done"], _Infos(h, round(time.time() - self.tstart, 6))
         if not self.waiting_step:
@@ -638,7 +677,8 @@ class GpuVecEnv(object):
         if self._loc_ring:
             out = self._loc_ring[self._loc_turn]
             self._loc_turn = (self._loc_turn + 1) % len(self._loc_ring)
-        loc = self.env.get_action_candidates(self._actions_to_device(order_actions), obs_out=out)
+        loc = self.env.get_action_candidates(self._actions_to_device(order_actions, "cands"), obs_out=out)
+        self._staging_release("cands")
         if self.candidates_on_device:
             return loc
         if self.num_groups > 1:
@@ -657,6 +697,8 @@ class GpuVecEnv(object):
         idx = np.asarray(list(indexs), dtype=np.int32).reshape(-1)
         if len(np.unique(idx)) != len(idx) or (len(idx) and (idx.min() < 0 or idx.max() >= self.num_envs)):
             raise ValueError("reset_specific needs distinct env indices in [0, num_envs)")
+        if self.feeder is not None:
+            self.feeder.tick()
         obs = self.env.reset_bins(torch.from_numpy(idx).to(self.device))
         for e, _ in self._envs_and_rows():
             e.invalidate_obs_buffers()
@@ -705,8 +747,10 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
         feeder = itemgen.StreamFeeder(itemgen.streams_for_args(args, args.num_processes),
                                       ring_len=int(getattr(args, "item_ring", 4096)), buffer_size=args.bufferSize)
         sequences, kw["item_stream"] = feeder.initial, 1
+    # (args.num_groups is not a reference argument: > 1 steps the envs as that many independent groups on their own HIP
+    # streams, item streams included -- GroupedPackingEnv)
     envs = GpuVecEnv(shapes, sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
-                     feeder=feeder, **kw)
+                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 1)), **kw)
     return envs, [envs.observation_space, envs.action_space], envs.obs_len
 
 

@@ -6,7 +6,7 @@ Run from the repo root (only where /root/reference exists -- never on the GPU bo
     python tests/golden/make_golden.py
 
 What executes from /root/reference, unmodified:
-    environment/physics0/space.py     Space.__init__, reset, get_possible_position
+    environment/physics0/space.py     Space.__init__, reset, get_possible_position, get_heuristic_action
     environment/physics0/cvTools.py   find_out_contour, find_convex_vetex, convexHulls,
                                       getConvexHullActions
     environment/physics0/IRcreator.py ItemCreator, LoadItemCreator
@@ -466,6 +466,46 @@ def random_creator_golden(n_items=400):
     return out
 
 
+HEUR_METHODS = ("MINZ", "DBLF", "FIRSTFIT", "HM")
+
+
+def heuristic_cases(steps=22):
+    """The reference's own ``Space.get_heuristic_action`` (space.py:162-218) on the states of two online episodes
+    played by the reference's PackingGame under the scripted MINZ policy: every method (MINZ, DBLF, FIRSTFIT, HM) x
+    every flip (dirIdx 0..3) per state.  A consumer replays the same episodes (same shapes, sequences, actions) and
+    asks its own scorer at every state.  The RANDOM branch (space.py:219-226) is recorded as what it is: it hands
+    ``np.where``'s tuple to ``np.random.choice``, which raises for every input."""
+    out = {}
+    for tag, shapes, seq_seed in (("general", synthetic.general_shapes(n_shapes=16, n_rot=4, seed=21), 4),
+                                  ("blockout", synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0), 5)):
+        seqs = synthetic.make_sequences(shapes.n_shapes, 16, 80, seed=seq_seed)
+        env = make_reference_env(shapes, seqs)
+        obs = env.reset()
+        heur, items, acts, nvalid, hms, dones = [], [], [], [], [], []
+        for _ in range(steps):
+            sp = env.space
+            res = np.zeros((len(HEUR_METHODS), 4, 3), dtype=np.int64)
+            for mi, method in enumerate(HEUR_METHODS):
+                for d in range(4):
+                    res[mi, d] = sp.get_heuristic_action(d, method, env.next_item_ID, env.shapeDict[env.next_item_ID])
+            heur.append(res); items.append(env.next_item_ID); nvalid.append(int(sp.naiveMask.sum()))
+            hms.append(sp.heightmapC.copy())
+            a = minz_action(obs, 500)
+            obs, r, d, info = env.step(a)
+            acts.append(a); dones.append(d)
+            if d:
+                obs = env.reset()
+        random_raises = False
+        try:
+            env.space.get_heuristic_action(0, "RANDOM", env.next_item_ID, env.shapeDict[env.next_item_ID])
+        except ValueError:
+            random_raises = True
+        out.update({tag + "_seq": seqs, tag + "_heur": np.array(heur), tag + "_item": np.array(items),
+                    tag + "_act": np.array(acts), tag + "_nvalid": np.array(nvalid), tag + "_hm": np.array(hms),
+                    tag + "_done": np.array(dones), tag + "_random_raises": np.array(random_raises)})
+    return out
+
+
 def main():
     cube = synthetic.cube_shapes()
     blk = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
@@ -482,6 +522,7 @@ def main():
     np.savez_compressed(os.path.join(OUT, "tools_test.npz"), **tools_test_golden())
     np.savez_compressed(os.path.join(OUT, "tools_test_hier.npz"), **tools_test_hier_golden())
     np.savez_compressed(os.path.join(OUT, "random_creators.npz"), **random_creator_golden())
+    np.savez_compressed(os.path.join(OUT, "heuristic_cases.npz"), **heuristic_cases())
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

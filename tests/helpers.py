@@ -21,6 +21,10 @@ def golden_scenario(name):
         sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
     elif name == "online_general":
         sh = synthetic.general_shapes(n_shapes=16, n_rot=8, seed=1)
+    elif name == "heuristic_general":
+        sh = synthetic.general_shapes(n_shapes=16, n_rot=4, seed=21)
+    elif name == "heuristic_blockout":
+        sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
     else:
         raise KeyError(name)
     return sh

@@ -165,3 +165,29 @@ def test_tools_test_hierachical_trajectories_match_reference(golden_dir):
         lens.append(steps)
     assert row == len(g["ids"])
     assert abs(np.mean(rsums) - float(g["avg_reward"])) < 1e-12 and np.mean(lens) == float(g["avg_length"])
+
+
+HEUR_METHODS = ("MINZ", "DBLF", "FIRSTFIT", "HM")
+
+
+@pytest.mark.parametrize("tag", ["general", "blockout"])
+def test_heuristic_actions_match_reference(golden_dir, tag):
+    """Space.get_heuristic_action (space.py:162-218) as the reference's own Space computed it on the states of an
+    episode its own PackingGame played (tests/golden/make_golden.py:heuristic_cases): 4 methods x 4 flips per state."""
+    g = _load(golden_dir, "heuristic_cases")
+    env = PackingGame(golden_scenario("heuristic_" + tag), g[tag + "_seq"], selectedAction=S, bufferSize=1)
+    obs = env.reset()
+    for t in range(len(g[tag + "_act"])):
+        assert env.next_item_ID == g[tag + "_item"][t] and int(env.space.naiveMask.sum()) == g[tag + "_nvalid"][t]
+        np.testing.assert_array_equal(env.space.heightmapC, g[tag + "_hm"][t])
+        for mi, method in enumerate(HEUR_METHODS):
+            for d in range(4):
+                got = env.space.get_heuristic_action(method, env.next_item_ID, d)
+                assert tuple(int(v) for v in got) == tuple(g[tag + "_heur"][t, mi, d]), (t, method, d)
+        a = minz_action(obs, S)
+        assert a == g[tag + "_act"][t]
+        obs, _, done, _ = env.step(a)
+        assert done == g[tag + "_done"][t]
+        if done:
+            obs = env.reset()
+    assert bool(g[tag + "_random_raises"])       # the reference's RANDOM branch raises for every input: nothing to match

@@ -50,8 +50,9 @@ def test_hierarchical_evaluation_matches_the_reference_golden(golden_dir, tmp_pa
     assert abs(out["avg_reward"] - float(g["avg_reward"])) < 1e-9 and out["avg_length"] == float(g["avg_length"])
 
 
-@pytest.mark.parametrize("k,sample", [(1, "instance"), (3, "instance"), (1, "category"), (2, "pose")])
-def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample):
+@pytest.mark.parametrize("k,sample,groups", [(1, "instance", 1), (3, "instance", 1), (1, "category", 1), (2, "pose", 1),
+                                             (1, "instance", 3), (3, "category", 2)])
+def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample, groups):
     """make_vec_envs(args) with nothing but the reference's namespace (no args.sequences): every environment draws its
     items like the reference's worker of that rank (RandomInstanceCreator / RandomCateCreator / RandomItemCreator on
     np.random seeded seed + rank; IRcreator.py:26-72, envs.py:41).  The oracle side restates the creators on numpy's
@@ -68,8 +69,9 @@ def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample):
     args = types.SimpleNamespace(
         num_processes=n, device=0, seed=seed, shapes=sh, dicPath=dic, dataSample=sample, resolutionA=0.02,
         resolutionH=0.01, resolutionZ=0.01, bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S,
-        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=64)
+        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=64, num_groups=groups)
     envs, spaces, obs_len = make_vec_envs(args, "./logs/runinfo", True)
+    assert envs.num_groups == groups              # grouped stepping: group g is fed rows [g*per, (g+1)*per) on its own stream
     envs.candidates_on_device = True
     creators = [RandomStreamItemCreator(seed + i, dic, sample, n_items=20) for i in range(n)]
     oenv = OracleVecEnv(n, sh, None, item_creators=creators, bufferSize=k)

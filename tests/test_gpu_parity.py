@@ -296,6 +296,74 @@ def test_full_size_properties_and_sharding_invariance(workload, n, parts, steps)
         e.close()
 
 
+@pytest.mark.parametrize("n,parts,steps", [(1024, 2, 110), (8192, 4, 110)])
+def test_full_size_hierarchical_properties_and_sharding_invariance(n, parts, steps):
+    """BASELINE config 4 (BlockOut buffered k = 10) at its per-GPU width (1024 bins = 8192 / 8) and at its full 8192 bins:
+    every placement through get_action_candidates + step (binPhy.py:161-169, 248-337) with order actions that exercise
+    every buffer slot, the C oracle on 64 sampled bins for both observations, done and reward, the same bins as `parts`
+    shards, and the size-independent properties of the online full-size test."""
+    from bench import make_workload
+    from oracle.c_oracle import COracleVecEnv
+    sh, seqs, kw = make_workload("blockout_k10")
+    k = kw["bufferSize"]
+    env = GpuPackingEnv(sh, seqs, n, device=DEV, **kw)
+    shards = [GpuPackingEnv(sh, seqs, n // parts, device=DEV, global_offset=o, global_bins=n, **kw)
+              for o in range(0, n, n // parts)]
+    per = n // parts
+    obs = env.reset()
+    sobs = [h.reset() for h in shards]
+    assert torch.equal(torch.cat(sobs), obs)
+    starts = [0, n // 3, n // 2 - 8, n - 16]
+    sample = np.concatenate([np.arange(o, o + 16) for o in starts])
+    cenvs = [COracleVecEnv(16, sh, seqs, global_offset=o, global_num=n, **kw) for o in starts]
+    np.testing.assert_array_equal(obs[sample].cpu().numpy(), _f32(np.concatenate([c.reset() for c in cenvs])))
+    vol = torch.from_numpy(sh.volumes).to(DEV)
+    prev_hm = env.get_heightmaps().clone()
+    placed_vol = torch.zeros(n, dtype=torch.float64, device=DEV)
+    gbin = torch.arange(n, device=DEV)
+    ndone = 0
+    for t in range(steps):
+        order = ((gbin * 3 + t) % k if t % 2 else torch.zeros_like(gbin)).to(torch.int32)
+        assert torch.equal(obs[:, k:], env.get_heightmaps().reshape(n, -1).float())        # order obs = [k ids | heightmap]
+        item = obs.gather(1, order.to(torch.int64)[:, None])[:, 0].to(torch.int64)         # the chosen buffer slot's item
+        loc = env.get_action_candidates(order)
+        assert torch.equal(loc[:, 5 * S], item.float())                                    # next_item_vec[0] (binPhy.py:191)
+        sorder = order[sample].cpu().numpy()
+        cloc = [c.get_action_candidates(sorder[16 * j:16 * j + 16]) for j, c in enumerate(cenvs)]
+        np.testing.assert_array_equal(loc[sample].cpu().numpy(), _f32(np.concatenate(cloc)),
+                                      err_msg=f"sampled location observations differ from the C oracle at step {t}")
+        act = env.policy_minz(loc)
+        obs, rew, done = env.step(act)
+        sact = act[sample].cpu().numpy()
+        cres = [c.step(sact[16 * j:16 * j + 16]) for j, c in enumerate(cenvs)]
+        np.testing.assert_array_equal(obs[sample].cpu().numpy(), _f32(np.concatenate([r[0] for r in cres])),
+                                      err_msg=f"sampled bins differ from the C oracle at step {t}")
+        np.testing.assert_array_equal(done[sample].cpu().numpy().astype(bool), np.concatenate([r[2] for r in cres]))
+        np.testing.assert_array_equal(rew[sample].cpu().numpy().astype(np.float32),
+                                      np.concatenate([r[1] for r in cres]).astype(np.float32))
+        slocs = [h.get_action_candidates(order[j * per:(j + 1) * per]) for j, h in enumerate(shards)]
+        assert torch.equal(torch.cat(slocs), loc), "location observations depend on how bins are sharded"
+        sobs = [h.step(h.policy_minz(lo))[0] for h, lo in zip(shards, slocs)]
+        assert torch.equal(torch.cat(sobs), obs), "result depends on how bins are sharded"
+        hm = env.get_heightmaps()
+        d = done.bool()
+        assert bool((hm[d] == 0).all())
+        assert bool((hm[~d] >= prev_hm[~d]).all())
+        assert float(hm.max()) <= 0.30 + 1e-9
+        exp_rew = torch.where(d, torch.zeros_like(rew), vol[item.clamp(min=0)] / 0.03072 * 10)
+        assert torch.allclose(rew, exp_rew, atol=1e-12, rtol=0)
+        placed_vol = torch.where(d, torch.zeros_like(placed_vol), placed_vol + vol[item.clamp(min=0)])
+        assert bool((placed_vol <= 0.03072 + 1e-12).all())
+        prev_hm = hm.clone()
+        ndone += int(d.sum())
+    tot = env.episode_totals().cpu().numpy()
+    assert ndone > n // 4 and tot[0] == ndone
+    env.check_device_error()
+    for e in [env] + shards:
+        e.check_device_error()
+        e.close()
+
+
 def test_more_than_S_candidates_sorted_selection():
     """Random per-cell heights make almost every valid cell its own level component -> more than
     S=500 candidates: exercises the `np.argsort(candidates[:,3])[:S]` branch (binPhy.py:209-212).
@@ -375,6 +443,30 @@ def test_heuristic_actions_match_oracle():
         gobs, _, _, _ = genv.step(act)
         oobs, _, _, _ = oenv.step(act)
         np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs))
+    genv.close()
+
+
+@pytest.mark.parametrize("tag", ["general", "blockout"])
+def test_heuristic_actions_match_reference_golden(golden_dir, tag):
+    """irbpp_heuristic_action against what the reference's own Space.get_heuristic_action (space.py:162-218) returned
+    on the states of an episode the reference's PackingGame played (heuristic_cases.npz): the same episode is replayed
+    here (trajectory 1, the recorded actions) and every method x flip is asked at every state, the states with no
+    valid cell (all scores 1e6 -> index 0) included."""
+    g = np.load(os.path.join(golden_dir, "heuristic_cases.npz"))
+    sh = golden_scenario("heuristic_" + tag)
+    genv = GpuVecEnv(sh, g[tag + "_seq"], 1, device=DEV)
+    gobs = genv.reset()
+    for t in range(len(g[tag + "_act"])):
+        assert int(gobs[0, 5 * S].item()) == g[tag + "_item"][t]
+        np.testing.assert_array_equal(genv.env.get_heightmaps()[0].cpu().numpy(), g[tag + "_hm"][t])
+        for mi, method in enumerate(("MINZ", "DBLF", "FIRSTFIT", "HM")):
+            for d in range(4):
+                got = genv.env.heuristic_action(method, d).cpu().numpy()[0]
+                assert tuple(int(v) for v in got) == tuple(g[tag + "_heur"][t, mi, d]), (t, method, d)
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        assert int(act[0]) == g[tag + "_act"][t]
+        gobs, _, gdone, _ = genv.step(act)
+        assert bool(gdone[0]) == bool(g[tag + "_done"][t])
     genv.close()
 
 

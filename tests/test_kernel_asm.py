@@ -1,0 +1,48 @@
+"""The shipped code object obeys the scalar-load rule the generic overlap loop relies on (irbpp_amd/asmcheck.py):
+no use of a scalar load's destination before lgkmcnt(0) -- checked on the disassembly of the in-tree library, so it
+holds for the hipcc that built it; plus a self-test of the checker on an injected hazard."""
+import os
+
+import pytest
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd import asmcheck, build
+
+
+@pytest.fixture(scope="module")
+def disassembly():
+    path = build.build(force=False)
+    assert os.path.exists(path)
+    return asmcheck.disassemble(path)
+
+
+def _problems(text):
+    out = []
+    for name, ins in asmcheck.parse(text).items():
+        out += asmcheck.check_function(name, ins)[1]
+    return out
+
+
+def test_no_use_of_scalar_load_destinations_before_the_wait(disassembly):
+    funcs = asmcheck.parse(disassembly)
+    for kernel in ("irbpp_env_kernel", "irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide",
+                   "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel", "irbpp_heuristic_kernel"):
+        assert kernel in funcs and len(funcs[kernel]) > 100
+    # the pipelined 64-byte list loads are where they are expected (three walk depths x two address forms x three quads)
+    for kernel in ("irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide"):
+        n16 = sum(1 for _, m, o, _ in funcs[kernel] if m == "s_load_dwordx16" and o.rstrip().endswith("0x0"))
+        assert n16 >= 6, (kernel, n16)
+    assert _problems(disassembly) == []
+
+
+def test_checker_sees_an_injected_hazard(disassembly):
+    out, done = [], 0
+    for line in disassembly.splitlines():
+        out.append(line)
+        if done == 0 and "s_load_dwordx16 s[" in line and "0x0 " in line:
+            first = int(line.split("s[")[1].split(":")[0])
+            out.append(f"\ts_mov_b32 s100, s{first + 3}                                   // 000000000004: BE800000")
+            done = 1
+    assert done == 1
+    probs = _problems("\n".join(out))
+    assert len(probs) == 1 and "destination touched before lgkmcnt(0)" in probs[0]
