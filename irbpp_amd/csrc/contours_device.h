@@ -216,6 +216,134 @@ __device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, in
     return r == TRACE_RUNNING ? -1 : r;
 }
 
+// ---------------------------------------------------------------------------------------
+// The same walk with a short iteration (the trace kernel's form; trace_border above stays as the plain statement
+// of it and serves the in-workgroup contour stage of the hull kernel and the sequential redo).  What is different:
+//   * a pixel is ONE number, pos = x | y << 4 -- the byte a contour point is stored as -- and a move adds a per-direction
+//     delta; all per-direction constants (move delta, frame, run direction, side line) come out of 8-entry byte tables
+//     held in two SGPRs each and read with one v_perm_b32 (the direction code carries 0x0c in its upper bytes, which
+//     makes v_perm return the table byte zero-extended);
+//   * the level image lies in LDS as two FRAMES of 18 dwords: rows (y = -1 .. 16) and columns (x = -1 .. 16), every
+//     line shifted left by one bit, a zero line before and behind: the three lines around a pixel are three reads at
+//     one address (no edge cases), and bits p-1, p, p+1 of a line are bits p .. p+2 of the stored word (no shifts by -1);
+//   * the contour point is stored unconditionally at index min(n, cap) and n advances only when the direction changed
+//     (CHAIN_APPROX_SIMPLE): a point that is not one gets overwritten by the next store;
+//   * one loop exit: the three ways a step can end the walk are folded into its result by selects, so the lanes of a
+//     wave -- which walk different borders in lockstep -- run straight-line code.
+// ~85 instructions per step where trace_step compiles to ~160 (disassembly of the trace kernel).
+// ---------------------------------------------------------------------------------------
+constexpr int FRAME_LINES = 18, FRAME_COLS = FRAME_LINES, FRAME_WORDS = 2 * FRAME_LINES;
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t byte_table(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
+#else
+__device__ inline uint32_t byte_table(uint32_t hi, uint32_t lo, uint32_t sel) {       // v_perm_b32 as far as it is used here (host passes)
+    const unsigned long long t = ((unsigned long long)hi << 32) | lo;
+    uint32_t out = 0;
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t c = (sel >> (8 * k)) & 255u;
+        out |= (c < 8 ? (uint32_t)((t >> (8 * c)) & 255u) : (c == 12 ? 0u : 255u)) << (8 * k);
+    }
+    return out;
+}
+#endif
+// frames of one level image from its row words r[y] (bit x = pixel (x, y)) and column words c[x] (bit y)
+__device__ __forceinline__ void frames_store(uint32_t* fr, const uint32_t (&r)[16], const uint32_t (&c)[16]) {
+    fr[0] = 0u; fr[FRAME_LINES - 1] = 0u; fr[FRAME_COLS] = 0u; fr[FRAME_WORDS - 1] = 0u;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { fr[1 + k] = r[k] << 1; fr[FRAME_COLS + 1 + k] = c[k] << 1; }
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }   // v_bfe_u32
+// bit `bit` of v as a mask, 0 or ~0 (v_bfe_i32; as asm because the compiler otherwise rewrites mask-and-select as and + compare + cndmask)
+template <int BIT>
+__device__ __forceinline__ uint32_t bit_flag(uint32_t v) { uint32_t m; asm("v_bfe_i32 %0, %1, %2, 1" : "=v"(m) : "v"(v), "n"(BIT)); return m; }
+#else
+__device__ inline uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) { return (v >> (off & 31u)) & ((1u << width) - 1u); }
+template <int BIT>
+__device__ inline uint32_t bit_flag(uint32_t v) { return ((v >> BIT) & 1u) ? ~0u : 0u; }
+#endif
+__device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t if_set, uint32_t if_clear) { return (if_set & mask) | (if_clear & ~mask); }   // v_bfi_b32
+// 8-bit neighbour mask (bit s = neighbour in direction s, in the frame's own orientation) from the three stored lines
+// around a pixel at position p of the middle line: bits p .. p+2 of a stored line are pixels p-1, p, p+1
+__device__ __forceinline__ uint32_t nb_frame(uint32_t a, uint32_t b, uint32_t c, int p) {
+    constexpr uint32_t SEL = 0x0c0c0c00u;
+    const uint32_t ra = byte_table(0x0e060a02u, 0x0c040800u, ((a >> p) & 7u) | SEL);      // NE, N, NW (bits 1..3): the line before, reversed
+    const uint32_t rb = byte_table(0x11011101u, 0x10001000u, ((b >> p) & 7u) | SEL);      // E (bit 0) = pixel p+1, W (bit 4) = pixel p-1
+    return (bit_field(c, (uint32_t)p, 3) << 5) | ra | rb;                                  // SW, S, SE (bits 5..7): the line after
+}
+// All lanes of the wave call it together; `active` says whether the lane has a border to follow (an inactive lane
+// passes x0 = y0 = 0 and pointers into memory of its own: it computes along, harmlessly).  The loop is uniform -- it
+// runs until no lane of the wave is walking any more -- and its body is straight-line code for every lane: a lane that
+// has closed its border keeps computing on whatever its registers hold (every address it forms stays inside its own
+// frames and its own slot, and n no longer advances), which costs nothing in lockstep and saves the execution-mask
+// bookkeeping of a per-lane exit (two dozen scalar instructions per step in the compiler's rendering of it).
+// Returns the number of points, 0 if (x0, y0) does not start an outer border, -1 if the iteration guard tripped.
+__device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active = true) {
+    // per-direction tables, entry s in byte s: pos delta + 17; flags (1 axis move, 2 vertical frame, 4 towards higher
+    // bits, 8 side line = the line after); bit offset of the line index in pos (4 rows / 0 columns); frame offset in bytes
+    constexpr uint32_t DELTA_LO = 0x00010212u, DELTA_HI = 0x22212010u;      // E +1, NE -15, N -16, NW -17 | W -1, SW +15, S +16, SE +17
+    constexpr uint32_t FLAG_LO = 0x000b000du, FLAG_HI = 0x00070001u;        // E 13, N 11 | W 1, S 7
+    constexpr uint32_t LSH_LO = 0x04000404u, LSH_HI = 0x04000404u;          // N and S index columns (x = pos & 15), all others rows
+    constexpr uint32_t FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16, FOFF_HI = FOFF_LO;   // N and S read the column frame (byte offset)
+    constexpr uint32_t SEL = 0x0c0c0c00u;
+    const int pos0 = x0 | (y0 << 4);
+    // first neighbour: clockwise search 3, 2, 1, 0, 7, 6, 5 (the west pixel is background)
+    const uint32_t nb0 = nb_frame(fr[y0], fr[y0 + 1], fr[y0 + 2], x0);
+    const uint32_t rot = ((nb0 << 4) | (nb0 >> 4)) & 0xFFu;                // direction 3 -> bit 7
+    const bool isolated = rot == 0u;
+    const int s_first = (3 - (7 - (31 - __builtin_clz(rot | (isolated ? 1u : 0u))))) & 7;
+    const int pos1 = pos0 + (int)byte_table(DELTA_HI, DELTA_LO, (uint32_t)s_first | SEL) - 17;
+    const uint32_t s_close = (uint32_t)(s_first ^ 4) | SEL;                // a run that ends on the start, moving against the first step
+    int pos = pos0, n = 0, result = 0;
+    uint32_t nb16 = nb0 | (nb0 << 8), k2 = (uint32_t)(s_first + 1), prev = (uint32_t)(s_first ^ 4) | SEL;
+    uint32_t run = (active && !isolated) ? 1u : 0u;                        // (an integer, not a flag: no lane mask is carried around the loop)
+    int guard = 0;
+    for (; guard < 4096; ++guard) {
+        if (__ballot(run != 0u) == 0ull) break;                            // uniform: nobody walks any more
+        if (run != 0u) {
+        IRBPP_TRACE_ITER();
+        // counter-clockwise search k2, k2 + 1, ... for the next border pixel (nb != 0: the pixel we came from)
+        k2 &= 7u;
+        const uint32_t s2 = ((k2 + (uint32_t)__builtin_ctz(nb16 >> k2)) & 7u) | SEL;
+        pts[n < cap ? n : cap] = (uint8_t)pos;                            // CHAIN_APPROX_SIMPLE: kept iff the direction changed
+        n += s2 != prev ? 1 : 0;
+        prev = s2;
+        int pos4 = pos + (int)byte_table(DELTA_HI, DELTA_LO, s2) - 17;
+        const bool closed1 = pos4 == pos0 && pos == pos1;
+        // standing on pos4, arrived by s2: the three lines around it in the frame of the move
+        const uint32_t flags = byte_table(FLAG_HI, FLAG_LO, s2);
+        const uint32_t lsh = byte_table(LSH_HI, LSH_LO, s2), psh = lsh ^ 4u;
+        const uint32_t li = bit_field((uint32_t)pos4, lsh, 4);
+        int p = (int)bit_field((uint32_t)pos4, psh, 4);
+        const uint32_t* ln = (const uint32_t*)((const char*)fr + ((li << 2) + byte_table(FOFF_HI, FOFF_LO, s2)));
+        const uint32_t wa = ln[0], wm = ln[1], wb = ln[2];
+        {
+            // straight run (see run_forward / run_backward): E looks at the row below, W at the row above, S at the
+            // column to the left, N at the column to the right.  Stored lines are shifted by one: bit q + 1 = pixel q.
+            const uint32_t side = bit_select(bit_flag<3>(flags), wb, wa);
+            const uint32_t blocked = side | (side << 1) | (side >> 1);
+            const uint32_t lf = (uint32_t)__builtin_ctz(~(((wm >> 1) & ~blocked) >> (p + 1)));
+            const uint32_t lb = (uint32_t)__builtin_clz(~(((wm << 1) & ~blocked) << (30 - p)));
+            const int dp = (int)(bit_select(bit_flag<2>(flags), lf, 0u - lb) & bit_flag<0>(flags));
+            p += dp;
+            pos4 += dp * (1 << psh);
+        }
+        const bool closed2 = pos4 == pos0 && s2 == s_close;
+        const uint32_t nbl = nb_frame(wa, wm, wb, p);
+        const uint32_t nb = bit_select(bit_flag<1>(flags), nb_untranspose(nbl), nbl);
+        const bool ends = closed1 || closed2;
+        result = ends ? n : result;
+        run = (ends || pos4 < pos0) ? 0u : 1u;                             // run interiors lie between their end points in raster order
+        pos = pos4;
+        k2 = s2 + 5u;
+        nb16 = nb | (nb << 8);
+        }
+    }
+    if (guard >= 4096) return -1;                                          // (uniform)
+    if (active && isolated && cap > 0) pts[0] = (uint8_t)pos0;
+    return !active ? 0 : (isolated ? 1 : result);
+}
+
 #define IRBPP_PX(p) ((int)((p) & 15))
 #define IRBPP_PY(p) ((int)((p) >> 4))
 

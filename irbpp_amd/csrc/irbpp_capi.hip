@@ -70,6 +70,7 @@ inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np
 constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
 constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
 constexpr int TRACE_CPW32_BINS = 0;         // ... 32 per wave (0: never; set from the A/B runs in profiles/r04)
+constexpr int INLINE_POLYGON_BINS = 0;      // launches over at most this many bins approximate their borders inside the trace kernel
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
@@ -257,7 +258,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_img, N * P.wimg * 16);
     ALLOC(w_imgrot, N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
-    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * 6 * TRACE_BIG);   // one scratch per wave of the trace grid
+    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * TRACE_BIG_BYTES);   // one scratch per wave of the trace grid
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
@@ -554,11 +555,17 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
         // beyond (half / a third of either grid with striding measured -4 ... -9 %)
         const int cpw = pick_trace_cpw(env, n), pgrid = 2 * n;
+        // Few bins: the SIMDs idle anyway, so a trace wave runs approxPolyDP on the borders it followed itself (the path a full
+        // record list takes) and the polygon kernel -- a launch, a ramp and a record round trip through L2 -- is not launched.
+        const int tune = env->cfg.tuning;
+        const bool inline_polygon = (tune & IRBPP_TUNE_INLINE_POLYGON) || (!(tune & IRBPP_TUNE_SPLIT_POLYGON) && n <= INLINE_POLYGON_BINS);
+        Params Pt = env->P;
+        if (inline_polygon) Pt.round_cap = 0;
         int tgrid = n * (64 / cpw);
         if (tgrid > trace_grid_cap(env->P.N)) tgrid = trace_grid_cap(env->P.N);      // (w_big holds one scratch per wave of the grid)
         auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
-        hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
-        hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
+        hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
+        if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }

@@ -1528,7 +1528,8 @@ constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders
 static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
 static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
-constexpr int TRACE_ISTRIDE = 34;                                    // u16 per staged image: 32 + 2 (17 dwords: odd)
+constexpr int TRACE_FSTRIDE = FRAME_WORDS + 1;                        // dwords per staged image: two frames + 1 (37: odd, lanes on distinct banks)
+constexpr int TRACE_BIG_BYTES = 6 * TRACE_BIG + 64;                   // scratch of the sequential redo: points, polygon, stack, 16-bit image
 // Candidates per wave (chunk) of the trace kernel: 64 at full width; 32 or 16 when the launch has too few candidates to
 // give every SIMD a wave of 64 (a wave lasts as long as its longest border: with fewer borders per wave the mean wave is
 // shorter and the idle SIMDs take the extra waves -- launch_group in irbpp_capi.hip picks by the number of bins).
@@ -1536,7 +1537,7 @@ template <int TRACE_CPW>
 __device__ __forceinline__ void trace_body(const Params& P, const State& S, long long* prof) {
     constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
     __shared__ __attribute__((aligned(16))) uint8_t slots[TRACE_CPW * SLOT];            // one border per tracing lane
-    __shared__ __attribute__((aligned(16))) uint16_t simg[TRACE_CPW * TRACE_ISTRIDE];   // one level image per tracing lane
+    __shared__ __attribute__((aligned(16))) uint32_t sfr[TRACE_CPW * TRACE_FSTRIDE];    // one level image per tracing lane: row + column frames
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
     const int lane = threadIdx.x;
@@ -1563,7 +1564,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         const size_t g = (size_t)seg * seg_cap + gi;
         // ---- my candidate, its level image into LDS
         int my_n = 0, rk = 0, x0 = 0, y0 = 0;
-        uint16_t* const im = simg + (lane < TRACE_CPW ? lane : 0) * TRACE_ISTRIDE;
+        uint32_t* const fr = sfr + (lane < TRACE_CPW ? lane : 0) * TRACE_FSTRIDE;
         uint8_t* const my_slot = slots + (lane < TRACE_CPW ? lane : 0) * SLOT;
         if (have) {
             const uint2 ce = S.w_cand[g];
@@ -1573,25 +1574,22 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
             y0 = (e >> 4) & 15u;
             rk = b * P.R + (int)S.w_imgrot[(size_t)b * P.wimg + img];
             const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * P.wimg + img) * 16);
-            uint32_t* li = (uint32_t*)im;
             const uint4 v0 = gi[0], v1 = gi[1];
             const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            uint32_t r[16];
+            uint32_t r[16], c[16];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                li[q] = w[q];                                         // row words 2q, 2q + 1
-                r[2 * q] = w[q] & 0xFFFFu;
-                r[2 * q + 1] = w[q] >> 16;
+            for (int q = 0; q < 8; ++q) {                             // row words 2q, 2q + 1
+                r[2 * q] = c[2 * q] = w[q] & 0xFFFFu;
+                r[2 * q + 1] = c[2 * q + 1] = w[q] >> 16;
             }
-            transpose16(r);                                           // column words for the vertical run jumps
-#pragma unroll
-            for (int q = 0; q < 8; ++q) li[8 + q] = r[2 * q] | (r[2 * q + 1] << 16);
+            transpose16(c);                                           // column words for the vertical moves
+            frames_store(fr, r, c);
         }
         const long long t_staged = prof ? (long long)clock64() : 0;
         // ---- follow the borders, all lanes in lockstep
-        if (have) {
-            const int n = trace_border(im, im + 16, x0, y0, my_slot, CAP);
-            if (n < 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+        {
+            const int n = trace_border_fast(fr, x0, y0, my_slot, CAP, have);
+            if (n < 0) { if (lane == 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD); }
             else my_n = n;                                            // 0: not the first pixel of its component
         }
         // ---- a border of more than 128 points (not seen in any workload): sequential, in global scratch
@@ -1601,9 +1599,11 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                 const int l0 = __ffsll((long long)big) - 1;
                 big &= big - 1ull;
                 if (lane == l0) {
-                    uint8_t* gsc = S.w_big + (size_t)blockIdx.x * (6 * TRACE_BIG);        // one scratch per wave of the grid
+                    uint8_t* gsc = S.w_big + (size_t)blockIdx.x * TRACE_BIG_BYTES;        // one scratch per wave of the grid
                     SlotMem m;
                     m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
+                    uint16_t* im = (uint16_t*)(gsc + 6 * TRACE_BIG);                      // the plain walk reads 16-bit row and column words
+                    for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)(fr[1 + q] >> 1); im[16 + q] = (uint16_t)(fr[FRAME_COLS + 1 + q] >> 1); }
                     if (contour_vertices(im, im + 16, x0, y0, m, S.w_vmask + (size_t)rk * 16) != 0)
                         atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                     my_n = 0;

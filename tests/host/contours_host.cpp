@@ -64,6 +64,15 @@ int host_trace_border(const uint16_t* rows, int x0, int y0, uint8_t* pts, int ca
     return trace_border(rows, cols, x0, y0, pts, cap);
 }
 
+// trace_border_fast (the trace kernel's walk) on the frames of the image: same contract as host_trace_border
+int host_trace_border_fast(const uint16_t* rows, int x0, int y0, uint8_t* pts, int cap) {
+    uint32_t r[16], c[16], fr[FRAME_WORDS];
+    for (int y = 0; y < 16; ++y) r[y] = c[y] = rows[y];
+    transpose16(c);
+    frames_store(fr, r, c);
+    return trace_border_fast(fr, x0, y0, pts, cap);
+}
+
 // approx_and_convex on a point list: vrows[16] gets the vertex bits; returns 1 ok, 0 stack overflow.
 int host_approx_and_convex(const uint8_t* pts, int count, int cap_stk, uint32_t* vrows) {
     static uint8_t dst[4096];

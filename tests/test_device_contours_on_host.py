@@ -50,6 +50,8 @@ def host():
     lib.host_start_candidates.argtypes = [u16p, u32p]
     lib.host_trace_border.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
     lib.host_trace_border.restype = C.c_int
+    lib.host_trace_border_fast.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
+    lib.host_trace_border_fast.restype = C.c_int
     lib.host_approx_and_convex.argtypes = [u8p, C.c_int, C.c_int, u32p]
     lib.host_approx_and_convex.restype = C.c_int
     lib.host_contour_vertices.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
@@ -106,16 +108,17 @@ def test_candidates_and_trace_equal_the_oracle_borders(host, seed):
         host.host_start_candidates(rows, cand)
         listed = {(x, y) for y in range(16) for x in range(16) if (cand[y] >> x) & 1}
         assert set(starts) <= listed                                   # every true start is a candidate
-        for (x, y) in listed:
-            n = host.host_trace_border(rows, x, y, pts, 512)
-            if (x, y) in starts:
-                got = [(pts[i] & 15, pts[i] >> 4) for i in range(n)]
-                assert got == starts[(x, y)]                           # same points, same order
-            else:
-                assert n == 0                                          # a later pixel of some component
-        if outer:                                                      # a tight slot reports the true length
-            longest = max(outer, key=len)
-            assert host.host_trace_border(rows, longest[0][0], longest[0][1], pts, 3) == len(longest)
+        for trace in (host.host_trace_border, host.host_trace_border_fast):     # the plain walk and the trace kernel's
+            for (x, y) in listed:
+                n = trace(rows, x, y, pts, 511)
+                if (x, y) in starts:
+                    got = [(pts[i] & 15, pts[i] >> 4) for i in range(n)]
+                    assert got == starts[(x, y)]                           # same points, same order
+                else:
+                    assert n == 0                                          # a later pixel of some component
+            if outer:                                                      # a tight slot reports the true length
+                longest = max(outer, key=len)
+                assert trace(rows, longest[0][0], longest[0][1], pts, 3) == len(longest)
 
 
 def _oracle_vertices(contour_xy):

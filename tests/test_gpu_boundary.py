@@ -115,3 +115,81 @@ def test_order_and_location_actions_have_their_own_staging():
         np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cobs), err_msg=f"step {t}")
         np.testing.assert_array_equal(gdone, cdone)
     genv.close()
+
+
+def _unit_item_shapes(n_rot=2):
+    """One 2 cm cube: its footprint is exactly one action cell (2 x 2 heightmap cells at resolutionH 0.01, step 2), so
+    posZmap[r, X, Y] is the maximum of heightmap block (X, Y) -- any 16 x 16 level image can be dialled in."""
+    from irbpp_amd.shapes import ShapeSet
+    from irbpp_amd.synthetic import _box_tables
+    ext = np.array([0.02, 0.02, 0.02])
+    return ShapeSet(np.array([[ext] * n_rot]), np.array([8e-6]), [[_box_tables(ext, 0.01) for _ in range(n_rot)]], name="unit")
+
+
+def _snake_image():
+    """One 8-connected component whose outer border has more than 128 CHAIN_APPROX_SIMPLE points: five zigzag rows
+    joined at alternating ends (a border runs along both sides of a one-pixel line and turns at every pixel)."""
+    img = np.zeros((16, 16), dtype=bool)
+    for j, y0 in enumerate((0, 3, 6, 9, 12)):
+        for x in range(16):
+            img[y0 + (x & 1), x] = True
+        if j < 4:
+            xe = 15 if j % 2 == 0 else 0
+            img[y0 + 2, xe] = True
+            img[y0 + 1, xe] = True
+            img[y0 + 3, xe] = True
+    return img
+
+
+def test_adversarial_level_images_through_transition_trace_polygon_emit():
+    """Level images chosen at will -- random speckle at several densities, rings, a snake whose border outgrows the
+    128-point slot of the trace kernel (its sequential redo) -- fed through the whole split pipeline by way of the
+    heightmap of a bin that observes a one-cell item; every location observation against the oracle."""
+    from oracle import contours as OC
+    from oracle.packing import OracleVecEnv
+    sh = _unit_item_shapes()
+    seqs = np.zeros((8, 40), dtype=np.int32)
+    n, k = 6, 2
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k)
+    genv.candidates_on_device = True
+    oenv = OracleVecEnv(n, sh, seqs, bufferSize=k)
+    np.testing.assert_array_equal(genv.reset().cpu().numpy(), _f32(oenv.reset()))
+    snake = _snake_image()
+    outer = [c for c, hole in zip(*(lambda r: (r[0], r[2]))(OC.find_contours(snake.astype(np.uint8)))) if not hole]
+    assert len(outer) == 1 and len(outer[0]) > 128, len(outer[0])           # the redo path is really taken
+    rng = np.random.RandomState(12)
+    big = 0
+    for t in range(8):
+        imgs = []
+        for i in range(n):
+            kind = (t + i) % 4
+            if kind == 0:
+                imgs.append(snake if (t // 4) % 2 == 0 else snake.T.copy())
+            elif kind == 1:
+                imgs.append(rng.rand(16, 16) < rng.uniform(0.3, 0.7))
+            elif kind == 2:
+                g = np.maximum(np.abs(np.arange(16)[:, None] - 7.5), np.abs(np.arange(16)[None, :] - 7.5))
+                imgs.append((np.floor(g) % 2 == 0) ^ (rng.rand(16, 16) < 0.03))
+            else:
+                imgs.append(np.kron(rng.rand(4, 4) < 0.5, np.ones((4, 4), dtype=bool)) ^ (rng.rand(16, 16) < 0.05))
+        hm = np.zeros((n, 32, 32))
+        for i, im in enumerate(imgs):                                       # image pixel (x, y) = action cell (row y, col x)
+            lv = np.where(im, 0.05, 0.11) + rng.randint(0, 2, size=(16, 16)) * np.where(im, 0.0, 0.03)
+            hm[i] = np.kron(lv, np.ones((2, 2)))
+        big += sum(1 for im in imgs if im is snake or (im.shape == snake.shape and (im == snake.T).all()))
+        genv.env.set_heightmaps(torch.from_numpy(hm).to(DEV))
+        for i in range(n):
+            oenv.envs[i].space.heightmapC[:] = hm[i]
+        oa = np.array([t % k] * n)
+        gloc = genv.get_action_candidates(oa).cpu().numpy()
+        oloc = _f32(oenv.get_action_candidates(oa))
+        np.testing.assert_array_equal(gloc, oloc, err_msg=f"round {t}")
+        act = np.array([int(np.argmin(np.where(c.reshape(S, 5)[:, 4] == 1, c.reshape(S, 5)[:, 3], np.inf)))
+                        if (c.reshape(S, 5)[:, 4] == 1).any() else 0 for c in oloc[:, :5 * S]])
+        gord, _, gdone, _ = genv.step(act)
+        oord, _, odone, _ = oenv.step(act)
+        np.testing.assert_array_equal(gord.cpu().numpy(), _f32(oord))
+        np.testing.assert_array_equal(gdone, odone)
+    assert big >= 8
+    genv.env.check_device_error()
+    genv.close()

@@ -194,3 +194,32 @@ def test_item_grouped_launch_order_changes_nothing():
     b.check_device_error()
     a.close()
     b.close()
+
+
+@pytest.mark.parametrize("workload,n,steps", [("blockout", 160, 120), ("general", 96, 45)])
+def test_trace_launch_shapes_change_nothing(workload, n, steps):
+    """The launch shapes the library picks by the number of bins -- 64 / 32 / 16 candidate starts per trace wave, borders
+    approximated by the polygon kernel or inside the trace kernel -- forced one by one through irbpp_config::tuning:
+    every observation, reward and done flag equals the default's, through auto-resets."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload(workload)
+    flags = [_lib.TUNE_TRACE_CPW64 | _lib.TUNE_SPLIT_POLYGON, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
+             _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON]
+    envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)] + \
+           [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
+    obs = [e.reset() for e in envs]
+    for o in obs[1:]:
+        assert torch.equal(o, obs[0])
+    done_total = 0
+    for t in range(steps):
+        act = envs[0].policy_minz(obs[0])
+        res = [e.step(act) for e in envs]
+        for j, (o, r, d) in enumerate(res[1:]):
+            assert torch.equal(o, res[0][0]), f"step {t}, tuning {flags[j]}"
+            assert torch.equal(r, res[0][1]) and torch.equal(d, res[0][2])
+        obs = [r[0].clone() for r in res]
+        done_total += int(res[0][2].sum())
+    assert done_total > n // 2
+    for e in envs:
+        e.check_device_error()
+        e.close()
