@@ -109,6 +109,7 @@ void layout_lds(Params& P) {
     const int32_t mb_bytes = align16(P.mb_w * P.mb_h * 8);
     if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
     else { P.o_mb = off; off += mb_bytes; }
+    P.o_c2 = off;        off += mb_bytes ? align16(P.AC * 8) : 0;     // block path: per-action-cell maxima, the grid's first step
     P.o_vmask = off;     off += align16(P.R * 16 * 4);
     P.o_vbits = P.o_taskidx;                           // naiveMask bit rows: handed over before the task index is built (split_handover)
     P.o_m1 = off;        off += P.box ? align16(P.Hx * P.Ay * 8) : 0; // box path: row maxima of the tile, [Hx][Ay]

@@ -143,7 +143,7 @@ struct Params {
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid
     // mb[pi][pj] = max of the b x b heightmap block at (pi*step, pj*step) replaces the cell list:
     // max over the tile of (H - B) == (max over the tile of H) - B exactly (rounding is monotone).
-    int32_t block_b, mb_w, mb_h, o_mb;
+    int32_t block_b, mb_w, mb_h, o_mb, o_c2;
     // Division by the runtime grid sizes costs ~25 VALU instructions each; n / d == umulhi(n, mg_d) exactly
     // for n, d < 2^16 with mg_d = floor(2^32 / d) + 1 (d >= 2), see fdiv() in irbpp_kernels.hip.
     uint32_t mg_hy, mg_step, mg_ay, mg_ax, mg_ac, mg_mbw;

@@ -36,7 +36,10 @@ constexpr int WAVES = BLOCK / 64;
 
 // Tooling build only (tools/build_variant.sh NAME -DIRBPP_ABLATE): phase `bit` runs twice when Params.dbg_repeat has the
 // bit set.  Every repeated phase is idempotent, so results do not change and the slow-down of a launch
-// prices the phase at full chip load.  In the product build the trip count is the constant 1.
+// prices the phase at full chip load (and the instruction counters of a PMC pass its instruction count).  In the product
+// build the trip count is the constant 1.  Bits: 0 in-workgroup trace, 1 Douglas-Peucker (hull kernel), 2 overlap loops,
+// 3 emit stores, 5 tile staging, 6 block-max grid, 7 level codes + masks, 8 float32 heightmap copy, 9 level images +
+// candidate bits, 10 candidate list.
 #ifdef IRBPP_ABLATE
 #define IRBPP_REPS(bit) (1 + ((P.dbg_repeat >> (bit)) & 1))
 #else
@@ -243,6 +246,7 @@ struct Lds {
     int* sr;                // the R ShapeRots of the observed item, as dwords
     double* hm;
     double* mb;             // block-max grid of the tile (block path of the overlap test)
+    double* c2;             // maxima of the action cells' own step x step heightmap cells, [Ax][Ay] (block path)
     double* m1;             // row maxima of the tile, [Hx][Ay] (box path of the overlap test)
     double* posz;
     uint8_t* lev;
@@ -264,6 +268,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     L.sr = (int*)(smem + P.o_sr);
     L.hm = (double*)(smem + P.o_hm);
     L.mb = (double*)(smem + P.o_mb);
+    L.c2 = (double*)(smem + P.o_c2);
     L.m1 = (double*)(smem + P.o_m1);
     L.posz = (double*)(smem + P.o_posz);
     L.lev = smem + P.o_lev;
@@ -712,7 +717,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
-    if (use_block) {                             // block-max grid of the current tile
+    if (use_block)
+    for (int rep = 0; rep < IRBPP_REPS(6); ++rep) {
+        if (rep) __syncthreads();
+        // Block-max grid of the current tile, in two steps.  (1) the maximum of every action cell's own step x step cells:
+        // in the phase-plane layout those are entry X*Ay + Y of every plane -- step^2 conflict-free reads at one index.
+        // (2) a b x b block is (b / step)^2 neighbouring action cells.  (Reading the b^2 cells of every block straight from
+        // the planes took 16 scattered reads with their index arithmetic per block at b = 4, step = 2.)
+#ifdef IRBPP_AB_OLD_MBGRID
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
             double m = -1e300;
@@ -727,6 +739,23 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             }
             L.mb[t] = m;
         }
+#else
+        const int planes = P.pp * P.pp, mq = P.block_b / P.step;
+        for (int t = tid; t < AC; t += BLOCK) {
+            double m = L.hm[t];
+            for (int pl = 1; pl < planes; ++pl) m = fmax(m, L.hm[pl * P.PL + t]);
+            L.c2[t] = m;
+        }
+        __syncthreads();
+        for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
+            const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
+            const double* c = L.c2 + pi * Ay + pj;
+            double m = -1e300;
+            for (int i = 0; i < mq; ++i)
+                for (int j = 0; j < mq; ++j) m = fmax(m, c[i * Ay + j]);
+            L.mb[t] = m;
+        }
+#endif
     }
     __syncthreads();
 
@@ -853,6 +882,8 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     }
     }
     int level_code[8];
+    for (int rep = 0; rep < IRBPP_REPS(7); ++rep) {
+    if (rep) my_valid = 0;
     const bool rows_align = (1 << P.g_ysh) == Ay;            // a wave's 64 consecutive cells are whole rows of the action grid
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -899,6 +930,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             todo &= ~__ballot(code == c);
         }
         if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
+    }
     }
     } else {
     // ---- generic path: ONE action cell per lane, and only cells that can be in range.  A wave task is (rotation r,
@@ -1085,6 +1117,7 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
     if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
+    for (int rep = 0; rep < IRBPP_REPS(8); ++rep)
     for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) obs[5 * P.S + 9 + w.lin] = (float)L.hm[tile_walk_index(P, w)];
     __syncthreads();
     stamp(io, b, 2);
@@ -1387,14 +1420,18 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
         __syncthreads();
     }
-    const int ntasks = contour_tasks(P, L);
+    int ntasks = 0;
+    for (int rep = 0; rep < IRBPP_REPS(9); ++rep) { if (rep) __syncthreads(); ntasks = contour_tasks(P, L); }
     int ncand = 0;
     uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 16);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
     const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
     for (int base = 0; base < ntasks; base += IMGS) {                        // one batch of level images at a time
-        contour_images<IPT>(P, L, rows, base, false);
-        const int batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks);
+        int batch_total = 0;
+        for (int rep = 0; rep < IRBPP_REPS(9); ++rep) {
+            contour_images<IPT>(P, L, rows, base, false);
+            batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks);
+        }
         const int nb = ntasks - base < IMGS ? ntasks - base : IMGS;
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)rows;
@@ -1407,7 +1444,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         // entries; a batch with more candidates (speckle) goes image by image (an image has at most 64).
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
-            const int total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub);
+            int total = 0;
+            for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub);
             if (tid == 0) {
                 // This die's list; should it be full (the dispatcher gave this die far more than its share of speckled
                 // bins, or the device runs in a partition mode where XCC_ID does not spread the workgroups over eight
@@ -1851,6 +1889,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             for (int i = tid; i < P.tile_words; i += BLOCK) L.hm[i] = 0.0;
             __syncthreads();
         }
+        for (int rep = 0; rep < IRBPP_REPS(5); ++rep)
         for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) L.hm[tile_walk_index(P, w)] = ghm[w.lin];
     }
     uint32_t st_key = 0u;
