@@ -70,6 +70,7 @@ inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np
 constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
 constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
 constexpr int TRACE_CPW32_BINS = 0;         // ... 32 per wave (0: never; set from the A/B runs in profiles/r04)
+constexpr int INLINE_POLYGON_BINS = 0;      // launches over at most this many bins approximate their borders inside the trace kernel
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
@@ -145,7 +146,6 @@ void layout_lds(Params& P) {
         P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);       // >= 4 * S bytes for the rows' values too
     }
     P.e_keys = e;   e += align16(keys);
-    P.e_dps = e;    e += 4 * (64 * TRACE_P * 4 + 64 * TRACE_P);      // per wave: arg-max words + scratch bytes of the segmented Douglas-Peucker
     P.emit_lds_bytes = e;
 }
 
@@ -235,8 +235,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     P.wimg = P.R * 64;
     P.seg_cap = 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;
-    P.pool_cap = (P.N / NXCD + 64) * 512;                   // dwords per die: 2 KB of contour points per bin of a fair share (a bin uses ~100 B)
-    if (P.pool_cap > (1 << 24) - 64) P.pool_cap = (1 << 24) - 64;   // (a border's offset travels in 24 bits)
+    P.round_cap = (P.N / NXCD + 64) * 16;
     layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes_full > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
@@ -262,10 +261,8 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
     ALLOC(w_big, (size_t)trace_grid_cap(P.N) * TRACE_BIG_BYTES);   // one scratch per wave of the trace grid
     ALLOC(w_total, NXCD * XCD_STRIDE);
-    ALLOC(w_bused, NXCD * XCD_STRIDE);
-    ALLOC(w_bpool, (size_t)NXCD * P.pool_cap);
-    ALLOC(w_bidx, N * BORDER_CAP);
-    ALLOC(w_bcount, N);
+    ALLOC(w_nround, NXCD * XCD_STRIDE);
+    ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     {   // identity launch order until an ordering pass writes another one
@@ -558,15 +555,18 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
         // beyond (half / a third of either grid with striding measured -4 ... -9 %)
-        const int cpw = pick_trace_cpw(env, n);
-        // (IRBPP_TUNE_INLINE_POLYGON: no pool, i.e. every trace wave approximates the borders it followed itself -- the path a
-        // full pool takes, forced for the parity tests)
+        const int cpw = pick_trace_cpw(env, n), pgrid = 2 * n;
+        // Few bins: the SIMDs idle anyway, so a trace wave runs approxPolyDP on the borders it followed itself (the path a full
+        // record list takes) and the polygon kernel -- a launch, a ramp and a record round trip through L2 -- is not launched.
+        const int tune = env->cfg.tuning;
+        const bool inline_polygon = (tune & IRBPP_TUNE_INLINE_POLYGON) || (!(tune & IRBPP_TUNE_SPLIT_POLYGON) && n <= INLINE_POLYGON_BINS);
         Params Pt = env->P;
-        if (env->cfg.tuning & IRBPP_TUNE_INLINE_POLYGON) Pt.pool_cap = 0;
+        if (inline_polygon) Pt.round_cap = 0;
         int tgrid = n * (64 / cpw);
         if (tgrid > trace_grid_cap(env->P.N)) tgrid = trace_grid_cap(env->P.N);      // (w_big holds one scratch per wave of the grid)
         auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
         hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
+        if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }

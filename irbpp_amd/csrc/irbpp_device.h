@@ -29,8 +29,8 @@ constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 constexpr int WMETA = 8;
 constexpr int NXCD = 8;                            // accelerator dies of the MI355X: one flat candidate list each
 constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each
-constexpr int BORDER_CAP = 512;                    // closed borders a bin can hand from the trace kernel to its emit workgroup through the pool
-                                                   // (a bin with more -- pathological speckle -- has the rest approximated by the trace waves)
+constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;   // a round record of the polygon kernel: [points | border length | border
+                                                                     // start] per position, then the vertex-row index of the position's border
 constexpr int MAX_BINS = 1 << 20;                 // bins per device (irbpp_create refuses more): keeps every per-launch index an int32
 
 struct ShapeRot {
@@ -113,10 +113,8 @@ struct State {
     uint2* w_cand;         // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
                            // (bin, image<<8 | y0<<4 | x0)
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
-    uint32_t* w_bpool;     // [NXCD][pool_cap] dwords: contour points (x | y << 4 bytes) of the closed borders, trace kernel -> emit kernel
-    int32_t* w_bused;      // [NXCD * XCD_STRIDE] dwords taken from each XCD's pool (XCD-local atomicAdd, zeroed by the emit kernel)
-    uint2* w_bidx;         // [N][BORDER_CAP] a bin's borders: (xcd << 24 | dword offset in that pool, points | rotation << 8)
-    int32_t* w_bcount;     // [N] borders listed for the bin (atomicAdd by the tracing lanes, zeroed by the bin's emit workgroup)
+    uint8_t* w_round;      // [NXCD][round_cap][ROUND_BYTES] round records, trace kernel -> polygon kernel
+    int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list
     int32_t* w_total;      // [NXCD * XCD_STRIDE] candidates in each XCD's list (XCD-local atomicAdd in the transition kernel, zeroed by the emit kernel)
 };
 
@@ -139,7 +137,7 @@ struct Params {
     int32_t o_hm, o_posz, o_lev, o_present, o_taskidx, o_tasklist, o_img, o_clist, o_vmask, o_scratch, o_red, o_dps;
     int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;   // lds_bytes: transition kernel (no posZValid region)
     int32_t lds_bytes_full;   // + posZValid at o_posz: heuristic kernel
-    int32_t e_vmask, e_red, e_hist, e_keys, e_dps, emit_lds_bytes;   // the emit kernel's own carve-up
+    int32_t e_vmask, e_red, e_hist, e_keys, emit_lds_bytes;   // the emit kernel's own carve-up
     int32_t big_slot_bytes;   // bytes of the scratch region the serial redo of an oversized border may use
     // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid
@@ -156,7 +154,7 @@ struct Params {
     int32_t split;         // 1: transition kernel -> trace kernel -> emit kernel; 0: everything in the transition kernel
     int32_t wimg;          // level images a bin can hand over: R * 64
     int32_t seg_cap;       // entries of one XCD's flat candidate list: twice the worst case (R*AC per bin) of its share of the bins
-    int32_t pool_cap;      // dwords of one XCD's border pool (a full pool makes the trace waves approximate their borders in place)
+    int32_t round_cap;     // round records of one XCD's list (a full list makes the trace kernel approximate in place)
     int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
 };
 

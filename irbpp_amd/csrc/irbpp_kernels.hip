@@ -6,8 +6,8 @@
 //                         overlap test of the next item over (rot,X,Y) (space.py:98-129); height levels -> per-level
 //                         binary images -> candidate start pixels of their outer borders (cvTools.py:61-84)
 //   irbpp_trace_kernel    border following over the candidates of ALL bins, one per lane (cv2.findContours)
-//   irbpp_emit_kernel     one workgroup per bin: approxPolyDP + convex vertices of the bin's borders (cvTools.py:40-59,91-96),
-//                         candidate set -> select/pad S rows -> float32 observation (binPhy.py:183-232)
+//   irbpp_polygon_kernel  approxPolyDP + convex vertices of 128 contour points per wave (cvTools.py:40-59,91-96)
+//   irbpp_emit_kernel     one workgroup per bin: candidate set -> select/pad S rows -> float32 observation (binPhy.py:183-232)
 // The float64 heightmap tile of a bin lives in LDS for the whole transition kernel (8 KiB at 32x32, 32 KiB at 64x64);
 // footprint tables are wave-uniform reads served from L2; levels, level images and vertex bit grids stay in LDS;
 // posZValid, the images, the candidate lists and the polygon rounds are handed from kernel to kernel through
@@ -595,31 +595,6 @@ __device__ __forceinline__ uint32_t wave_or_to_lane63(uint32_t x) {
     return (uint32_t)v;
 }
 
-// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
-// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
-// 0 that a shift brings in from outside the row is the identity of both sum and max.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
-__device__ __forceinline__ int wave_inclusive_sum(int v) {
-    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
-    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
-    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
-    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
-    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
-    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int wave_inclusive_max(int v) {
-    v = imax(v, dpp_shift<0x111, 0xF>(v));
-    v = imax(v, dpp_shift<0x112, 0xF>(v));
-    v = imax(v, dpp_shift<0x114, 0xF>(v));
-    v = imax(v, dpp_shift<0x118, 0xF>(v));
-    v = imax(v, dpp_shift<0x142, 0xA>(v));
-    v = imax(v, dpp_shift<0x143, 0xC>(v));
-    return v;
-}
-
 // a GCell as ONE 16-byte scalar load (the struct's fields would be fetched one s_load_dword(x2) each)
 typedef int32_t gcell_words __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) gcell_words* ConstGCellPtr;
@@ -632,7 +607,6 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 // PATH: the overlap path compiled in -- one of the three, so that a transition kernel carries (and allocates registers
 // for) only the path its data set takes, or PATH_ANY: decided at run time from Params (heuristic kernel, fallback build).
 enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
-constexpr int GENERIC_TICKET = 40;               // word of Lds::redi that deals the generic path's tasks
 // One footprint cell list walked for G row groups at once (overlap_test's generic path): per cell one 16-byte scalar
 // load (bottom height, byte offset in the tile), per row group one LDS read at lane base + offset, one subtract and
 // one max; four cells (one 64-byte scalar load) per trip, two max chains per row group.
@@ -740,7 +714,6 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
-    if (tid == 0) L.redi[GENERIC_TICKET] = WAVES;            // generic path: the first WAVES tasks are taken without a ticket
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
@@ -985,25 +958,28 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // general 14.6 -> 14.9 M; SQ_INSTS_VALU of the kernel -14 %).
     // A rotation's groups are split evenly over ceil(groups / gmax) tasks; gmax drops when that would leave waves
     // without a task.
-    // The task table lives in the lanes of every wave, one rotation per lane (lanes 0 .. 7): row groups in range, tasks, tasks
-    // before the rotation.  (As three unrolled 8-element arrays in scalar registers with their select chains it cost the
-    // capped build most of its 137 SGPR spills.)
-    int my_grp = 0;
-    if (lane < R && item >= 0) {
-        const ShapeRot* sp = (const ShapeRot*)srw + lane;
-        const int wx = Ax - sp->ax + 1, wy = Ay - sp->ay + 1;
-        if (wx > 0 && wy > 0) my_grp = (wx + rpw - 1) >> (6 - ysh);
+    int ngrp[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        int n = 0;
+        if (r < R && item >= 0) {
+            const ShapeRot* sp = (const ShapeRot*)srw + r;
+            const int wx = Ax - __builtin_amdgcn_readfirstlane(sp->ax) + 1, wy = Ay - __builtin_amdgcn_readfirstlane(sp->ay) + 1;
+            if (wx > 0 && wy > 0) n = (wx + rpw - 1) >> (6 - ysh);
+        }
+        ngrp[r] = n;
     }
-    // (my_grp <= 4 -- an action grid is at most 256 cells, four waves' worth -- so the ceilings are spelled out)
-    const int t3 = my_grp > 3 ? 2 : (my_grp > 0 ? 1 : 0), t2 = (my_grp + 1) >> 1;
-    const int n3 = __builtin_amdgcn_readlane(wave_inclusive_sum(t3), 63), n2 = __builtin_amdgcn_readlane(wave_inclusive_sum(t2), 63);
+    int first[9];                                            // tasks before rotation r
+    // (ngrp <= 4 -- an action grid is at most 256 cells, four waves' worth -- so the ceilings are spelled out)
+    int n3 = 0, n2 = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) { n3 += ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0); n2 += (ngrp[r] + 1) >> 1; }
     const int gmax = n3 >= WAVES ? 3 : (n2 >= WAVES ? 2 : 1);
-    const int my_tasks = gmax == 3 ? t3 : (gmax == 2 ? t2 : my_grp);
-    const int my_incl = wave_inclusive_sum(my_tasks), my_first = my_incl - my_tasks;          // tasks before this lane's rotation
-    const int ntask = __builtin_amdgcn_readlane(my_incl, 63);
-    auto task_rotation = [&](int t) {                        // the last rotation whose tasks start at or before t
-        return __popcll(__ballot(lane >= 1 && lane < 8 && t >= my_first));
-    };
+    first[0] = 0;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        first[r + 1] = first[r] + (gmax == 3 ? (ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0)) : (gmax == 2 ? (ngrp[r] + 1) >> 1 : ngrp[r]));
+    const int ntask = first[8];
     int pref = 0;
     auto task_finish = [&](int r, int X, int s_ax, int s_ay, double ext_z_r, double z) {
         const bool in_range = X <= Ax - s_ax && Y <= Ay - s_ay;
@@ -1045,19 +1021,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const char* lv = (const char*)(T.gcell + ob);
         for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
     };
-    for (int t = wave, mine = 0; ; ++mine) {
-        // Tasks are dealt by a ticket in LDS: a wave that drew a short list (or few row groups) comes back for the next task
-        // while the others are still walking (the static deal t = wave, wave + 4, ... was 8 % off an even split).  The first
-        // task of a wave is its own number: no round trip before the first walk.
-        if (mine > 0) {
-            int tk = 0;
-            if (lane == 0) tk = atomicAdd(&L.redi[GENERIC_TICKET], 1);
-            t = __builtin_amdgcn_readfirstlane(tk);
-        }
-        if (t >= ntask) break;
-        const int r = task_rotation(t);
-        const int tq = t - __builtin_amdgcn_readlane(my_first, r), ng = __builtin_amdgcn_readlane(my_grp, r);
-        const int nt = __builtin_amdgcn_readlane(my_tasks, r);
+    for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
+    for (int t = wave; t < ntask; t += WAVES) {
+        int r = 0;
+#pragma unroll
+        for (int q = 1; q < 8; ++q) r += t >= first[q] ? 1 : 0;
+        int tq = t, ng = 0, nt = 1;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) if (q == r) { tq = t - first[q]; ng = ngrp[q]; nt = first[q + 1] - first[q]; }
         // even split of ng groups over nt tasks: the first ng % nt tasks take one more
         const int base = nt == 1 ? ng : (nt == ng ? 1 : ng >> 1), rem = ng - base * nt;   // (nt is 1, 2 or ng)
         const int G = base + (tq < rem ? 1 : 0), g0 = tq * base + (tq < rem ? tq : rem);
@@ -1074,9 +1045,12 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         // its ShapeRots, before the placement is applied -- was measured and is worse: abc_fine 7.1 -> 6.9 M, general
         // 14.6 -> 14.1 M; the lines do not survive in L2 until they are needed, and the kept-alive register costs the
         // kernel its seventh wave per SIMD.)
-        if (mine == 0) prefetch_list(ob, nb);
-        if (t + WAVES < ntask) {                             // (whoever draws it: the list is pulled into this die's L2)
-            const int rn = task_rotation(t + WAVES);
+        if (t == wave) prefetch_list(ob, nb);
+        if (t + WAVES < ntask) {
+            const int tn = t + WAVES;
+            int rn = 0;
+#pragma unroll
+            for (int q = 1; q < 8; ++q) rn += tn >= first[q] ? 1 : 0;
             if (rn != r) {
                 const ShapeRot* sn = (const ShapeRot*)srw + rn;
                 prefetch_list(__builtin_amdgcn_readfirstlane(sn->ob), __builtin_amdgcn_readfirstlane(sn->nb));
@@ -1514,6 +1488,37 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 }
 
 // ---------------------------------------------------------------------------------------
+// Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
+irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
+    L.vmask = (uint32_t*)(smem + P.e_vmask);
+    L.redd = (double*)(smem + P.e_red);
+    L.redi = (int*)(L.redd + 8);
+    L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select, the sort keys, the rows' values
+    L.scratch = smem + P.e_keys;
+    const bool some = mode == MODE_RESET && io.bin_list != nullptr;
+    const int slot = (int)blockIdx.x + io.block_off;
+    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+    const int tid = threadIdx.x;
+    // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
+    // device error word to the step outputs: every bit of this step was raised by the transition or the trace
+    // kernel, which have completed (the emit kernel raises none).
+    if (blockIdx.x == 0 && tid < NXCD) { S.w_total[tid * XCD_STRIDE] = 0; S.w_nround[tid * XCD_STRIDE] = 0; }
+    if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
+    if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
+    float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
+    const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
+    for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
+    const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
+    __syncthreads();
+    stamp(io, b, 3);
+    emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
+}
+
+// ---------------------------------------------------------------------------------------
 // Split pipeline, middle kernels: border following + approxPolyDP + convexity over the candidate starts of ALL
 // bins of the launch as one flat list.  One bin has ~25 borders to follow, a handful of them long: traced inside
 // the bin's own workgroup, most lanes idle, and the bins with many or long borders set the duration of the
@@ -1523,6 +1528,31 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // follows its border (trace_border), and the wave then runs approx_convex_segmented on all the closed borders,
 // 128 contour points per round; vertex bits go to the bins' rows in global memory with one atomic OR each.
 // ---------------------------------------------------------------------------------------
+// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
+// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
+// 0 that a shift brings in from outside the row is the identity of both sum and max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
+    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
+    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
+    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
+    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
+    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+    v = imax(v, dpp_shift<0x111, 0xF>(v));
+    v = imax(v, dpp_shift<0x112, 0xF>(v));
+    v = imax(v, dpp_shift<0x114, 0xF>(v));
+    v = imax(v, dpp_shift<0x118, 0xF>(v));
+    v = imax(v, dpp_shift<0x142, 0xA>(v));
+    v = imax(v, dpp_shift<0x143, 0xC>(v));
+    return v;
+}
+
 #ifndef IRBPP_TRACE_P
 #define IRBPP_TRACE_P 2
 #endif
@@ -1534,62 +1564,10 @@ constexpr int TRACE_CAP = 128, TRACE_SLOT = TRACE_CAP + 4;            // points 
 constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points get rounds of their own, ahead of the
                                                                       // long ones (0 = one class: measured 27.46 vs 27.25 M steps/s for 8)
 static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
+static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
 constexpr int TRACE_FSTRIDE = FRAME_WORDS + 1;                        // dwords per staged image: two frames + 1 (37: odd, lanes on distinct banks)
 constexpr int TRACE_BIG_BYTES = 6 * TRACE_BIG + 64;                   // scratch of the sequential redo: points, polygon, stack, 16-bit image
-// approxPolyDP + find_convex_vetex of the borders the lanes of a wave hold -- lane i: my_n contour points at ptr_of(i),
-// vertex bits to row block my_key of `vmask` -- in rounds of 64 * PP points, whole borders packed back to back over the
-// positions q = u * 64 + lane (approx_convex_segmented).  Returns the number of rounds.  dps: 64 * PP words, dpscratch:
-// 64 * PP bytes, both private to the wave.
-template <int PP, typename PTR>
-__device__ inline int approx_lane_borders(int lane, int my_n, int my_key, const PTR& ptr_of, uint32_t* dps, uint8_t* dpscratch,
-                                          uint32_t* vmask) {
-    int left = my_n, rounds = 0;
-    for (;;) {
-        const int wn = left;
-        const int incl = wave_inclusive_sum(wn), excl = incl - wn;
-        if (__builtin_amdgcn_readlane(incl, 63) == 0) break;
-        const unsigned long long todo = __ballot(wn > 0);
-        const int base = __builtin_amdgcn_readlane(excl, __ffsll((long long)todo) - 1);
-        const unsigned long long sel = __ballot(wn > 0 && incl - base <= 64 * PP);       // the borders of this round
-        // which border does the point at position q belong to: border lanes drop their id at the position of their
-        // first point, a running maximum over the positions spreads it
-#pragma unroll
-        for (int u = 0; u < PP; ++u) dps[u * 64 + lane] = 0u;
-        IRBPP_WAVE_SYNC();
-        if ((sel >> lane) & 1ull) dps[excl - base] = (uint32_t)lane + 1u;
-        IRBPP_WAVE_SYNC();
-        int mark[PP];
-#pragma unroll
-        for (int u = 0; u < PP; ++u) mark[u] = (int)dps[u * 64 + lane];
-        IRBPP_WAVE_SYNC();
-        bool live[PP];
-        int pv[PP], jj[PP], nn[PP], sbq[PP], key[PP];
-        const uint8_t* pts[PP];
-        int carry = 0;
-#pragma unroll
-        for (int u = 0; u < PP; ++u) {
-            const int run = imax(wave_inclusive_max(mark[u]), carry);
-            carry = __builtin_amdgcn_readlane(run, 63);
-            const int owner = run - 1;                                    // lane that holds this position's border
-            const int on = owner >= 0 ? owner : 0;
-            nn[u] = __shfl(wn, on);
-            sbq[u] = __shfl(excl, on) - base;
-            key[u] = __shfl(my_key, on);
-            live[u] = owner >= 0 && u * 64 + lane < sbq[u] + nn[u];
-            pts[u] = ptr_of(on);
-            jj[u] = u * 64 + lane - sbq[u];
-            if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
-            pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
-        }
-        approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, key, dps, dpscratch, vmask);
-        IRBPP_WAVE_SYNC();
-        if ((sel >> lane) & 1ull) left = 0;
-        ++rounds;
-    }
-    return rounds;
-}
-
 // Candidates per wave (chunk) of the trace kernel: 64 at full width; 32 or 16 when the launch has too few candidates to
 // give every SIMD a wave of 64 (a wave lasts as long as its longest border: with fewer borders per wave the mean wave is
 // shorter and the idle SIMDs take the extra waves -- launch_group in irbpp_capi.hip picks by the number of bins).
@@ -1623,7 +1601,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         const bool have = lane < TRACE_CPW && gi < count;
         const size_t g = (size_t)seg * seg_cap + gi;
         // ---- my candidate, its level image into LDS
-        int my_n = 0, rk = 0, x0 = 0, y0 = 0, mb = 0, mrot = 0;
+        int my_n = 0, rk = 0, x0 = 0, y0 = 0;
         uint32_t* const fr = sfr + (lane < TRACE_CPW ? lane : 0) * TRACE_FSTRIDE;
         uint8_t* const my_slot = slots + (lane < TRACE_CPW ? lane : 0) * SLOT;
         if (have) {
@@ -1632,9 +1610,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
             const int b = (int)ce.x, img = (int)((e >> 8) & 511u);
             x0 = e & 15u;
             y0 = (e >> 4) & 15u;
-            mb = b;
-            mrot = (int)S.w_imgrot[(size_t)b * P.wimg + img];
-            rk = b * P.R + mrot;
+            rk = b * P.R + (int)S.w_imgrot[(size_t)b * P.wimg + img];
             const uint4* gi = (const uint4*)(S.w_img + ((size_t)b * P.wimg + img) * 16);
             const uint4 v0 = gi[0], v1 = gi[1];
             const uint32_t w[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
@@ -1673,38 +1649,99 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
             }
         }
         const long long t_traced = prof ? (long long)clock64() : 0;
-        // ---- the closed borders go to their bins: the contour points into this die's pool (one XCD-local allocation per
-        // wave), a line into the bin's border table (one atomicAdd on the bin's counter per border).  The bin's emit
-        // workgroup runs approxPolyDP + find_convex_vetex on them before it builds the observation -- per bin that is one
-        // round of 128 points as a rule, on a CU that otherwise waits for the emit kernel's loads.  (Until round 4 the waves
-        // packed their borders into round records here, ~7 k cycles of the slowest waves, for a polygon kernel of 25 us
-        // between trace and emit.)  A border that finds the pool or its bin's table full is approximated right here.
+        // ---- the closed borders go to the polygon kernel in rounds of 64 * PP contour points, borders packed back
+        // to back (optionally in two classes, TRACE_SHORT).  A wave traces for as long as its longest border takes and
+        // has 2 to 4 rounds' worth of points: approximating them here would stretch the slowest waves, which set the
+        // kernel's duration; as records in global memory every round is one work item of irbpp_polygon_kernel.
+        auto next_round = [&](int cls, int left, int& wn, int& excl, int& base) -> unsigned long long {
+            wn = (cls == 0 ? left <= TRACE_SHORT : true) ? left : 0;
+            const int incl = wave_inclusive_sum(wn);
+            excl = incl - wn;
+            if (__builtin_amdgcn_readlane(incl, 63) == 0) return 0ull;
+            const unsigned long long todo = __ballot(wn > 0);
+            base = __builtin_amdgcn_readlane(excl, __ffsll((long long)todo) - 1);
+            return __ballot(wn > 0 && incl - base <= 64 * PP);
+        };
+        int n_rounds = 0;                                             // first pass: how many rounds
+        {
+            int left = my_n;
+            for (int cls = 0; cls < 2; ++cls)
+                for (;;) {
+                    int wn, excl, base = 0;
+                    const unsigned long long sel = next_round(cls, left, wn, excl, base);
+                    if (sel == 0ull) break;
+                    if ((sel >> lane) & 1ull) left = 0;
+                    ++n_rounds;
+                }
+        }
+        // their records: one allocation in this XCD's list (L2-local atomic, like the candidate lists)
+        const int round_cap = P.round_cap;
         const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));
-        const int pool_cap = P.pool_cap;
-        const int sz = (my_n + 3) >> 2;                               // dwords of my border (0: none)
-        const int incl = wave_inclusive_sum(sz), total = __builtin_amdgcn_readlane(incl, 63);
         int at = 0;
-        if (total > 0 && pool_cap > 0) {
-            if (lane == 0) at = atomicAdd(S.w_bused + xcd * XCD_STRIDE, total);
+        if (n_rounds > 0) {
+            if (lane == 0) at = atomicAdd(S.w_nround + xcd * XCD_STRIDE, n_rounds);
             at = __builtin_amdgcn_readfirstlane(at);
         }
-        const bool pool_ok = at + total <= pool_cap;
-        bool exported = false;
-        if (my_n > 0 && pool_ok) {
-            const int k = atomicAdd(S.w_bcount + mb, 1);
-            if (k < BORDER_CAP) {
-                const int off = at + incl - sz;
-                uint32_t* dst = S.w_bpool + (size_t)xcd * pool_cap + off;
-                const uint32_t* src = (const uint32_t*)my_slot;
-                for (int q = 0; q < sz; ++q) dst[q] = src[q];
-                S.w_bidx[(size_t)mb * BORDER_CAP + k] = make_uint2(((uint32_t)xcd << 24) | (uint32_t)off, (uint32_t)my_n | ((uint32_t)mrot << 8));
-                exported = true;
+        const bool inline_dp = at + n_rounds > round_cap;             // list full: approximate here (never changes results)
+        uint8_t* const rec0 = S.w_round + ((size_t)xcd * round_cap + at) * ROUND_BYTES;
+        int left = my_n, n_dp = 0;
+        for (int cls = 0; cls < 2; ++cls)
+        for (;;) {
+            int wn, excl, base = 0;
+            const unsigned long long sel = next_round(cls, left, wn, excl, base);
+            if (sel == 0ull) break;
+            // which border does the point at position q = u * 64 + lane belong to: border lanes drop their id at
+            // the position of their first point, a running maximum over the positions spreads it
+#pragma unroll
+            for (int u = 0; u < PP; ++u) dps[u * 64 + lane] = 0u;
+            IRBPP_WAVE_SYNC();
+            if ((sel >> lane) & 1ull) dps[excl - base] = (uint32_t)lane + 1u;
+            IRBPP_WAVE_SYNC();
+            int mark[PP];
+#pragma unroll
+            for (int u = 0; u < PP; ++u) mark[u] = (int)dps[u * 64 + lane];
+            IRBPP_WAVE_SYNC();
+            bool live[PP];
+            int pv[PP], jj[PP], nn[PP], sbq[PP], prk[PP];
+            const uint8_t* pts[PP];
+            int carry = 0;
+#pragma unroll
+            for (int u = 0; u < PP; ++u) {
+                const int run = imax(wave_inclusive_max(mark[u]), carry);
+                carry = __builtin_amdgcn_readlane(run, 63);
+                const int owner = run - 1;                                    // lane that traced this position's border
+                const int on = owner >= 0 ? owner : 0;
+                nn[u] = __shfl(wn, on);
+                sbq[u] = __shfl(excl, on) - base;
+                prk[u] = __shfl(rk, on);
+                live[u] = owner >= 0 && u * 64 + lane < sbq[u] + nn[u];
+                pts[u] = slots + on * SLOT;
+                jj[u] = u * 64 + lane - sbq[u];
+                if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
+                pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
             }
+            if (inline_dp) {
+                approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+            } else {
+                uint8_t* const rec = rec0 + (size_t)n_dp * ROUND_BYTES;       // [pts | n | sb][64 * PP] bytes, then rk words
+#pragma unroll
+                for (int u = 0; u < PP; ++u) {
+                    const int q = u * 64 + lane;
+                    rec[q] = (uint8_t)pv[u];
+                    rec[64 * PP + q] = (uint8_t)(live[u] ? nn[u] : 0);         // 0: no point at this position
+                    rec[2 * 64 * PP + q] = (uint8_t)sbq[u];
+                    ((uint32_t*)(rec + 3 * 64 * PP))[q] = (uint32_t)prk[u];
+                }
+            }
+            if ((sel >> lane) & 1ull) left = 0;
+            ++n_dp;
         }
-        int n_dp = 0;
-        if (__ballot(my_n > 0 && !exported) != 0ull)                  // (uniform)
-            n_dp = approx_lane_borders<PP>(lane, exported ? 0 : my_n, rk, [&](int on) { return (const uint8_t*)(slots + on * SLOT); },
-                                           dps, dpscratch, S.w_vmask);
+        if (inline_dp && n_rounds > 0 && at < round_cap) {            // reserved but unused slots of a full list: no points
+            const int lim = at + n_rounds < round_cap ? n_rounds : round_cap - at;
+            for (int i = 0; i < lim; ++i)
+#pragma unroll
+                for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
+        }
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
             const int b0 = (int)S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW].x;
             long long* row = prof + (size_t)b0 * PHASE_ROW;
@@ -1723,56 +1760,57 @@ extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel(const Params
 extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c32(const Params P, const State S, long long* prof) { trace_body<32>(P, S, prof); }
 extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c16(const Params P, const State S, long long* prof) { trace_body<16>(P, S, prof); }
 
-// ---------------------------------------------------------------------------------------
-// Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
-// ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
-irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
-    L.vmask = (uint32_t*)(smem + P.e_vmask);
-    L.redd = (double*)(smem + P.e_red);
-    L.redi = (int*)(L.redd + 8);
-    L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select, the sort keys, the rows' values
-    L.scratch = smem + P.e_keys;
-    const bool some = mode == MODE_RESET && io.bin_list != nullptr;
-    const int slot = (int)blockIdx.x + io.block_off;
-    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
-    const int tid = threadIdx.x;
-    // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
-    // device error word to the step outputs: every bit of this step was raised by the transition or the trace
-    // kernel, which have completed (the emit kernel raises none).
-    if (blockIdx.x == 0 && tid < NXCD) { S.w_total[tid * XCD_STRIDE] = 0; S.w_bused[tid * XCD_STRIDE] = 0; }
-    if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
-    if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
-    float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
-    const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
-    for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
-    const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
-    int nbord = S.w_bcount[b];                       // the borders the trace kernel listed for this bin
-    nbord = nbord < BORDER_CAP ? nbord : BORDER_CAP;
-    __syncthreads();
-    if (tid == 0) S.w_bcount[b] = 0;                 // (everyone has read it) ready for the next launch
-    // approxPolyDP + find_convex_vetex of the bin's borders: 64 borders per wave and pass, the waves side by side; the
-    // vertex bits join the isolated pixels' (and those of borders the trace kernel approximated itself) in L.vmask
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        uint32_t* const dps = (uint32_t*)(smem + P.e_dps) + wave * (64 * TRACE_P);
-        uint8_t* const dpscratch = smem + P.e_dps + WAVES * 64 * TRACE_P * 4 + wave * (64 * TRACE_P);
-        for (int g = wave * 64; g < nbord; g += WAVES * 64) {
-            const int i = g + lane;
-            uint2 e = make_uint2(0u, 0u);
-            if (i < nbord) e = S.w_bidx[(size_t)b * BORDER_CAP + i];
-            const uint8_t* mine = (const uint8_t*)(S.w_bpool + (size_t)(e.x >> 24) * P.pool_cap + (e.x & 0xFFFFFFu));
-            const int lo = (int)(uint32_t)(uintptr_t)mine, hi = (int)(uint32_t)((uintptr_t)mine >> 32);
-            approx_lane_borders<TRACE_P>(lane, (int)(e.y & 255u), (int)((e.y >> 8) & 7u),
-                                         [&](int on) { return (const uint8_t*)(((uintptr_t)(uint32_t)__shfl(hi, on) << 32) | (uintptr_t)(uint32_t)__shfl(lo, on)); },
-                                         dps, dpscratch, L.vmask);
-        }
+// Split pipeline, after the trace kernel: approxPolyDP + find_convex_vetex of one round of borders per wave
+// (approx_convex_segmented on the 64 * TRACE_P contour points of a record); vertex bits go to the bins' rows in
+// global memory with one atomic OR each.  The rounds of the eight lists are numbered through like the chunks of
+// the trace kernel; every round is the same amount of work, so the waves finish together.
+extern "C" __global__ void __launch_bounds__(64)
+irbpp_polygon_kernel(const Params P, const State S) {
+    constexpr int PP = TRACE_P;
+    __shared__ uint32_t dps[64 * PP];
+    __shared__ uint8_t dpscratch[64 * PP];
+    __shared__ __attribute__((aligned(16))) uint8_t lpts[64 * PP];
+    const int lane = threadIdx.x;
+    const int round_cap = P.round_cap;
+    int seg_n[NXCD], seg_first[NXCD + 1];
+    seg_first[0] = 0;
+#pragma unroll
+    for (int s = 0; s < NXCD; ++s) {
+        const int n = S.w_nround[s * XCD_STRIDE];
+        seg_n[s] = n < round_cap ? n : round_cap;
+        seg_first[s + 1] = seg_first[s] + seg_n[s];
     }
-    __syncthreads();
-    stamp(io, b, 3);
-    emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
+    for (int rd = blockIdx.x; rd < seg_first[NXCD]; rd += gridDim.x) {
+        int seg = 0;
+#pragma unroll
+        for (int s = 1; s < NXCD; ++s) seg += rd >= seg_first[s] ? 1 : 0;
+        int first = 0;
+#pragma unroll
+        for (int s = 0; s < NXCD; ++s) if (s == seg) first = seg_first[s];
+        const uint8_t* const rec = S.w_round + ((size_t)seg * round_cap + (rd - first)) * ROUND_BYTES;
+        bool live[PP];
+        int pv[PP], jj[PP], nn[PP], sbq[PP], prk[PP];
+        const uint8_t* pts[PP];
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            const int q = u * 64 + lane;
+            pv[u] = rec[q];
+            nn[u] = rec[64 * PP + q];
+            sbq[u] = rec[2 * 64 * PP + q];
+            prk[u] = (int)((const uint32_t*)(rec + 3 * 64 * PP))[q];
+            lpts[q] = (uint8_t)pv[u];
+        }
+        IRBPP_WAVE_SYNC();
+#pragma unroll
+        for (int u = 0; u < PP; ++u) {
+            live[u] = nn[u] > 0;
+            jj[u] = u * 64 + lane - sbq[u];
+            if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; pv[u] = 0; }
+            pts[u] = lpts + sbq[u];
+        }
+        approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+        IRBPP_WAVE_SYNC();
+    }
 }
 
 // ---------------------------------------------------------------------------------------

@@ -263,7 +263,7 @@ class GpuPackingEnv(object):
         """Tooling: (LDS bytes per workgroup, name of the transition-kernel build that launches)."""
         lds, name = C.c_int32(0), C.c_char_p()
         _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(name)), "irbpp_debug_kernel_info")
-        return lds.value, name.value.decode() + " + irbpp_trace_kernel + irbpp_emit_kernel"
+        return lds.value, name.value.decode() + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
 
     def enable_kernel_timing(self, capacity: int, every: int = 1) -> None:
         """Tooling: bracket the kernels of the next transitions with HIP events on their stream, ``capacity`` pairs

@@ -203,7 +203,7 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
     every observation, reward and done flag equals the default's, through auto-resets."""
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
-    flags = [_lib.TUNE_TRACE_CPW64, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
+    flags = [_lib.TUNE_TRACE_CPW64 | _lib.TUNE_SPLIT_POLYGON, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
              _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON]
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)] + \
            [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]

@@ -26,7 +26,7 @@ def _problems(text):
 def test_no_use_of_scalar_load_destinations_before_the_wait(disassembly):
     funcs = asmcheck.parse(disassembly)
     for kernel in ("irbpp_env_kernel", "irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide",
-                   "irbpp_trace_kernel", "irbpp_emit_kernel", "irbpp_heuristic_kernel"):
+                   "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel", "irbpp_heuristic_kernel"):
         assert kernel in funcs and len(funcs[kernel]) > 100
     # the pipelined 64-byte list loads are where they are expected (three walk depths x two address forms x three quads)
     for kernel in ("irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide"):

@@ -23,7 +23,7 @@ from irbpp_amd.build import source_hash  # noqa: E402
 
 src, workload, bins = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rev = sys.argv[4] if len(sys.argv) > 4 else ""
-STEP_KERNELS = ("irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_emit_kernel")
+STEP_KERNELS = ("irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel")
 
 
 def agg(sub):
