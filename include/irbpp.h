@@ -84,8 +84,9 @@ typedef struct {
 #define IRBPP_TUNE_TRACE_CPW64   32   /* border following with 64 / 32 / 16 candidate starts per wave whatever the number of */
 #define IRBPP_TUNE_TRACE_CPW32   64   /* bins (default: by the number of bins, see launch_group in irbpp_capi.hip)          */
 #define IRBPP_TUNE_TRACE_CPW16  128
-#define IRBPP_TUNE_INLINE_POLYGON 256 /* every trace wave approximates the borders it followed itself; no polygon kernel  */
-#define IRBPP_TUNE_SPLIT_POLYGON  512 /* ... never, whatever the number of bins (default: inline for launches over few bins) */
+#define IRBPP_TUNE_INLINE_POLYGON 256 /* every trace wave approximates the borders it followed itself; no polygon kernel (the
+                                         path a full record list takes, forced for the parity tests; measured slower at every size) */
+#define IRBPP_TUNE_NO_HEAVY_FIRST 512 /* emit kernel: the bins in launch order, speckled ones not first                        */
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
  * adds on `done` (binPhy.py:299-311,327; monitor.py:58-75).  All device pointers, one entry

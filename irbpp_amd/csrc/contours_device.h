@@ -630,38 +630,23 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         sxy[u] = live[u] ? (int)pts[u][0] : 0;
         fxy[u] = sxy[u];
     }
-    // The arg-max words are never cleared between rounds: a round's keys carry the round's number in their top six bits
-    // (distances fit ten: at most 2 * 15^2), so whatever an earlier round left in a word loses against the first key of
-    // this round, and a word nobody wrote this round is recognised by its stale number.  One clear up front (and one
-    // every 62 rounds, for the pathological recursion depth) instead of a store, a wait and a wave barrier per round.
-    uint32_t round_no = 0u;
-    auto next_round_no = [&]() {
-        if (round_no == 0u || round_no == 63u) {
-#pragma unroll
-            for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
-            IRBPP_WAVE_SYNC();
-            round_no = 0u;
-        }
-        ++round_no;
-    };
     for (int it = 0; it < 3; ++it) {
-        next_round_no();
+#pragma unroll
+        for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
+        IRBPP_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             if (live[u]) {
                 int t = j[u] - pos[u];
                 if (t < 0) t += n[u];
                 const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
-                if (t >= 1) atomicMax(&slots[sb[u]], (round_no << 26) | ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]);
+                if (t >= 1) atomicMax(&slots[sb[u]], ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]);
             }
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
 #pragma unroll
-        for (int u = 0; u < P; ++u) {
-            best[u] = live[u] ? slots[sb[u]] : 0u;
-            best[u] = (best[u] >> 26) == round_no ? best[u] & 0x03FFFFFFu : 0u;      // (a one-point border writes nothing)
-        }
+        for (int u = 0; u < P; ++u) best[u] = live[u] ? slots[sb[u]] : 0u;
         IRBPP_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < P; ++u) {
@@ -695,7 +680,9 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         any_active |= active[u];
     }
     while (__ballot(any_active) != 0ull) {
-        next_round_no();
+#pragma unroll
+        for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
+        IRBPP_WAVE_SYNC();
         int t[P], dx[P], dy[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
@@ -707,13 +694,13 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
                 if (t[u] < 0) t[u] += n[u];
                 int dist = (py[u] - IRBPP_PY(axy[u])) * dx[u] - (px[u] - IRBPP_PX(axy[u])) * dy[u];
                 dist = dist < 0 ? -dist : dist;
-                atomicMax(&slots[sb[u] + ss[u]], (round_no << 26) | ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u]);
+                atomicMax(&slots[sb[u] + ss[u]], ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u]);
             }
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
 #pragma unroll
-        for (int u = 0; u < P; ++u) best[u] = active[u] ? slots[sb[u] + ss[u]] & 0x03FFFFFFu : 0u;      // (every active lane wrote its slice's word)
+        for (int u = 0; u < P; ++u) best[u] = active[u] ? slots[sb[u] + ss[u]] : 0u;
         IRBPP_WAVE_SYNC();
         any_active = false;
 #pragma unroll

@@ -30,6 +30,7 @@ struct irbpp_env {
     bool item_order = false;               // launch slots grouped by observed item, one contiguous range per XCD (generic path)
     long long* phase_cycles = nullptr;
     int32_t* auto_actions = nullptr;       // irbpp_set_auto_policy
+    int heavy_turn = 0;                    // State::w_heavy list of the next observing launch
     int32_t* err_mirror = nullptr;         // irbpp_step_out::err_dev of the last step: every error bit is ORed into it as it is raised
     std::vector<std::pair<const float*, int32_t*>> obs_buffers;   // irbpp_register_obs_buffer: buffer -> rows per bin
     std::vector<hipEvent_t> timing;        // tooling: event pairs around irbpp_env_kernel (ring)
@@ -70,7 +71,6 @@ inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np
 constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
 constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
 constexpr int TRACE_CPW32_BINS = 0;         // ... 32 per wave (0: never; set from the A/B runs in profiles/r04)
-constexpr int INLINE_POLYGON_BINS = 0;      // launches over at most this many bins approximate their borders inside the trace kernel
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
@@ -263,6 +263,9 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
+    P.heavy_cap = P.N >= 64 ? P.N / 8 : 0;                 // expensive bins the emit kernel serves first (generic data only, see launch_group)
+    P.heavy_thr = (P.S * 7) / 10;
+    ALLOC(w_heavy, 2 * (size_t)(XCD_STRIDE + P.heavy_cap));
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }
     {   // identity launch order until an ordering pass writes another one
@@ -550,16 +553,23 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
     // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
     const bool split = env->P.split && observes;
+    // expensive bins first in the emit kernel: free-form level images only (lattice and box data never get there), not for a
+    // listed reset (its observation rows go by list position)
+    const bool heavy_first = split && env->P.heavy_cap > 0 && env->P.block_b == 0 && !env->P.box && io.bin_list == nullptr &&
+                             !(env->cfg.tuning & IRBPP_TUNE_NO_HEAVY_FIRST);
+    io.heavy_turn = heavy_first ? env->heavy_turn : -1;
+    if (heavy_first) env->heavy_turn ^= 1;
     hipLaunchKernelGGL(pick_env_kernel(env).fn, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything
         // beyond (half / a third of either grid with striding measured -4 ... -9 %)
         const int cpw = pick_trace_cpw(env, n), pgrid = 2 * n;
-        // Few bins: the SIMDs idle anyway, so a trace wave runs approxPolyDP on the borders it followed itself (the path a full
-        // record list takes) and the polygon kernel -- a launch, a ramp and a record round trip through L2 -- is not launched.
+        // (IRBPP_TUNE_INLINE_POLYGON: every trace wave runs approxPolyDP on the borders it followed itself -- the path a full
+        // record list takes -- and no polygon kernel is launched.  Measured at 1024 / 2048 / 4096 bins: 11.8 / 20.2 / 28.8 M
+        // steps/s against 13.9 / - / 31.1 M: the approximation stretches the slowest trace waves.  For the parity tests.)
         const int tune = env->cfg.tuning;
-        const bool inline_polygon = (tune & IRBPP_TUNE_INLINE_POLYGON) || (!(tune & IRBPP_TUNE_SPLIT_POLYGON) && n <= INLINE_POLYGON_BINS);
+        const bool inline_polygon = (tune & IRBPP_TUNE_INLINE_POLYGON) != 0;
         Params Pt = env->P;
         if (inline_polygon) Pt.round_cap = 0;
         int tgrid = n * (64 / cpw);
@@ -567,7 +577,8 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
         hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
-        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
+        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P,
+                           env->T, env->S, io, mode);
     }
 }
 

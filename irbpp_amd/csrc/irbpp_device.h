@@ -115,6 +115,8 @@ struct State {
     uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
     uint8_t* w_round;      // [NXCD][round_cap][ROUND_BYTES] round records, trace kernel -> polygon kernel
     int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list
+    int32_t* w_heavy;      // [2][XCD_STRIDE + heavy_cap] bins with many border starts, listed by the transition kernel for the emit kernel
+                           // to serve first: counter, then the bins; two lists used in turn (StepIO::heavy_turn)
     int32_t* w_total;      // [NXCD * XCD_STRIDE] candidates in each XCD's list (XCD-local atomicAdd in the transition kernel, zeroed by the emit kernel)
 };
 
@@ -155,6 +157,7 @@ struct Params {
     int32_t wimg;          // level images a bin can hand over: R * 64
     int32_t seg_cap;       // entries of one XCD's flat candidate list: twice the worst case (R*AC per bin) of its share of the bins
     int32_t round_cap;     // round records of one XCD's list (a full list makes the trace kernel approximate in place)
+    int32_t heavy_cap, heavy_thr;   // bins the emit kernel can serve first (0: off); border starts + isolated pixels that make a bin one of them
     int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
 };
 
@@ -191,6 +194,7 @@ struct StepIO {
     int32_t* err_out;           // optional [1]: copy of the device error word, written by the emit kernel (split pipeline)
     int32_t use_order;          // 1: launch slot -> bin through State::order (bins grouped by observed item per die); 0: identity
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
+    int32_t heavy_turn;         // which of State::w_heavy's two lists this launch fills and serves (-1: none: listed resets, block / box data)
 };
 
 }  // namespace irbpp

@@ -366,7 +366,7 @@ __device__ __forceinline__ uint32_t row_candidates(const uint16_t* rows, int gg,
 }
 
 // first pass over the batch, one thread per (image, row): isolated pixels are marked as vertices on the spot; returns
-// the number of candidate starts of the whole batch.  (The candidates are recomputed by contour_list rather than kept:
+// the number of candidate starts of the whole batch (low 16 bits) and of its isolated pixels (high 16 bits).  (The candidates are recomputed by contour_list rather than kept:
 // IPT words per thread would be IPT more live registers through two barriers.)
 template <int IPT>
 __device__ inline int contour_candidates(const Params& P, const Lds& L, const uint16_t* const rows, int base, int ntasks) {
@@ -379,7 +379,7 @@ __device__ inline int contour_candidates(const Params& P, const Lds& L, const ui
         uint32_t iso;
         const uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
         if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
-        my_count += __popc(cand);
+        my_count += __popc(cand) + (__popc(iso) << 16);
     }
     return block_sum_int(my_count, L.redi);
 }
@@ -422,7 +422,7 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
         contour_images<CONTOUR_IPT>(P, L, L.img, base, true);
         // (a) candidate starts.  The list holds CLIST entries; a batch with more candidates (pathological
         // speckle) is walked one image at a time (an image has at most 64: every other pixel of every other row).
-        const int batch_total = contour_candidates<CONTOUR_IPT>(P, L, L.img, base, ntasks);
+        const int batch_total = contour_candidates<CONTOUR_IPT>(P, L, L.img, base, ntasks) & 0xFFFF;
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
         const int total = contour_list<CONTOUR_IPT>(L, L.img, L.clist, base, ntasks, nsub, sub);
@@ -595,6 +595,31 @@ __device__ __forceinline__ uint32_t wave_or_to_lane63(uint32_t x) {
     return (uint32_t)v;
 }
 
+// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
+// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
+// 0 that a shift brings in from outside the row is the identity of both sum and max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
+    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
+    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
+    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
+    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
+    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+    v = imax(v, dpp_shift<0x111, 0xF>(v));
+    v = imax(v, dpp_shift<0x112, 0xF>(v));
+    v = imax(v, dpp_shift<0x114, 0xF>(v));
+    v = imax(v, dpp_shift<0x118, 0xF>(v));
+    v = imax(v, dpp_shift<0x142, 0xA>(v));
+    v = imax(v, dpp_shift<0x143, 0xC>(v));
+    return v;
+}
+
 // a GCell as ONE 16-byte scalar load (the struct's fields would be fetched one s_load_dword(x2) each)
 typedef int32_t gcell_words __attribute__((ext_vector_type(4)));
 typedef const __attribute__((address_space(4))) gcell_words* ConstGCellPtr;
@@ -607,6 +632,7 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 // PATH: the overlap path compiled in -- one of the three, so that a transition kernel carries (and allocates registers
 // for) only the path its data set takes, or PATH_ANY: decided at run time from Params (heuristic kernel, fallback build).
 enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
+constexpr int GENERIC_TICKET = 40;               // word of Lds::redi that deals the generic path's tasks
 // One footprint cell list walked for G row groups at once (overlap_test's generic path): per cell one 16-byte scalar
 // load (bottom height, byte offset in the tile), per row group one LDS read at lane base + offset, one subtract and
 // one max; four cells (one 64-byte scalar load) per trip, two max chains per row group.
@@ -714,6 +740,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     if (tid < R) L.present[tid] = 0ull;
+    if (tid == 0) L.redi[GENERIC_TICKET] = WAVES;            // generic path: the first WAVES tasks are taken without a ticket
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
@@ -958,28 +985,25 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // general 14.6 -> 14.9 M; SQ_INSTS_VALU of the kernel -14 %).
     // A rotation's groups are split evenly over ceil(groups / gmax) tasks; gmax drops when that would leave waves
     // without a task.
-    int ngrp[8];
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        int n = 0;
-        if (r < R && item >= 0) {
-            const ShapeRot* sp = (const ShapeRot*)srw + r;
-            const int wx = Ax - __builtin_amdgcn_readfirstlane(sp->ax) + 1, wy = Ay - __builtin_amdgcn_readfirstlane(sp->ay) + 1;
-            if (wx > 0 && wy > 0) n = (wx + rpw - 1) >> (6 - ysh);
-        }
-        ngrp[r] = n;
+    // The task table lives in the lanes of every wave, one rotation per lane (lanes 0 .. 7): row groups in range, tasks, tasks
+    // before the rotation.  (As three unrolled 8-element arrays in scalar registers with their select chains it cost the
+    // capped build most of its 137 SGPR spills.)
+    int my_grp = 0;
+    if (lane < R && item >= 0) {
+        const ShapeRot* sp = (const ShapeRot*)srw + lane;
+        const int wx = Ax - sp->ax + 1, wy = Ay - sp->ay + 1;
+        if (wx > 0 && wy > 0) my_grp = (wx + rpw - 1) >> (6 - ysh);
     }
-    int first[9];                                            // tasks before rotation r
-    // (ngrp <= 4 -- an action grid is at most 256 cells, four waves' worth -- so the ceilings are spelled out)
-    int n3 = 0, n2 = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) { n3 += ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0); n2 += (ngrp[r] + 1) >> 1; }
+    // (my_grp <= 4 -- an action grid is at most 256 cells, four waves' worth -- so the ceilings are spelled out)
+    const int t3 = my_grp > 3 ? 2 : (my_grp > 0 ? 1 : 0), t2 = (my_grp + 1) >> 1;
+    const int n3 = __builtin_amdgcn_readlane(wave_inclusive_sum(t3), 63), n2 = __builtin_amdgcn_readlane(wave_inclusive_sum(t2), 63);
     const int gmax = n3 >= WAVES ? 3 : (n2 >= WAVES ? 2 : 1);
-    first[0] = 0;
-#pragma unroll
-    for (int r = 0; r < 8; ++r)
-        first[r + 1] = first[r] + (gmax == 3 ? (ngrp[r] > 3 ? 2 : (ngrp[r] > 0 ? 1 : 0)) : (gmax == 2 ? (ngrp[r] + 1) >> 1 : ngrp[r]));
-    const int ntask = first[8];
+    const int my_tasks = gmax == 3 ? t3 : (gmax == 2 ? t2 : my_grp);
+    const int my_incl = wave_inclusive_sum(my_tasks), my_first = my_incl - my_tasks;          // tasks before this lane's rotation
+    const int ntask = __builtin_amdgcn_readlane(my_incl, 63);
+    auto task_rotation = [&](int t) {                        // the last rotation whose tasks start at or before t
+        return __popcll(__ballot(lane >= 1 && lane < 8 && t >= my_first));
+    };
     int pref = 0;
     auto task_finish = [&](int r, int X, int s_ax, int s_ay, double ext_z_r, double z) {
         const bool in_range = X <= Ax - s_ax && Y <= Ay - s_ay;
@@ -1021,14 +1045,19 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const char* lv = (const char*)(T.gcell + ob);
         for (int o = lane * 128; o < nb * 16; o += 64 * 128) pref |= *(const int*)(lv + o);
     };
-    for (int rep = 0; rep < IRBPP_REPS(2); ++rep)
-    for (int t = wave; t < ntask; t += WAVES) {
-        int r = 0;
-#pragma unroll
-        for (int q = 1; q < 8; ++q) r += t >= first[q] ? 1 : 0;
-        int tq = t, ng = 0, nt = 1;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) if (q == r) { tq = t - first[q]; ng = ngrp[q]; nt = first[q + 1] - first[q]; }
+    for (int t = wave, mine = 0; ; ++mine) {
+        // Tasks are dealt by a ticket in LDS: a wave that drew a short list (or few row groups) comes back for the next task
+        // while the others are still walking (the static deal t = wave, wave + 4, ... was 8 % off an even split).  The first
+        // task of a wave is its own number: no round trip before the first walk.
+        if (mine > 0) {
+            int tk = 0;
+            if (lane == 0) tk = atomicAdd(&L.redi[GENERIC_TICKET], 1);
+            t = __builtin_amdgcn_readfirstlane(tk);
+        }
+        if (t >= ntask) break;
+        const int r = task_rotation(t);
+        const int tq = t - __builtin_amdgcn_readlane(my_first, r), ng = __builtin_amdgcn_readlane(my_grp, r);
+        const int nt = __builtin_amdgcn_readlane(my_tasks, r);
         // even split of ng groups over nt tasks: the first ng % nt tasks take one more
         const int base = nt == 1 ? ng : (nt == ng ? 1 : ng >> 1), rem = ng - base * nt;   // (nt is 1, 2 or ng)
         const int G = base + (tq < rem ? 1 : 0), g0 = tq * base + (tq < rem ? tq : rem);
@@ -1045,12 +1074,9 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         // its ShapeRots, before the placement is applied -- was measured and is worse: abc_fine 7.1 -> 6.9 M, general
         // 14.6 -> 14.1 M; the lines do not survive in L2 until they are needed, and the kept-alive register costs the
         // kernel its seventh wave per SIMD.)
-        if (t == wave) prefetch_list(ob, nb);
-        if (t + WAVES < ntask) {
-            const int tn = t + WAVES;
-            int rn = 0;
-#pragma unroll
-            for (int q = 1; q < 8; ++q) rn += tn >= first[q] ? 1 : 0;
+        if (mine == 0) prefetch_list(ob, nb);
+        if (t + WAVES < ntask) {                             // (whoever draws it: the list is pulled into this die's L2)
+            const int rn = task_rotation(t + WAVES);
             if (rn != r) {
                 const ShapeRot* sn = (const ShapeRot*)srw + rn;
                 prefetch_list(__builtin_amdgcn_readfirstlane(sn->ob), __builtin_amdgcn_readfirstlane(sn->nb));
@@ -1422,7 +1448,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     }
     int ntasks = 0;
     for (int rep = 0; rep < IRBPP_REPS(9); ++rep) { if (rep) __syncthreads(); ntasks = contour_tasks(P, L); }
-    int ncand = 0;
+    int ncand = 0, niso = 0;
     uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 16);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
     const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));     // HW_REG_XCC_ID: the die this workgroup runs on
@@ -1432,6 +1458,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
             contour_images<IPT>(P, L, rows, base, false);
             batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks);
         }
+        niso += batch_total >> 16;
+        batch_total &= 0xFFFF;
         const int nb = ntasks - base < IMGS ? ntasks - base : IMGS;
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)rows;
@@ -1484,6 +1512,19 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         m[1] = ncand;
         m[2] = nvalid;
         m[3] = item;
+        // A bin with many border starts (speckled level images) is a bin whose observation is expensive: more than S
+        // candidates mean a radix select and a sort, five times the time of an ordinary bin, and the emit kernel lasts as
+        // long as the last of them.  Such bins enter a list that the emit kernel serves FIRST (its leading workgroups); the
+        // count of starts + isolated pixels tracks the number of candidates closely (r = 0.997 on the "general" data set, every
+        // bin with more than S candidates has >= 390 of them against a median of 107).
+        int heavy = 0;
+        const int turn = ka->io.heavy_turn;
+        if (turn >= 0 && ncand + niso >= P.heavy_thr) {
+            int32_t* hv = ka->S.w_heavy + (size_t)turn * (XCD_STRIDE + P.heavy_cap);
+            const int pos = atomicAdd(hv, 1);
+            if (pos < P.heavy_cap) { hv[XCD_STRIDE + pos] = b; heavy = 1; }
+        }
+        m[4] = heavy;
     }
 }
 
@@ -1500,14 +1541,30 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     L.img = (uint16_t*)(smem + P.e_hist);            // the 256 counters of the radix select, the sort keys, the rows' values
     L.scratch = smem + P.e_keys;
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;
-    const int slot = (int)blockIdx.x + io.block_off;
-    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     // Workgroup 0 also retires the launch's flat candidate list (the trace kernel is done with it) and hands the
     // device error word to the step outputs: every bit of this step was raised by the transition or the trace
     // kernel, which have completed (the emit kernel raises none).
     if (blockIdx.x == 0 && tid < NXCD) { S.w_total[tid * XCD_STRIDE] = 0; S.w_nround[tid * XCD_STRIDE] = 0; }
     if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
+    // The grid's first heavy_cap workgroups serve the bins the transition kernel listed as expensive (see split_handover),
+    // the rest the bins in launch order minus those: the expensive ones start at once instead of wherever their index
+    // puts them.  The list of the next launch (the other one of two, used in turn) is cleared here.
+    const int hg = io.heavy_turn >= 0 ? P.heavy_cap : 0;
+    int slot, b;
+    if ((int)blockIdx.x < hg) {
+        const int32_t* hv = S.w_heavy + (size_t)io.heavy_turn * (XCD_STRIDE + P.heavy_cap);
+        if (blockIdx.x == 0 && tid == 0) S.w_heavy[(size_t)(io.heavy_turn ^ 1) * (XCD_STRIDE + P.heavy_cap)] = 0;
+        int cnt = hv[0];
+        cnt = cnt < P.heavy_cap ? cnt : P.heavy_cap;
+        if ((int)blockIdx.x >= cnt) return;
+        b = hv[XCD_STRIDE + blockIdx.x];
+        slot = b;
+    } else {
+        slot = (int)blockIdx.x - hg + io.block_off;
+        b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+        if (hg > 0 && b >= 0 && b < P.N && S.w_meta[(size_t)b * WMETA + 4] != 0) return;       // served by a leading workgroup
+    }
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
     const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
@@ -1528,31 +1585,6 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
 // follows its border (trace_border), and the wave then runs approx_convex_segmented on all the closed borders,
 // 128 contour points per round; vertex bits go to the bins' rows in global memory with one atomic OR each.
 // ---------------------------------------------------------------------------------------
-// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
-// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
-// 0 that a shift brings in from outside the row is the identity of both sum and max.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
-__device__ __forceinline__ int wave_inclusive_sum(int v) {
-    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
-    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
-    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
-    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
-    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
-    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int wave_inclusive_max(int v) {
-    v = imax(v, dpp_shift<0x111, 0xF>(v));
-    v = imax(v, dpp_shift<0x112, 0xF>(v));
-    v = imax(v, dpp_shift<0x114, 0xF>(v));
-    v = imax(v, dpp_shift<0x118, 0xF>(v));
-    v = imax(v, dpp_shift<0x142, 0xA>(v));
-    v = imax(v, dpp_shift<0x143, 0xC>(v));
-    return v;
-}
-
 #ifndef IRBPP_TRACE_P
 #define IRBPP_TRACE_P 2
 #endif

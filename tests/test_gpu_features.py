@@ -198,13 +198,13 @@ def test_item_grouped_launch_order_changes_nothing():
 
 @pytest.mark.parametrize("workload,n,steps", [("blockout", 160, 120), ("general", 96, 45)])
 def test_trace_launch_shapes_change_nothing(workload, n, steps):
-    """The launch shapes the library picks by the number of bins -- 64 / 32 / 16 candidate starts per trace wave, borders
-    approximated by the polygon kernel or inside the trace kernel -- forced one by one through irbpp_config::tuning:
-    every observation, reward and done flag equals the default's, through auto-resets."""
+    """The launch shapes the library can take -- 64 / 32 / 16 candidate starts per trace wave, borders approximated by the
+    polygon kernel or inside the trace kernel, speckled bins first in the emit kernel or in launch order -- forced one by
+    one through irbpp_config::tuning: every observation, reward and done flag equals the default's, through auto-resets."""
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
-    flags = [_lib.TUNE_TRACE_CPW64 | _lib.TUNE_SPLIT_POLYGON, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
-             _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON]
+    flags = [_lib.TUNE_TRACE_CPW64, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
+             _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON, _lib.TUNE_NO_HEAVY_FIRST]
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)] + \
            [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     obs = [e.reset() for e in envs]
