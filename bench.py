@@ -460,7 +460,7 @@ def main():
 
     # Extra measurements on one GPU (never `value`): the same bins as four independent groups on four HIP streams
     # (vec_env.GroupedPackingEnv: one group's straggler workgroups overlap the next group's kernels; how much that gives
-    # depends on how the runtime maps the streams onto its hardware queues, hence the better of two instances),
+    # depends on how the runtime maps the streams onto its hardware queues, hence two instances, both reported),
     # north_star's 8192 bins on one GPU, the other BASELINE configs at their per-GPU sizes, and the rate a user of the
     # reference-facing VecEnv API gets.
     extra, grouped = None, None
@@ -468,14 +468,25 @@ def main():
         extra = {}
         if workload == "blockout" and groups == 1 and bins % 4 == 0 and bins >= 2048:
             runs = [side_run(workload, bins, 4, 0.3) for _ in range(2)]
-            grouped = max(runs, key=lambda r: r["value"])
-            grouped["note"] = "better of two instances; see bench.py"
+            grouped = dict(runs[0])                             # BOTH instances: how the runtime maps four streams onto its
+            grouped["value"] = float(np.mean([r["value"] for r in runs]))    # hardware queues varies from one to the next
+            grouped["ms_per_step"] = float(np.mean([r["ms_per_step"] for r in runs]))
+            grouped["instances"] = [r["value"] for r in runs]
+            grouped["note"] = "mean of two instances (both listed); see bench.py"
         if workload == "blockout":
             if bins != 8192:
                 extra["bins8192_one_gpu"] = side_run("blockout", 8192)
             extra["cfg3_general_4096"] = side_run("general", 4096)
             extra["cfg4_blockout_k10_1024_per_gpu"] = side_run("blockout_k10", 1024)
             extra["cfg5_abc_fine_2048_per_gpu"] = side_run("abc_fine", 2048)
+            # the sharded configs at their per-GPU sizes again, stepped as independent groups of bins on their own streams
+            # (vec_env.groups_for): a launch over so few bins leaves most of the chip idle, and groups overlap each other's kernels
+            from irbpp_amd.vec_env import groups_for
+            for key, wl, nb in (("cfg3_general_4096", "general", 4096), ("cfg4_blockout_k10_1024_per_gpu", "blockout_k10", 1024),
+                                ("cfg5_abc_fine_2048_per_gpu", "abc_fine", 2048)):
+                g = groups_for(wl, nb)
+                if g > 1:
+                    extra[key + f"_grouped"] = side_run(wl, nb, g)
             extra["cfg1_cube_4096"] = side_run("cube", 4096)
             extra["vecenv_step"] = vecenv_rate(4096, dev)
 

@@ -33,6 +33,27 @@ def _tool(name):
     raise RuntimeError(f"{name} not found")
 
 
+def scratch_sizes(so_path):
+    """{kernel: bytes of scratch (private segment) per lane} from the code object's metadata notes."""
+    with tempfile.TemporaryDirectory() as tmp:
+        fat, co = os.path.join(tmp, "fat.bin"), os.path.join(tmp, "dev.co")
+        subprocess.run([_tool("llvm-objcopy"), "--dump-section", f".hip_fatbin={fat}", so_path, os.path.join(tmp, "copy.so")],
+                       check=True, capture_output=True)
+        subprocess.run([_tool("clang-offload-bundler"), "--unbundle", "--type=o", f"--input={fat}",
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", f"--output={co}"], check=True, capture_output=True)
+        notes = subprocess.run([_tool("llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True).stdout
+    out, name = {}, None
+    for line in notes.splitlines():
+        line = line.strip()
+        if line.startswith(".name:"):
+            name = line.split(":", 1)[1].strip()
+        elif line.startswith(".private_segment_fixed_size:") and name is not None:
+            out[name] = int(line.split(":", 1)[1])
+        elif line.startswith("- .") or line.startswith("- .agpr_count"):
+            pass
+    return out
+
+
 def disassemble(so_path):
     """llvm-objdump -d of the gfx950 code object bundled in the library's .hip_fatbin section."""
     with tempfile.TemporaryDirectory() as tmp:

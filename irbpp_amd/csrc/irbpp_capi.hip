@@ -577,8 +577,8 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
         hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
-        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P,
-                           env->T, env->S, io, mode);
+        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T,
+                           env->S, io, mode);
     }
 }
 

@@ -29,7 +29,10 @@ constexpr int CONTOUR_IPT = IRBPP_CONTOUR_IPT;
 constexpr int WMETA = 8;
 constexpr int NXCD = 8;                            // accelerator dies of the MI355X: one flat candidate list each
 constexpr int XCD_STRIDE = 64;                     // ints between the lists' counters: a 256-byte line each
-constexpr int ROUND_POINTS = 128, ROUND_BYTES = ROUND_POINTS * 7;   // a round record of the polygon kernel: [points | border length | border
+#ifndef IRBPP_TRACE_P
+#define IRBPP_TRACE_P 2                            // contour points per lane of a polygon round (A/B: 4 measured in profiles/r04)
+#endif
+constexpr int ROUND_POINTS = 64 * IRBPP_TRACE_P, ROUND_BYTES = ROUND_POINTS * 7;   // a round record of the polygon kernel: [points | border length | border
                                                                      // start] per position, then the vertex-row index of the position's border
 constexpr int MAX_BINS = 1 << 20;                 // bins per device (irbpp_create refuses more): keeps every per-launch index an int32
 

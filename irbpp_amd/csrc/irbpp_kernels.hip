@@ -1531,9 +1531,12 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // ---------------------------------------------------------------------------------------
 // Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))
-irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+// HEAVY_FIRST: the grid may lead with the workgroups of the speckled bins (StepIO::heavy_turn >= 0: free-form level images).
+// One build serves all data: with this code in, the register allocator happens to fit the kernel into its 64 VGPRs; the
+// build without it spilled four of them and cost the BlockOut step 1.1 us (19.1 vs 18.0 us, profiles/r04/s8) --
+// tests/test_kernel_asm.py watches the scratch sizes of the step's kernels.
+template <bool HEAVY_FIRST>
+__device__ __forceinline__ void emit_body(const Params P, const Tables T, const State S, const StepIO io, const int mode, unsigned char* smem) {
     Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
     L.vmask = (uint32_t*)(smem + P.e_vmask);
     L.redd = (double*)(smem + P.e_red);
@@ -1550,20 +1553,27 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     // The grid's first heavy_cap workgroups serve the bins the transition kernel listed as expensive (see split_handover),
     // the rest the bins in launch order minus those: the expensive ones start at once instead of wherever their index
     // puts them.  The list of the next launch (the other one of two, used in turn) is cleared here.
-    const int hg = io.heavy_turn >= 0 ? P.heavy_cap : 0;
-    int slot, b;
-    if ((int)blockIdx.x < hg) {
-        const int32_t* hv = S.w_heavy + (size_t)io.heavy_turn * (XCD_STRIDE + P.heavy_cap);
-        if (blockIdx.x == 0 && tid == 0) S.w_heavy[(size_t)(io.heavy_turn ^ 1) * (XCD_STRIDE + P.heavy_cap)] = 0;
-        int cnt = hv[0];
-        cnt = cnt < P.heavy_cap ? cnt : P.heavy_cap;
-        if ((int)blockIdx.x >= cnt) return;
-        b = hv[XCD_STRIDE + blockIdx.x];
-        slot = b;
-    } else {
-        slot = (int)blockIdx.x - hg + io.block_off;
+    int slot = (int)blockIdx.x + io.block_off, b = 0;
+    bool mapped = false;
+    if constexpr (HEAVY_FIRST) {
+        const int hg = io.heavy_turn >= 0 ? P.heavy_cap : 0;
+        if ((int)blockIdx.x < hg) {
+            const int32_t* hv = S.w_heavy + (size_t)io.heavy_turn * (XCD_STRIDE + P.heavy_cap);
+            if (blockIdx.x == 0 && tid == 0) S.w_heavy[(size_t)(io.heavy_turn ^ 1) * (XCD_STRIDE + P.heavy_cap)] = 0;
+            int cnt = hv[0];
+            cnt = cnt < P.heavy_cap ? cnt : P.heavy_cap;
+            if ((int)blockIdx.x >= cnt) return;
+            b = hv[XCD_STRIDE + blockIdx.x];
+            slot = b;
+            mapped = true;
+        } else {
+            slot -= hg;
+        }
+    }
+    if (!mapped) {
         b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
-        if (hg > 0 && b >= 0 && b < P.N && S.w_meta[(size_t)b * WMETA + 4] != 0) return;       // served by a leading workgroup
+        if constexpr (HEAVY_FIRST)
+            if (io.heavy_turn >= 0 && b >= 0 && b < P.N && S.w_meta[(size_t)b * WMETA + 4] != 0) return;       // served by a leading workgroup
     }
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
@@ -1574,6 +1584,13 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
     stamp(io, b, 3);
     emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
 }
+#define IRBPP_EMIT_KERNEL(NAME, HF)                                                                                      \
+    extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))                      \
+    NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                              \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                            \
+        emit_body<HF>(P, T, S, io, mode, smem);                                                                         \
+    }
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel, true)
 
 // ---------------------------------------------------------------------------------------
 // Split pipeline, middle kernels: border following + approxPolyDP + convexity over the candidate starts of ALL
@@ -1585,9 +1602,6 @@ irbpp_emit_kernel(const Params P, const Tables T, const State S, const StepIO io
 // follows its border (trace_border), and the wave then runs approx_convex_segmented on all the closed borders,
 // 128 contour points per round; vertex bits go to the bins' rows in global memory with one atomic OR each.
 // ---------------------------------------------------------------------------------------
-#ifndef IRBPP_TRACE_P
-#define IRBPP_TRACE_P 2
-#endif
 #ifndef IRBPP_TRACE_SHORT
 #define IRBPP_TRACE_SHORT 0
 #endif

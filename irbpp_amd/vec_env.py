@@ -449,6 +449,20 @@ class GroupedPackingEnv(object):
             e.close()
 
 
+def groups_for(workload_kind: str, num_bins: int) -> int:
+    """How many independent groups of bins (GroupedPackingEnv / GpuVecEnv(num_groups=...)) a caller without a preference
+    should step ``num_bins`` bins as.  Measured on one MI355X (profiles/r04/s1, s7): the heavy transition kernels of
+    free-form data (``"general"``, ``"abc_fine"``: 128 / 400 us per launch) overlap well -- general 15.1 -> 17.8 M steps/s
+    with 2 groups at 4096 bins, abc_fine 5.6 -> 6.2 / 6.7 M with 2 / 4 groups at 2048 -- whereas a buffered BlockOut step
+    at 1024 bins is a chain of six short latency-bound kernels whose length does not depend on the number of bins:
+    groups change nothing there (10.8 / 11.0 / 6.1 M for 1 / 2 / 4 groups, the last one hit by stream-to-queue aliasing).
+    Lattice data at full width gains from four groups (29.0 -> 35.3 M at 4096 bins) when the caller can work on one
+    group while the others step; ``value`` of bench.py stays the one-group figure."""
+    if workload_kind in ("general", "abc_fine") and num_bins >= 1024 and num_bins % 4 == 0:
+        return 4 if workload_kind == "abc_fine" else 2
+    return 1
+
+
 class _Infos(Sequence):
     """The ``infos`` sequence of step_wait, materialised lazily: N dicts per step would cost more
     host time than the whole GPU step.  infos[i] -> {'Valid': True} plus, where done,

@@ -52,35 +52,37 @@ def perturbed(shapes, seed, ulps=1):
 def run(workload, bins, steps, seed):
     shapes, seqs, kw = bench.make_workload(workload)
     pert, moved = perturbed(shapes, seed)
-    a = COracleVecEnv(bins, shapes, seqs, **kw)
-    b = COracleVecEnv(bins, pert, seqs, **kw)
-    oa, ob = a.reset(), b.reset()
-    alive = np.ones(bins, dtype=bool)                      # this episode has been identical so far
+    # the raw games (no auto-reset): both sides are reset together, exactly once per episode of the original, so that they
+    # always play the same trajectory
+    a = COracleVecEnv(bins, shapes, seqs, **kw).envs
+    b = COracleVecEnv(bins, pert, seqs, **kw).envs
+    oa = [g.reset() for g in a]
+    ob = [g.reset() for g in b]
     episodes = diverged = same_steps = 0
     first = []
-    age = np.zeros(bins, dtype=int)
-    for t in range(steps):
-        act = [minz(o) for o in oa]
-        oa, ra, da, _ = a.step(act)
-        ob, rb, db, _ = b.step(act)
-        eq = (oa.astype(np.float32) == ob.astype(np.float32)).all(axis=1) & (ra == rb) & (da == db)
-        age += 1
-        newly = alive & ~eq
-        diverged += int(newly.sum())
-        first += list(age[newly])
-        same_steps += int((alive & eq).sum())
-        alive &= eq
-        for i in np.nonzero(da)[0]:                        # the original's episode ended: both sides start over
-            episodes += 1
-            if not db[i] or not alive[i]:
-                b.envs[i].reset()                          # (b's auto-reset already ran if it ended too; a fresh one either way)
-            alive[i] = True
-            age[i] = 0
-        # re-align b on a after an episode end on a's side only
-        for i in np.nonzero(da & ~db)[0]:
-            ob[i] = b.envs[i].reset()
-    return {"workload": workload, "bins": bins, "steps": steps, "table_entries_moved": moved, "episodes": episodes,
-            "episodes_diverged": diverged, "identical_bin_steps": same_steps,
+    for i in range(bins):
+        alive, b_over, age = True, False, 0
+        for t in range(steps):
+            act = minz(oa[i])
+            oa[i], ra, da, _ = a[i].step(act)
+            if not b_over:
+                ob[i], rb, db, _ = b[i].step(act)
+                b_over = db
+                eq = bool((oa[i].astype(np.float32) == ob[i].astype(np.float32)).all()) and ra == rb and da == db
+            else:
+                eq = False
+            age += 1
+            if alive and not eq:
+                diverged += 1
+                first.append(age)
+            same_steps += int(alive and eq)
+            alive = alive and eq
+            if da:
+                episodes += 1
+                oa[i], ob[i] = a[i].reset(), b[i].reset()
+                alive, b_over, age = True, False, 0
+    return {"workload": workload, "bins": bins, "steps_per_bin": steps, "table_entries_moved": moved, "episodes": episodes,
+            "episodes_diverged": diverged, "identical_bin_steps": same_steps, "bin_steps": bins * steps,
             "median_steps_to_divergence": float(np.median(first)) if first else None}
 
 

@@ -46,3 +46,16 @@ def test_checker_sees_an_injected_hazard(disassembly):
     assert done == 1
     probs = _problems("\n".join(out))
     assert len(probs) == 1 and "destination touched before lgkmcnt(0)" in probs[0]
+
+
+def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
+    """Bytes of scratch per lane, from the code object's metadata.  The 64-VGPR / 96-SGPR cap of the eight-wave builds makes
+    the register allocation touchy (round 4: one variant of the emit kernel spilled four VGPRs and cost the BlockOut step
+    1.1 us): a build that spills more than the state the profiles were taken on fails here instead of shipping."""
+    sizes = asmcheck.scratch_sizes(build.build(force=False))
+    limits = {"irbpp_emit_kernel": 0, "irbpp_trace_kernel": 0, "irbpp_trace_kernel_c32": 0, "irbpp_trace_kernel_c16": 0,
+              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 12, "irbpp_env_kernel_box8": 12, "irbpp_env_kernel_generic8": 28,
+              "irbpp_env_kernel_generic": 0, "irbpp_env_kernel_box": 0, "irbpp_env_kernel_wide": 0}
+    for kernel, limit in limits.items():
+        assert kernel in sizes, kernel
+        assert sizes[kernel] <= limit, (kernel, sizes[kernel], limit)
