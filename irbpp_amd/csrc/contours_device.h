@@ -606,6 +606,35 @@ __device__ inline void cleanup_convex_serial(uint8_t* dst, int cnt, uint32_t* vr
     }
 }
 
+// Arg-max keys of one segment pre-reduced inside each row of 16 lanes before they meet in LDS.  Lanes next to each other
+// that carry the same segment (`seg` >= 0: the segment's arg-max word; -1: no key) form a run; four row shifts on the DPP
+// network give every lane the maximum of its run up to itself, and only the run's last lane of the row (`tail`) sends its
+// key to the word with ds_max_u32.  A segment then costs at most a handful of LDS atomics instead of one per point: all
+// points of a border (hop rounds) or a slice (Douglas-Peucker rounds) hitting ONE word were serialised by the LDS, which
+// made 66 % of the polygon kernel's LDS cycles bank conflicts and the LDS, busy for two thirds of the kernel's duration,
+// its bottleneck (profiles/r03/final/sq2_summary.json).  Any way of combining keys of one segment is right (the result is
+// their maximum; keys are unique), so a wrapped slice -- two runs of one segment -- needs no special care.
+// MEASURED AND NOT TAKEN (profiles/r04/s10, build with -DIRBPP_AB_ROW_ARGMAX): the conflict share of the polygon kernel's LDS
+// cycles fell from 66 % to 15 % and its LDS cycles by 58 %, and the kernel got SLOWER, 24.1 -> 27.9 us on BlockOut and
+// 26.9 -> 33.3 us on "general": it is bound by its vector instructions (4.4 cycles each per SIMD), and the ~21 added per
+// point set and round cost more than the serialised atomics did -- the LDS takes those in its stride.
+#if defined(__HIP_DEVICE_COMPILE__) && defined(IRBPP_AB_ROW_ARGMAX)
+__device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) {
+#define IRBPP_ROW_STEP(CTRL)                                                                                      \
+    {                                                                                                             \
+        const int pseg = __builtin_amdgcn_update_dpp(-2, seg, CTRL, 0xF, 0xF, false);                             \
+        const uint32_t pkey = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, CTRL, 0xF, 0xF, false);          \
+        key = pseg == seg ? (pkey > key ? pkey : key) : key;                                                      \
+    }
+    IRBPP_ROW_STEP(0x111) IRBPP_ROW_STEP(0x112) IRBPP_ROW_STEP(0x114) IRBPP_ROW_STEP(0x118)      // row_shr:1, 2, 4, 8
+#undef IRBPP_ROW_STEP
+    const int nseg = __builtin_amdgcn_update_dpp(-2, seg, 0x101, 0xF, 0xF, false);                // row_shl:1: my right neighbour's
+    tail = seg >= 0 && nseg != seg;
+}
+#else
+__device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) { tail = seg >= 0; }       // every key goes to its word
+#endif
+
 // A wave serves 64 * P contour points per round: position q = u * 64 + lane, u < P, borders packed back to
 // back over the positions (a border of up to 64 * P points fits).  Per position:
 //   live: a point sits here;  pv: the point (x | y<<4);  j, n: its index in / the size of its border;
@@ -634,14 +663,24 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
+        int hseg[P];
+        uint32_t hkey[P];
+#pragma unroll
+        for (int u = 0; u < P; ++u) { hseg[u] = -1; hkey[u] = 0u; }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             if (live[u]) {
                 int t = j[u] - pos[u];
                 if (t < 0) t += n[u];
                 const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
-                if (t >= 1) atomicMax(&slots[sb[u]], ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]);
+                if (t >= 1) { hseg[u] = sb[u]; hkey[u] = ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]; }
             }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {                        // (all lanes: the row shifts read their neighbours)
+            bool tail;
+            row_run_max(hseg[u], hkey[u], tail);
+            if (tail) atomicMax(&slots[hseg[u]], hkey[u]);
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
@@ -683,10 +722,13 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
-        int t[P], dx[P], dy[P];
+        int t[P], dx[P], dy[P], dseg[P];
+        uint32_t dkey[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             t[u] = dx[u] = dy[u] = 0;
+            dseg[u] = -1;
+            dkey[u] = 0u;
             if (active[u]) {
                 dx[u] = IRBPP_PX(bxy[u]) - IRBPP_PX(axy[u]);
                 dy[u] = IRBPP_PY(bxy[u]) - IRBPP_PY(axy[u]);
@@ -694,8 +736,15 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
                 if (t[u] < 0) t[u] += n[u];
                 int dist = (py[u] - IRBPP_PY(axy[u])) * dx[u] - (px[u] - IRBPP_PX(axy[u])) * dy[u];
                 dist = dist < 0 ? -dist : dist;
-                atomicMax(&slots[sb[u] + ss[u]], ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u]);
+                dseg[u] = sb[u] + ss[u];
+                dkey[u] = ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u];
             }
+        }
+#pragma unroll
+        for (int u = 0; u < P; ++u) {
+            bool tail;
+            row_run_max(dseg[u], dkey[u], tail);
+            if (tail) atomicMax(&slots[dseg[u]], dkey[u]);
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];

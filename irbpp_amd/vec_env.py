@@ -487,7 +487,8 @@ class _Infos(Sequence):
 class GpuVecEnv(object):
     """Drop-in for ``VecPyTorch(ShmemVecEnv(...))`` as the trainer uses it (trainer.py:148,165,267,281).
 
-    ``obs_ring`` (default 3): observations are written into a ring of that many buffers owned by the environment
+    ``obs_ring`` (default 3; ``make_vec_envs`` -- the drop-in constructor -- passes 0 unless ``args.obs_ring`` says
+    otherwise): observations are written into a ring of that many buffers owned by the environment
     and, for online environments, registered with the library (``irbpp_register_obs_buffer``: only the candidate
     rows that exist are stored), instead of a fresh allocation with a full rewrite per step.  The tensor a call
     returns is therefore overwritten ``obs_ring`` observation-producing calls later -- the trainer keeps ``state``
@@ -763,8 +764,11 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
         sequences, kw["item_stream"] = feeder.initial, 1
     # (args.num_groups is not a reference argument: > 1 steps the envs as that many independent groups on their own HIP
     # streams, item streams included -- GroupedPackingEnv)
+    # args.obs_ring (not a reference argument either): 0 (default here) = every call returns a fresh observation tensor, the
+    # reference's behaviour; 3 = the ring of library-registered buffers GpuVecEnv uses by default (+10 % step rate; an
+    # observation is overwritten three calls later, which the reference's trainer never notices)
     envs = GpuVecEnv(shapes, sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
-                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 1)), **kw)
+                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 1)), obs_ring=int(getattr(args, "obs_ring", 0)), **kw)
     return envs, [envs.observation_space, envs.action_space], envs.obs_len
 
 

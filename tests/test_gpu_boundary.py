@@ -193,3 +193,32 @@ def test_adversarial_level_images_through_transition_trace_polygon_emit():
     assert big >= 8
     genv.env.check_device_error()
     genv.close()
+
+
+def test_make_vec_envs_hands_out_observations_that_stay():
+    """The drop-in constructor returns a fresh observation tensor per call like the reference's VecPyTorch (envs.py:149-165):
+    a caller may keep every state of a rollout.  (GpuVecEnv's own default, a ring of three registered buffers, recycles
+    them: the opt-in `args.obs_ring`.)"""
+    from oracle.c_oracle import COracleVecEnv as CO
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    args = types.SimpleNamespace(
+        num_processes=8, device=0, seed=1, shapes=sh, sequences=seqs, resolutionA=0.02, resolutionH=0.01, resolutionZ=0.01,
+        bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S, bufferSize=1, scale=[100, 100, 100], evaluate=True)
+    envs, _, _ = make_vec_envs(args, "./logs/runinfo", True)
+    cenv = CO(8, sh, seqs)
+    states = [envs.reset()]
+    want = [_f32(cenv.reset())]
+    for t in range(12):
+        act = envs.env.policy_minz(states[-1]).cpu().numpy()
+        obs, _, _, _ = envs.step(act)
+        states.append(obs)
+        want.append(_f32(cenv.step(act)[0]))
+    for got, ref in zip(states, want):                                      # every state of the rollout, looked at afterwards
+        np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    assert len({s.data_ptr() for s in states}) == len(states)
+    envs.close()
+    ring = GpuVecEnv(sh, seqs, 8, device=DEV)                                # the opt-in: three buffers in turn
+    ptrs = [ring.reset().data_ptr()] + [ring.step(np.zeros(8, dtype=np.int64))[0].data_ptr() for _ in range(5)]
+    assert len(set(ptrs)) == 3
+    ring.close()
