@@ -1,9 +1,9 @@
 #!/bin/bash
-# Tooling: fold gpurun_out/final (written by tools/_final.sh on the GPU box) into profiles/r03/final and
+# Tooling: fold gpurun_out/final (written by tools/_final.sh on the GPU box) into profiles/r04/final and
 # profiles/pmc_hbm.json.   bash tools/fold_final.sh [<git rev the session ran on>]
 set -e
 cd "$(dirname "$0")/.."
-S=gpurun_out/final; D=profiles/r03/final; REV=${1:-$(git rev-parse --short HEAD)}
+S=gpurun_out/final; D=profiles/r04/final; REV=${1:-$(git rev-parse --short HEAD)}
 mkdir -p $D/other_workloads
 for f in bench_default.json bench_driver_style.json pytest_gpu.txt trace_blockout.json phase_blockout.json phase_general.json \
          phase_abc_fine.json phase_cube.json; do cp $S/$f $D/$f; done
