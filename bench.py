@@ -422,7 +422,10 @@ def main():
     shapes, seqs, kw = make_workload(workload)
     if a.tuning:
         kw["tuning"] = a.tuning
-    groups = a.groups if a.groups > 0 else 1               # `value`: ONE group = one launch per kernel over all bins
+    # `value` (cfg 2, the headline) is ONE group = one launch per kernel over all bins; north_star's sharded configs, whose
+    # per-GPU launches are small, take the number of groups the library recommends for their data and size unless --groups says otherwise
+    from irbpp_amd.vec_env import groups_for
+    groups = a.groups if a.groups > 0 else (groups_for(workload, bins) if a.config in ("cfg4", "cfg5") else 1)
     env = GroupedPackingEnv(shapes, seqs, bins, groups, device=dev, **D.shard(rank, world, bins), **kw)
     hc = env.Hx * env.Hy
     k = int(kw.get("bufferSize", 1))

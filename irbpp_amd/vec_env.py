@@ -501,10 +501,16 @@ class GpuVecEnv(object):
     def __init__(self, shapes: ShapeSet, sequences: np.ndarray, num_envs: int, device="cuda:0",
                  allow_early_resets: bool = True, num_groups: int = 1, obs_ring: int = 3, feeder=None, **env_kw):
         """``num_groups`` > 1: the envs are stepped as that many independent groups on their own HIP streams
-        (GroupedPackingEnv); ``step()`` still covers all envs, and ``step_async(actions, group=g)`` /
+        (GroupedPackingEnv); 0: as many as ``groups_for`` recommends for this data set and size; ``step()`` still covers all envs, and ``step_async(actions, group=g)`` /
         ``step_wait(group=g)`` let an actor loop work on one group while the others step.
         ``feeder``: an ``itemgen.StreamFeeder`` for environments created with ``item_stream=1``."""
         self.num_groups = int(num_groups)
+        if self.num_groups == 0:            # the library's own choice (groups_for): which overlap path does this data set take?
+            probe = GpuPackingEnv(shapes, sequences[:1], 1, device=device, **{k: v for k, v in env_kw.items() if k != "item_stream"})
+            generic = "generic" in probe.kernel_info()[1]
+            fine = probe.Hx * probe.Hy > 32 * 32
+            probe.close()
+            self.num_groups = groups_for(("abc_fine" if fine else "general") if generic else "lattice", num_envs)
         if self.num_groups > 1:
             self.env = GroupedPackingEnv(shapes, sequences, num_envs, self.num_groups, device=device, **env_kw)
         else:

@@ -222,3 +222,27 @@ def test_make_vec_envs_hands_out_observations_that_stay():
     ptrs = [ring.reset().data_ptr()] + [ring.step(np.zeros(8, dtype=np.int64))[0].data_ptr() for _ in range(5)]
     assert len(set(ptrs)) == 3
     ring.close()
+
+
+def test_num_groups_zero_lets_the_library_choose():
+    """GpuVecEnv(num_groups=0): groups_for() by the overlap path the data set takes and the number of envs -- free-form tables
+    at 1024 envs step as two groups, lattice data as one; observations equal an ungrouped environment's either way."""
+    gen = synthetic.general_shapes(n_shapes=24, n_rot=8, seed=1)
+    seqs = synthetic.make_sequences(gen.n_shapes, 256, 60, seed=9)
+    auto = GpuVecEnv(gen, seqs, 1024, device=DEV, num_groups=0)
+    one = GpuVecEnv(gen, seqs, 1024, device=DEV)
+    assert auto.num_groups == 2 and one.num_groups == 1
+    a, b = auto.reset(), one.reset()
+    torch.cuda.synchronize()
+    assert torch.equal(a, b)
+    for t in range(6):
+        act = one.env.policy_minz(b).cpu().numpy()
+        a, ra, da, _ = auto.step(act)
+        b, rb, db, _ = one.step(act)
+        assert torch.equal(a, b) and np.array_equal(da, db) and torch.equal(ra, rb)
+    auto.close()
+    one.close()
+    blk = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    lat = GpuVecEnv(blk, synthetic.make_sequences(blk.n_shapes, 64, 150, seed=5), 1024, device=DEV, num_groups=0)
+    assert lat.num_groups == 1
+    lat.close()
