@@ -56,7 +56,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     # The generic overlap loop waits for its pipelined scalar loads in a second asm statement: refuse a library in
     # which the compiler put a use of the loaded registers in between (asmcheck.py; disassembly of what was just built)
     from . import asmcheck
-    chk = asmcheck.check_library(out)
+    try:
+        chk = asmcheck.check_library(out)
+    except (RuntimeError, OSError, subprocess.CalledProcessError) as e:      # no llvm-objdump & co on this machine: the CPU suite's
+        if verbose:                                                        # test_kernel_asm.py is where the check is mandatory
+            print(f"asmcheck skipped: {e}")
+        return out
     if verbose:
         print(f"asmcheck: {chk['scalar_loads']} scalar loads in {chk['functions']} kernels, {len(chk['problems'])} hazards")
     if chk["problems"]:

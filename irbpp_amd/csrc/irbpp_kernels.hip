@@ -751,22 +751,6 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         // in the phase-plane layout those are entry X*Ay + Y of every plane -- step^2 conflict-free reads at one index.
         // (2) a b x b block is (b / step)^2 neighbouring action cells.  (Reading the b^2 cells of every block straight from
         // the planes took 16 scattered reads with their index arithmetic per block at b = 4, step = 2.)
-#ifdef IRBPP_AB_OLD_MBGRID
-        for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
-            const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
-            double m = -1e300;
-            int colp[8];                                     // block_b <= 8 (irbpp_load_shapes)
-#pragma unroll
-            for (int j = 0; j < 8; ++j) colp[j] = j < P.block_b ? tile_col_part(P, pj * P.step + j) : 0;
-            for (int i = 0; i < P.block_b; ++i) {
-                const double* rowp = L.hm + tile_row_part(P, pi * P.step + i);
-#pragma unroll
-                for (int j = 0; j < 8; ++j)
-                    if (j < P.block_b) m = fmax(m, rowp[colp[j]]);
-            }
-            L.mb[t] = m;
-        }
-#else
         const int planes = P.pp * P.pp, mq = P.block_b / P.step;
         for (int t = tid; t < AC; t += BLOCK) {
             double m = L.hm[t];
@@ -782,7 +766,6 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 for (int j = 0; j < mq; ++j) m = fmax(m, c[i * Ay + j]);
             L.mb[t] = m;
         }
-#endif
     }
     __syncthreads();
 

@@ -1,4 +1,4 @@
-# Tooling: the verification + profile pass behind profiles/r03/final (gpurun -- 'bash tools/_final.sh')
+# Tooling: the verification + profile pass behind profiles/r04/final (gpurun -- 'bash tools/_final.sh')
 O=gpurun_out/final; mkdir -p $O
 timeout 600 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
