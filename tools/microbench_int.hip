@@ -9,10 +9,10 @@
 #define ITER 4096
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
-enum Op { ADD_U32, MUL_LO_U32, MUL_HI_U32, MUL_I24, MAD_I24, MAD_U64_U32, PERM_B32, BFE_U32, READLANE, DPP_ROW_SHR, BPERMUTE, FFBL, CNDMASK, LSHL_ADD, NOPS };
+enum Op { ADD_U32, MUL_LO_U32, MUL_HI_U32, MUL_I24, MAD_I24, MAD_U64_U32, PERM_B32, BFE_U32, READLANE, DPP_ROW_SHR, BPERMUTE, FFBL, CNDMASK, LSHL_ADD, CNDMASK_SGPR, CMP_CNDMASK, BFI, MAX_DPP, ADD_SGPR_SRC, NOPS };
 static const char* NAMES[] = {"v_add_u32", "v_mul_lo_u32", "v_mul_hi_u32", "v_mul_i32_i24", "v_mad_i32_i24", "v_mad_u64_u32", "v_perm_b32",
                               "v_bfe_u32", "v_readlane_b32 (+ v_add with the SGPR)", "v_mov_b32 dpp row_shr:1", "ds_bpermute_b32", "v_ffbl_b32",
-                              "v_cndmask_b32 (vcc)", "v_lshl_add_u32"};
+                              "v_cndmask_b32 (vcc, no writer in the loop)", "v_lshl_add_u32", "v_cndmask_b32_e64 (SGPR pair)", "v_cmp_lt_u32 + v_cndmask_b32 (pair)", "v_bfi_b32", "v_max_u32 dpp row_shr:1", "v_add_u32 with a fresh s_mov SGPR"};
 
 template <int OP>
 __global__ void __launch_bounds__(1024) k(uint32_t* out, int seed) {
@@ -21,6 +21,7 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, int seed) {
 #pragma unroll
     for (int j = 0; j < 12; ++j) u[j] = seed * 8 + j * 8 * 64 + lane * 8;
     unsigned long long w = (unsigned long long)seed * 77ull + lane;
+    const unsigned long long w0 = __ballot((lane ^ seed) & 1);
     for (int it = 0; it < ITER; ++it) {
 #pragma unroll
         for (int j = 0; j < 12; ++j) {
@@ -36,7 +37,12 @@ __global__ void __launch_bounds__(1024) k(uint32_t* out, int seed) {
             else if (OP == DPP_ROW_SHR) asm volatile("s_nop 1\n v_mov_b32_dpp %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[j]));
             else if (OP == BPERMUTE) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(u[j]) : "v"(u[(j + 1) % 12]));
             else if (OP == FFBL) asm volatile("v_ffbl_b32 %0, %0" : "+v"(u[j]));
-            else if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(u[(j + 1) % 12]) : "vcc");
+            else if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(u[(j + 1) % 12]));
+            else if (OP == CNDMASK_SGPR) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[j]) : "v"(u[(j + 1) % 12]), "s"(w0));
+            else if (OP == CMP_CNDMASK) asm volatile("v_cmp_lt_u32 vcc, %0, %1\n v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(u[(j + 1) % 12]) : "vcc");
+            else if (OP == BFI) asm volatile("v_bfi_b32 %0, %1, %0, %1" : "+v"(u[j]) : "v"(u[(j + 1) % 12]));
+            else if (OP == MAX_DPP) asm volatile("s_nop 1\n v_max_u32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(u[j]));
+            else if (OP == ADD_SGPR_SRC) { int sg; asm volatile("s_mov_b32 %0, %1" : "=s"(sg) : "s"(seed)); asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[j]) : "s"(sg)); }
             else if (OP == LSHL_ADD) asm volatile("v_lshl_add_u32 %0, %0, 2, %1" : "+v"(u[j]) : "s"(seed));
         }
         if (OP == BPERMUTE) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -80,6 +86,7 @@ int main() {
     if (run<ADD_U32>(out, mhz, cus) || run<MUL_LO_U32>(out, mhz, cus) || run<MUL_HI_U32>(out, mhz, cus) || run<MUL_I24>(out, mhz, cus) ||
         run<MAD_I24>(out, mhz, cus) || run<MAD_U64_U32>(out, mhz, cus) || run<PERM_B32>(out, mhz, cus) || run<BFE_U32>(out, mhz, cus) ||
         run<READLANE>(out, mhz, cus) || run<DPP_ROW_SHR>(out, mhz, cus) || run<BPERMUTE>(out, mhz, cus) || run<FFBL>(out, mhz, cus) ||
-        run<CNDMASK>(out, mhz, cus) || run<LSHL_ADD>(out, mhz, cus)) return 1;
+        run<CNDMASK>(out, mhz, cus) || run<LSHL_ADD>(out, mhz, cus) || run<CNDMASK_SGPR>(out, mhz, cus) || run<CMP_CNDMASK>(out, mhz, cus) ||
+        run<BFI>(out, mhz, cus) || run<MAX_DPP>(out, mhz, cus) || run<ADD_SGPR_SRC>(out, mhz, cus)) return 1;
     return 0;
 }
