@@ -265,10 +265,15 @@ __device__ inline uint32_t bit_flag(uint32_t v) { return ((v >> BIT) & 1u) ? ~0u
 __device__ __forceinline__ uint32_t bit_select(uint32_t mask, uint32_t if_set, uint32_t if_clear) { return (if_set & mask) | (if_clear & ~mask); }   // v_bfi_b32
 // 8-bit neighbour mask (bit s = neighbour in direction s, in the frame's own orientation) from the three stored lines
 // around a pixel at position p of the middle line: bits p .. p+2 of a stored line are pixels p-1, p, p+1
-__device__ __forceinline__ uint32_t nb_frame(uint32_t a, uint32_t b, uint32_t c, int p) {
+// (the table words are passed in: the walk keeps them in scalar registers of its own for the whole loop -- the compiler,
+// left to itself, re-materialises such constants with an s_mov right in front of every use, and a vector instruction behind
+// a fresh scalar one costs a lone wave 13 cycles instead of 6, tools/microbench_int.hip)
+struct NbTables { uint32_t rev_hi, rev_lo, ew_hi, ew_lo; };
+__device__ __forceinline__ NbTables nb_tables() { return NbTables{0x0e060a02u, 0x0c040800u, 0x11011101u, 0x10001000u}; }
+__device__ __forceinline__ uint32_t nb_frame(uint32_t a, uint32_t b, uint32_t c, int p, const NbTables& t = nb_tables()) {
     constexpr uint32_t SEL = 0x0c0c0c00u;
-    const uint32_t ra = byte_table(0x0e060a02u, 0x0c040800u, ((a >> p) & 7u) | SEL);      // NE, N, NW (bits 1..3): the line before, reversed
-    const uint32_t rb = byte_table(0x11011101u, 0x10001000u, ((b >> p) & 7u) | SEL);      // E (bit 0) = pixel p+1, W (bit 4) = pixel p-1
+    const uint32_t ra = byte_table(t.rev_hi, t.rev_lo, ((a >> p) & 7u) | SEL);             // NE, N, NW (bits 1..3): the line before, reversed
+    const uint32_t rb = byte_table(t.ew_hi, t.ew_lo, ((b >> p) & 7u) | SEL);               // E (bit 0) = pixel p+1, W (bit 4) = pixel p-1
     return (bit_field(c, (uint32_t)p, 3) << 5) | ra | rb;                                  // SW, S, SE (bits 5..7): the line after
 }
 // All lanes of the wave call it together; `active` says whether the lane has a border to follow (an inactive lane
@@ -281,10 +286,19 @@ __device__ __forceinline__ uint32_t nb_frame(uint32_t a, uint32_t b, uint32_t c,
 __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active = true) {
     // per-direction tables, entry s in byte s: pos delta + 17; flags (1 axis move, 2 vertical frame, 4 towards higher
     // bits, 8 side line = the line after); bit offset of the line index in pos (4 rows / 0 columns); frame offset in bytes
-    constexpr uint32_t DELTA_LO = 0x00010212u, DELTA_HI = 0x22212010u;      // E +1, NE -15, N -16, NW -17 | W -1, SW +15, S +16, SE +17
-    constexpr uint32_t FLAG_LO = 0x000b000du, FLAG_HI = 0x00070001u;        // E 13, N 11 | W 1, S 7
-    constexpr uint32_t LSH_LO = 0x04000404u, LSH_HI = 0x04000404u;          // N and S index columns (x = pos & 15), all others rows
-    constexpr uint32_t FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16, FOFF_HI = FOFF_LO;   // N and S read the column frame (byte offset)
+    uint32_t DELTA_LO = 0x00010212u, DELTA_HI = 0x22212010u;                // E +1, NE -15, N -16, NW -17 | W -1, SW +15, S +16, SE +17
+    uint32_t FLAG_LO = 0x000b000du, FLAG_HI = 0x00070001u;                  // E 13, N 11 | W 1, S 7
+    uint32_t LSH_LO = 0x04000404u, LSH_HI = LSH_LO;                         // N and S index columns (x = pos & 15), all others rows
+    uint32_t FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16, FOFF_HI = FOFF_LO; // N and S read the column frame (byte offset)
+    NbTables NT = nb_tables();
+#if defined(__HIP_DEVICE_COMPILE__)
+    // opaque to the compiler from here on: the table words stay in the scalar registers they are in (see nb_frame)
+    // (v_perm_b32 takes one scalar operand: the low halves of the two-word tables live in vector registers)
+    asm volatile("" : "+v"(DELTA_LO), "+s"(DELTA_HI), "+v"(FLAG_LO), "+s"(FLAG_HI), "+s"(LSH_LO), "+s"(FOFF_LO));
+    asm volatile("" : "+s"(NT.rev_hi), "+v"(NT.rev_lo), "+s"(NT.ew_hi), "+v"(NT.ew_lo));
+    LSH_HI = LSH_LO;
+    FOFF_HI = FOFF_LO;
+#endif
     constexpr uint32_t SEL = 0x0c0c0c00u;
     const int pos0 = x0 | (y0 << 4);
     // first neighbour: clockwise search 3, 2, 1, 0, 7, 6, 5 (the west pixel is background)
@@ -297,9 +311,8 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
     int pos = pos0, n = 0, result = 0;
     uint32_t nb16 = nb0 | (nb0 << 8), k2 = (uint32_t)(s_first + 1), prev = (uint32_t)(s_first ^ 4) | SEL;
     uint32_t run = (active && !isolated) ? 1u : 0u;                        // (an integer, not a flag: no lane mask is carried around the loop)
-    int guard = 0;
-    for (; guard < 4096; ++guard) {
-        if (__ballot(run != 0u) == 0ull) break;                            // uniform: nobody walks any more
+    int guard = 4096;                                                      // (uniform; counts down: one scalar subtract and branch per step)
+    while (__ballot(run != 0u) != 0ull) {                                  // uniform: somebody still walks
         if (run != 0u) {
         IRBPP_TRACE_ITER();
         // counter-clockwise search k2, k2 + 1, ... for the next border pixel (nb != 0: the pixel we came from)
@@ -329,7 +342,7 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
             pos4 += dp * (1 << psh);
         }
         const bool closed2 = pos4 == pos0 && s2 == s_close;
-        const uint32_t nbl = nb_frame(wa, wm, wb, p);
+        const uint32_t nbl = nb_frame(wa, wm, wb, p, NT);
         const uint32_t nb = bit_select(bit_flag<1>(flags), nb_untranspose(nbl), nbl);
         const bool ends = closed1 || closed2;
         result = ends ? n : result;
@@ -338,8 +351,8 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
         k2 = s2 + 5u;
         nb16 = nb | (nb << 8);
         }
+        if (--guard == 0) return -1;                                       // (uniform)
     }
-    if (guard >= 4096) return -1;                                          // (uniform)
     if (active && isolated && cap > 0) pts[0] = (uint8_t)pos0;
     return !active ? 0 : (isolated ? 1 : result);
 }

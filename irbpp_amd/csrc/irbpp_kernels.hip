@@ -69,8 +69,49 @@ __device__ __forceinline__ int np_floor_divide_int(double a, double b, double in
     return r == 0.0 ? -(int)q : -(int)q - 1;
 }
 
+// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
+// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
+// 0 that a shift brings in from outside the row is the identity of both sum and max.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
+__device__ __forceinline__ int wave_inclusive_sum(int v) {
+    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
+    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
+    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
+    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
+    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
+    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
+__device__ __forceinline__ int wave_inclusive_max(int v) {
+    v = imax(v, dpp_shift<0x111, 0xF>(v));
+    v = imax(v, dpp_shift<0x112, 0xF>(v));
+    v = imax(v, dpp_shift<0x114, 0xF>(v));
+    v = imax(v, dpp_shift<0x118, 0xF>(v));
+    v = imax(v, dpp_shift<0x142, 0xA>(v));
+    v = imax(v, dpp_shift<0x143, 0xC>(v));
+    return v;
+}
+
+// wave64 maximum of a float64 on the DPP network (lane 63 ends up with it; every lane gets it back by v_readlane): a
+// butterfly of __shfl_xor is six ds_bpermute_b32 per word, 24 LDS cycles each and an LDS round trip of latency per step
+// (tools/microbench_int.hip)
+__device__ __forceinline__ double wave_max_f64(double v) {
+#define IRBPP_MAX_STEP(CTRL, ROWS)                                                                                   \
+    {                                                                                                                \
+        const int lo = __builtin_amdgcn_update_dpp(__double2loint(v), __double2loint(v), CTRL, ROWS, 0xF, false);    \
+        const int hi = __builtin_amdgcn_update_dpp(__double2hiint(v), __double2hiint(v), CTRL, ROWS, 0xF, false);    \
+        v = fmax(v, __hiloint2double(hi, lo));                                                                       \
+    }
+    IRBPP_MAX_STEP(0x111, 0xF) IRBPP_MAX_STEP(0x112, 0xF) IRBPP_MAX_STEP(0x114, 0xF) IRBPP_MAX_STEP(0x118, 0xF)
+    IRBPP_MAX_STEP(0x142, 0xA) IRBPP_MAX_STEP(0x143, 0xC)
+#undef IRBPP_MAX_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 __device__ inline double block_max_f64(double v, double* red) {
-    for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
+    v = wave_max_f64(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -80,7 +121,7 @@ __device__ inline double block_max_f64(double v, double* red) {
 }
 
 __device__ inline int block_sum_int(int v, int* red) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    v = __builtin_amdgcn_readlane(wave_inclusive_sum(v), 63);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
     __syncthreads();
@@ -593,31 +634,6 @@ __device__ __forceinline__ uint32_t wave_or_to_lane63(uint32_t x) {
     v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false);     // row_bcast15 into rows 1 and 3
     v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false);     // row_bcast31 into rows 2 and 3
     return (uint32_t)v;
-}
-
-// wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
-// row shifts, then the row totals are carried over with the two row broadcasts.  Operands are >= 0, so the
-// 0 that a shift brings in from outside the row is the identity of both sum and max.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ int dpp_shift(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, ROW_MASK, 0xF, false); }
-__device__ __forceinline__ int wave_inclusive_sum(int v) {
-    v += dpp_shift<0x111, 0xF>(v);           // row_shr:1
-    v += dpp_shift<0x112, 0xF>(v);           // row_shr:2
-    v += dpp_shift<0x114, 0xF>(v);           // row_shr:4
-    v += dpp_shift<0x118, 0xF>(v);           // row_shr:8
-    v += dpp_shift<0x142, 0xA>(v);           // row_bcast15 into rows 1 and 3
-    v += dpp_shift<0x143, 0xC>(v);           // row_bcast31 into rows 2 and 3
-    return v;
-}
-__device__ __forceinline__ int imax(int a, int b) { return a > b ? a : b; }
-__device__ __forceinline__ int wave_inclusive_max(int v) {
-    v = imax(v, dpp_shift<0x111, 0xF>(v));
-    v = imax(v, dpp_shift<0x112, 0xF>(v));
-    v = imax(v, dpp_shift<0x114, 0xF>(v));
-    v = imax(v, dpp_shift<0x118, 0xF>(v));
-    v = imax(v, dpp_shift<0x142, 0xA>(v));
-    v = imax(v, dpp_shift<0x143, 0xC>(v));
-    return v;
 }
 
 // a GCell as ONE 16-byte scalar load (the struct's fields would be fetched one s_load_dword(x2) each)
@@ -1205,8 +1221,7 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, const doub
             int c[4], sum = 0;
 #pragma unroll
             for (int i = 0; i < 4; ++i) { c[i] = (int)hist[tid * 4 + i]; sum += c[i]; }
-            int incl = sum;
-            for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(incl, o); if (tid >= o) incl += t; }
+            const int incl = wave_inclusive_sum(sum);                    // (DPP network: no LDS round trips)
             int run = incl - sum;                                        // elements in the bins below this lane's four
             if (run < remaining && remaining <= incl) {                  // the want-th element falls into one of my bins
 #pragma unroll
@@ -1387,10 +1402,18 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
                 const float h = rowval[i];
                 if (h < best) { best = h; bi = i; }              // ascending i per thread: the first of equals stays
             }
-        for (int o = 32; o > 0; o >>= 1) {
-            const float ob = __shfl_xor(best, o);
-            const int oi = __shfl_xor(bi, o);
-            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        {   // the wave's (lowest H, lowest row) on the DPP network: lane 63 ends up with it (see wave_max_f64)
+#define IRBPP_ARGMIN_STEP(CTRL, ROWS)                                                                                          \
+            {                                                                                                                  \
+                const float ob = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(best), __float_as_int(best), CTRL, ROWS, 0xF, false)); \
+                const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, ROWS, 0xF, false);                                     \
+                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }                                               \
+            }
+            IRBPP_ARGMIN_STEP(0x111, 0xF) IRBPP_ARGMIN_STEP(0x112, 0xF) IRBPP_ARGMIN_STEP(0x114, 0xF) IRBPP_ARGMIN_STEP(0x118, 0xF)
+            IRBPP_ARGMIN_STEP(0x142, 0xA) IRBPP_ARGMIN_STEP(0x143, 0xC)
+#undef IRBPP_ARGMIN_STEP
+            best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 63));
+            bi = __builtin_amdgcn_readlane(bi, 63);
         }
         __syncthreads();
         if ((tid & 63) == 0) { ((float*)L.redi)[4 + (tid >> 6)] = best; L.redi[8 + (tid >> 6)] = bi; }
@@ -1740,8 +1763,9 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                 carry = __builtin_amdgcn_readlane(run, 63);
                 const int owner = run - 1;                                    // lane that traced this position's border
                 const int on = owner >= 0 ? owner : 0;
-                nn[u] = __shfl(wn, on);
-                sbq[u] = __shfl(excl, on) - base;
+                const int ns = __shfl(wn | ((excl - base) << 8), on);           // (one gather for both: wn <= 128, start < 128)
+                nn[u] = ns & 255;
+                sbq[u] = ns >> 8;
                 prk[u] = __shfl(rk, on);
                 live[u] = owner >= 0 && u * 64 + lane < sbq[u] + nn[u];
                 pts[u] = slots + on * SLOT;
@@ -2185,8 +2209,7 @@ irbpp_item_order_kernel(const Tables T, const State S, int N) {
     if (tid < 64) {                                  // exclusive scan of the 1024 counts by one wave
         int v[16], sum = 0;
         for (int i = 0; i < 16; ++i) { v[i] = hist[tid * 16 + i]; sum += v[i]; }
-        int inc = sum;
-        for (int o = 1; o < 64; o <<= 1) { const int t = __shfl_up(inc, o); if (tid >= o) inc += t; }
+        const int inc = wave_inclusive_sum(sum);
         int acc = inc - sum;
         for (int i = 0; i < 16; ++i) { start[tid * 16 + i] = acc; acc += v[i]; }
     }
