@@ -1300,6 +1300,9 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
     // ---- candidate rows: per rotation, vertices ordered by (col, row) (np.unique, cvTools.py:101)
+    // the candidate rows the buffer holds from last time (registered buffers): asked for first -- nothing depends on it until
+    // the rows are stored, and as a load in front of them it was one more memory round trip on a path made of those
+    const int prev_rows = io.obs_rows != nullptr ? io.obs_rows[b] : -1;
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
     uint32_t* okey = keys + R * AC;                 // [S]
     uint32_t* hist = (uint32_t*)L.img;              // [256] counters of the radix select: the level images are done with
@@ -1363,10 +1366,8 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     // (typically 100 of 500 rows exist).
     int write_rows = P.S;
     if (io.obs_rows != nullptr) {
-        const int prev = io.obs_rows[b];
-        if (prev >= 0) write_rows = prev > nrows ? prev : nrows;
-        __syncthreads();                             // everyone has read the old count
-        if (tid == 0) io.obs_rows[b] = nrows;
+        if (prev_rows >= 0) write_rows = prev_rows > nrows ? prev_rows : nrows;
+        if (tid == 0) io.obs_rows[b] = nrows;        // (everyone read the old count at the top of the function, barriers ago)
     }
     for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
     for (int e = tid; e < 5 * write_rows; e += BLOCK) {
