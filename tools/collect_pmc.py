@@ -28,7 +28,10 @@ STEP_KERNELS = ("irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_polygon_kernel"
 
 def agg(sub):
     d = collections.defaultdict(lambda: collections.defaultdict(list))
-    for path in glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True):
+    paths = sorted(glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True))
+    if len(paths) > 1:      # gpurun_out/ is merged into, never cleaned: a pass of an earlier round must not be averaged in
+        raise SystemExit(f"{os.path.join(src, sub)}: more than one counter_collection.csv ({paths}): remove the stale ones")
+    for path in paths:
         with open(path) as f:
             for r in csv.DictReader(f):
                 d[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
