@@ -39,7 +39,8 @@ constexpr int WAVES = BLOCK / 64;
 // prices the phase at full chip load (and the instruction counters of a PMC pass its instruction count).  In the product
 // build the trip count is the constant 1.  Bits: 0 in-workgroup trace, 1 Douglas-Peucker (hull kernel), 2 overlap loops,
 // 3 emit stores, 5 tile staging, 6 block-max grid, 7 level codes + masks, 8 float32 heightmap copy, 9 level images +
-// candidate bits, 10 candidate list.
+// candidate bits, 10 candidate list, 11 drop height of the placement, 12 heightmap update, 13 overlap-test set-up,
+// 14 hand-over stores.
 #ifdef IRBPP_ABLATE
 #define IRBPP_REPS(bit) (1 + ((P.dbg_repeat >> (bit)) & 1))
 #else
@@ -755,10 +756,12 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     int* srw = L.sr;                                         // all R ShapeRots of the item in ONE coalesced load
     if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
+    for (int rep = 0; rep < IRBPP_REPS(13); ++rep) {
     if (tid < R) L.present[tid] = 0ull;
     if (tid == 0) L.redi[GENERIC_TICKET] = WAVES;            // generic path: the first WAVES tasks are taken without a ticket
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
+    }
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
     if (use_block)
     for (int rep = 0; rep < IRBPP_REPS(6); ++rep) {
@@ -1450,6 +1453,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     uint16_t* const clist = L.clist;
     {   // naiveMask's bit rows first: they share their LDS bytes with the task index built next
         uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
+        for (int rep = 0; rep < IRBPP_REPS(14); ++rep)
         for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
         __syncthreads();
     }
@@ -1470,8 +1474,10 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         const int nb = ntasks - base < IMGS ? ntasks - base : IMGS;
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)rows;
+        for (int rep = 0; rep < IRBPP_REPS(14); ++rep) {
         for (int i = tid; i < nb * 8; i += BLOCK) gi[(size_t)base * 8 + i] = lr[i];
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
+        }
         // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
         // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
         // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
@@ -1512,6 +1518,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         __syncthreads();                             // the next batch rebuilds the images and the list
     }
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
+    for (int rep = 0; rep < IRBPP_REPS(14); ++rep)
     for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
@@ -2026,9 +2033,11 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         if (ok && tid < sr.nt) tc0 = T.tcell[sr.ot + tid];
         if (in_grid && (ok || cold_args()->S.log_meta != nullptr)) {
             const Cell* cells = T.bcell + sr.ob;
+            for (int rep = 0; rep < IRBPP_REPS(11); ++rep) {
             double m = sr.has_out ? 0.0 : -1e300;
             for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v);
             z = block_max_f64(m, L.redd);
+            }
         }
         if (ok) {
             // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
@@ -2069,6 +2078,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
             const Cell* cells = T.tcell + sr.ot;
+            for (int rep = 0; rep < IRBPP_REPS(12); ++rep)
             for (int e = tid; e < sr.nt; e += BLOCK) {
                 const Cell tc = e == tid ? tc0 : cells[e];
                 const int ij = tc.ij;

@@ -8,7 +8,7 @@ OUT=$R/gpurun_out/$1; WL=${2:-blockout}; BINS=${3:-4096}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 export IRBPP_LIBRARY=$R/irbpp_amd/libirbpp_var_ablate.so
-for bit in 0 32 64 4 128 256 512 1024; do
+for bit in ${BITS:-0 32 64 4 128 256 512 1024 2048 4096 8192 16384}; do
   rm -rf /tmp/pmc_$bit
   IRBPP_DEBUG_REPEAT=$bit rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU \
     --output-format csv -d /tmp/pmc_$bit -o x -- python $R/bench.py --workload $WL --bins $BINS --tuning 2 --no-cpu-baseline --no-extra \
