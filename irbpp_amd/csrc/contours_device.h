@@ -224,7 +224,7 @@ __device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, in
 //     held in two SGPRs each and read with one v_perm_b32 (the direction code carries 0x0c in its upper bytes, which
 //     makes v_perm return the table byte zero-extended);
 //   * the level image lies in LDS as two FRAMES of 18 dwords: rows (y = -1 .. 16) and columns (x = -1 .. 16), every
-//     line shifted left by one bit, a zero line before and behind: the three lines around a pixel are three reads at
+//     line shifted left by one bit, a zero line before and behind (35 dwords: the two frames share the zero line between them): the three lines around a pixel are three reads at
 //     one address (no edge cases), and bits p-1, p, p+1 of a line are bits p .. p+2 of the stored word (no shifts by -1);
 //   * the contour point is stored unconditionally at index min(n, cap) and n advances only when the direction changed
 //     (CHAIN_APPROX_SIMPLE): a point that is not one gets overwritten by the next store;
@@ -232,7 +232,7 @@ __device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, in
 //     wave -- which walk different borders in lockstep -- run straight-line code.
 // ~85 instructions per step where trace_step compiles to ~160 (disassembly of the trace kernel).
 // ---------------------------------------------------------------------------------------
-constexpr int FRAME_LINES = 18, FRAME_COLS = FRAME_LINES, FRAME_WORDS = 2 * FRAME_LINES;
+constexpr int FRAME_LINES = 18, FRAME_COLS = FRAME_LINES - 1, FRAME_WORDS = 2 * FRAME_LINES - 1;   // (the zero line behind the rows is the one before the columns)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t byte_table(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #else
@@ -283,7 +283,11 @@ __device__ __forceinline__ uint32_t nb_frame(uint32_t a, uint32_t b, uint32_t c,
 // frames and its own slot, and n no longer advances), which costs nothing in lockstep and saves the execution-mask
 // bookkeeping of a per-lane exit (two dozen scalar instructions per step in the compiler's rendering of it).
 // Returns the number of points, 0 if (x0, y0) does not start an outer border, -1 if the iteration guard tripped.
-__device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active = true) {
+// `spill`: where the points from index `cap` on go (global memory, `spill_cap` bytes of the lane's own; nullptr / 0: nowhere,
+// as before) -- the slot in LDS holds the first `cap` points, which is all of nearly every border; the others cost their
+// lanes one more store per step, behind a branch the whole wave skips otherwise.
+__device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active = true,
+                                        uint8_t* spill = nullptr, int spill_cap = 0) {
     // per-direction tables, entry s in byte s: pos delta + 17; flags (1 axis move, 2 vertical frame, 4 towards higher
     // bits, 8 side line = the line after); bit offset of the line index in pos (4 rows / 0 columns); frame offset in bytes
     uint32_t DELTA_LO = 0x00010212u, DELTA_HI = 0x22212010u;                // E +1, NE -15, N -16, NW -17 | W -1, SW +15, S +16, SE +17
@@ -319,6 +323,7 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
         k2 &= 7u;
         const uint32_t s2 = ((k2 + (uint32_t)__builtin_ctz(nb16 >> k2)) & 7u) | SEL;
         pts[n < cap ? n : cap] = (uint8_t)pos;                            // CHAIN_APPROX_SIMPLE: kept iff the direction changed
+        if (n >= cap && n - cap < spill_cap) spill[n - cap] = (uint8_t)pos;
         n += s2 != prev ? 1 : 0;
         prev = s2;
         int pos4 = pos + (int)byte_table(DELTA_HI, DELTA_LO, s2) - 17;

@@ -259,7 +259,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_img, N * P.wimg * 16);
     ALLOC(w_imgrot, N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
-    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * TRACE_BIG_BYTES);   // one scratch per wave of the trace grid
+    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * TRACE_WAVE_BYTES);   // one scratch per wave of the trace grid
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);

@@ -115,7 +115,7 @@ struct State {
     uint8_t* w_imgrot;     // [N][wimg] rotation of each level image
     uint2* w_cand;         // [NXCD][seg_cap] flat lists of the launch's candidate starts, in arrival order:
                            // (bin, image<<8 | y0<<4 | x0)
-    uint8_t* w_big;        // [N][6 * 768] scratch of the sequential redo of a border with more than 128 points
+    uint8_t* w_big;        // [trace waves][TRACE_WAVE_BYTES] scratch of the sequential redo of a border with more than 128 points, then 64 x 72 spill bytes (points 56.. of the lanes' borders)
     uint8_t* w_round;      // [NXCD][round_cap][ROUND_BYTES] round records, trace kernel -> polygon kernel
     int32_t* w_nround;     // [NXCD * XCD_STRIDE] records in each XCD's list
     int32_t* w_heavy;      // [2][XCD_STRIDE + heavy_cap] bins with many border starts, listed by the transition kernel for the emit kernel

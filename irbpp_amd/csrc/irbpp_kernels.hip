@@ -1620,20 +1620,24 @@ IRBPP_EMIT_KERNEL(irbpp_emit_kernel, true)
 #define IRBPP_TRACE_SHORT 0
 #endif
 constexpr int TRACE_P = IRBPP_TRACE_P;                                // contour points per lane and polygon round
-constexpr int TRACE_CAP = 128, TRACE_SLOT = TRACE_CAP + 4;            // points per border slot; 33 dwords: odd stride
+constexpr int TRACE_CAP = 128;                                        // points of a border the wave-parallel path takes
+constexpr int TRACE_LDS_CAP = 56, TRACE_SLOT = TRACE_LDS_CAP + 4;     // of which in the lane's slot in LDS (15 dwords: odd stride); the rest
+constexpr int TRACE_SPILL = TRACE_CAP - TRACE_LDS_CAP;                //   in global scratch (a border of more than 56 points: one in ~10^3)
 constexpr int TRACE_SHORT = IRBPP_TRACE_SHORT;                        // borders of up to this many points get rounds of their own, ahead of the
                                                                       // long ones (0 = one class: measured 27.46 vs 27.25 M steps/s for 8)
 static_assert(TRACE_CAP <= 64 * TRACE_P, "a border must fit one polygon round");
 static_assert(ROUND_POINTS == 64 * TRACE_P, "a round record holds one polygon round");
 constexpr int TRACE_BIG = 768;                                        // point capacity of the sequential redo (global scratch)
-constexpr int TRACE_FSTRIDE = FRAME_WORDS + 1;                        // dwords per staged image: two frames + 1 (37: odd, lanes on distinct banks)
+constexpr int TRACE_FSTRIDE = FRAME_WORDS;                            // dwords per staged image: the two frames (35: odd, lanes on distinct banks)
+static_assert(TRACE_FSTRIDE % 2 == 1 && (TRACE_SLOT / 4) % 2 == 1 && TRACE_SLOT % 4 == 0, "odd dword strides in LDS");
 constexpr int TRACE_BIG_BYTES = 6 * TRACE_BIG + 64;                   // scratch of the sequential redo: points, polygon, stack, 16-bit image
+constexpr int TRACE_WAVE_BYTES = TRACE_BIG_BYTES + 64 * TRACE_SPILL;  // per wave of the grid: the redo's scratch, then the lanes' spill bytes
 // Candidates per wave (chunk) of the trace kernel: 64 at full width; 32 or 16 when the launch has too few candidates to
 // give every SIMD a wave of 64 (a wave lasts as long as its longest border: with fewer borders per wave the mean wave is
 // shorter and the idle SIMDs take the extra waves -- launch_group in irbpp_capi.hip picks by the number of bins).
 template <int TRACE_CPW>
 __device__ __forceinline__ void trace_body(const Params& P, const State& S, long long* prof) {
-    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, PP = TRACE_P;
+    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, LCAP = TRACE_LDS_CAP, PP = TRACE_P;
     __shared__ __attribute__((aligned(16))) uint8_t slots[TRACE_CPW * SLOT];            // one border per tracing lane
     __shared__ __attribute__((aligned(16))) uint32_t sfr[TRACE_CPW * TRACE_FSTRIDE];    // one level image per tracing lane: row + column frames
     __shared__ uint32_t dps[64 * PP];
@@ -1664,6 +1668,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         int my_n = 0, rk = 0, x0 = 0, y0 = 0;
         uint32_t* const fr = sfr + (lane < TRACE_CPW ? lane : 0) * TRACE_FSTRIDE;
         uint8_t* const my_slot = slots + (lane < TRACE_CPW ? lane : 0) * SLOT;
+        uint8_t* const wave_spill = S.w_big + (size_t)blockIdx.x * TRACE_WAVE_BYTES + TRACE_BIG_BYTES;    // [64][TRACE_SPILL]
         if (have) {
             const uint2 ce = S.w_cand[g];
             const uint32_t e = ce.y;
@@ -1686,7 +1691,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         const long long t_staged = prof ? (long long)clock64() : 0;
         // ---- follow the borders, all lanes in lockstep
         {
-            const int n = trace_border_fast(fr, x0, y0, my_slot, CAP, have);
+            const int n = trace_border_fast(fr, x0, y0, my_slot, LCAP, have, wave_spill + lane * TRACE_SPILL, TRACE_SPILL);
             if (n < 0) { if (lane == 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD); }
             else my_n = n;                                            // 0: not the first pixel of its component
         }
@@ -1697,7 +1702,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                 const int l0 = __ffsll((long long)big) - 1;
                 big &= big - 1ull;
                 if (lane == l0) {
-                    uint8_t* gsc = S.w_big + (size_t)blockIdx.x * TRACE_BIG_BYTES;        // one scratch per wave of the grid
+                    uint8_t* gsc = S.w_big + (size_t)blockIdx.x * TRACE_WAVE_BYTES;       // one scratch per wave of the grid
                     SlotMem m;
                     m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
                     uint16_t* im = (uint16_t*)(gsc + 6 * TRACE_BIG);                      // the plain walk reads 16-bit row and column words
@@ -1707,6 +1712,11 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                     my_n = 0;
                 }
             }
+        }
+        const bool spilled = __ballot(my_n > LCAP) != 0ull;           // (uniform) somebody's points lie partly in global scratch:
+        if (spilled) {                                                //   written by one lane, read by others below
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
         const long long t_traced = prof ? (long long)clock64() : 0;
         // ---- the closed borders go to the polygon kernel in rounds of 64 * PP contour points, borders packed back
@@ -1779,7 +1789,8 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                 pts[u] = slots + on * SLOT;
                 jj[u] = u * 64 + lane - sbq[u];
                 if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
-                pv[u] = live[u] ? (int)pts[u][jj[u]] : 0;
+                pv[u] = live[u] ? (int)pts[u][jj[u] < LCAP ? jj[u] : LCAP] : 0;
+                if (spilled && live[u] && jj[u] >= LCAP) pv[u] = (int)wave_spill[on * TRACE_SPILL + jj[u] - LCAP];
             }
             if (inline_dp) {
                 approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);

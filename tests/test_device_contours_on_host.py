@@ -52,6 +52,8 @@ def host():
     lib.host_trace_border.restype = C.c_int
     lib.host_trace_border_fast.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
     lib.host_trace_border_fast.restype = C.c_int
+    lib.host_trace_border_fast_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    lib.host_trace_border_fast_spill.restype = C.c_int
     lib.host_approx_and_convex.argtypes = [u8p, C.c_int, C.c_int, u32p]
     lib.host_approx_and_convex.restype = C.c_int
     lib.host_contour_vertices.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
@@ -119,6 +121,22 @@ def test_candidates_and_trace_equal_the_oracle_borders(host, seed):
             if outer:                                                      # a tight slot reports the true length
                 longest = max(outer, key=len)
                 assert trace(rows, longest[0][0], longest[0][1], pts, 3) == len(longest)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_trace_with_split_slot_equals_the_oracle_borders(host, seed):
+    """The trace kernel keeps the first 56 points of a border in LDS and the rest in global scratch
+    (irbpp_kernels.hip: TRACE_LDS_CAP / TRACE_SPILL): the walk with a split slot, at splits that every border crosses."""
+    pts = (C.c_uint8 * 512)()
+    for img in _images(300 + seed, 120):
+        rows = _rows(img)
+        outer, _, _ = _oracle_outer(img)
+        for c in outer:
+            for cap_lds, spill_cap in ((1, 255), (3, 200), (7, 3), (56, 72)):
+                n = host.host_trace_border_fast_spill(rows, c[0][0], c[0][1], pts, cap_lds, spill_cap)
+                assert n == len(c)                                     # the true length, whatever fits
+                m = min(n, cap_lds + spill_cap)
+                assert [(pts[i] & 15, pts[i] >> 4) for i in range(m)] == c[:m]
 
 
 def _oracle_vertices(contour_xy):

@@ -126,14 +126,16 @@ def _unit_item_shapes(n_rot=2):
     return ShapeSet(np.array([[ext] * n_rot]), np.array([8e-6]), [[_box_tables(ext, 0.01) for _ in range(n_rot)]], name="unit")
 
 
-def _snake_image():
+def _snake_image(zigzags=5):
     """One 8-connected component whose outer border has more than 128 CHAIN_APPROX_SIMPLE points: five zigzag rows
-    joined at alternating ends (a border runs along both sides of a one-pixel line and turns at every pixel)."""
+    joined at alternating ends (a border runs along both sides of a one-pixel line and turns at every pixel).  With 2, 3
+    or 4 rows the border has 61, 92 or 123 points: more than the 56 the trace kernel keeps in LDS, within the 128 of its
+    wave-parallel path."""
     img = np.zeros((16, 16), dtype=bool)
-    for j, y0 in enumerate((0, 3, 6, 9, 12)):
+    for j, y0 in enumerate((0, 3, 6, 9, 12)[:zigzags]):
         for x in range(16):
             img[y0 + (x & 1), x] = True
-        if j < 4:
+        if j < zigzags - 1:
             xe = 15 if j % 2 == 0 else 0
             img[y0 + 2, xe] = True
             img[y0 + 1, xe] = True
@@ -143,7 +145,8 @@ def _snake_image():
 
 def test_adversarial_level_images_through_transition_trace_polygon_emit():
     """Level images chosen at will -- random speckle at several densities, rings, a snake whose border outgrows the
-    128-point slot of the trace kernel (its sequential redo) -- fed through the whole split pipeline by way of the
+    128-point slot of the trace kernel (its sequential redo), shorter snakes whose borders outgrow the 56 points kept in
+    LDS (61, 92, 123: the rest lies in global scratch) -- fed through the whole split pipeline by way of the
     heightmap of a bin that observes a one-cell item; every location observation against the oracle."""
     from oracle import contours as OC
     from oracle.packing import OracleVecEnv
@@ -157,13 +160,20 @@ def test_adversarial_level_images_through_transition_trace_polygon_emit():
     snake = _snake_image()
     outer = [c for c, hole in zip(*(lambda r: (r[0], r[2]))(OC.find_contours(snake.astype(np.uint8)))) if not hole]
     assert len(outer) == 1 and len(outer[0]) > 128, len(outer[0])           # the redo path is really taken
+    mids = [_snake_image(z) for z in (2, 3, 4)]
+    for m, want in zip(mids, (61, 92, 123)):
+        got = [len(c) for c, hole in zip(*(lambda r: (r[0], r[2]))(OC.find_contours(m.astype(np.uint8)))) if not hole]
+        assert got == [want], got
     rng = np.random.RandomState(12)
     big = 0
-    for t in range(8):
+    for t in range(12):
         imgs = []
         for i in range(n):
             kind = (t + i) % 4
-            if kind == 0:
+            if kind == 0 and t >= 8:
+                m = mids[(t + i // 4) % 3]
+                imgs.append(m if i % 2 == 0 else m.T.copy())
+            elif kind == 0:
                 imgs.append(snake if (t // 4) % 2 == 0 else snake.T.copy())
             elif kind == 1:
                 imgs.append(rng.rand(16, 16) < rng.uniform(0.3, 0.7))
