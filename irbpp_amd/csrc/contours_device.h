@@ -577,6 +577,56 @@ __device__ inline void cleanup_convex_wave(int lane, int dv, int cnt, uint32_t* 
     }
 }
 
+// The same pass without its loop.  What the sequential pass does, vertex by vertex (v[i] = vertex i of cnt, T(i) = the removal
+// test on the triple v[i-1], v[i], v[i+1]): it tests v[0], v[1], ... in turn; a vertex that passes T is removed and the vertex
+// behind it is then kept WITHOUT being tested; a kept vertex becomes the next triple's first point.  So every tested triple
+// consists of original neighbours -- a vertex is only ever tested when the one before it was kept --, and
+//     removed(i) = T(i) and not removed(i-1),   removed(-1) = false:
+// inside a run of consecutive vertices that pass T, the first, third, fifth ... are removed.  One exception comes from the
+// pass working in place: the last vertex's triple ends on entry 0 of the array AS REWRITTEN, which is v[1] if v[0] was removed.
+// The pass also stops when two vertices are left; if this routine arrives at fewer than three it returns false and the
+// caller runs the sequential one (then, and only then, the stop can have mattered).  Vertex i in lane i, cnt <= 64.
+__device__ inline bool cleanup_convex_parallel(int lane, int dv, int cnt, uint32_t* vrows) {
+    const int ip = lane == 0 ? cnt - 1 : lane - 1, in = lane >= cnt - 1 ? 0 : lane + 1;
+    const int a = __shfl(dv, ip & 63), c = __shfl(dv, in);
+    const int v1 = __builtin_amdgcn_readlane(dv, 1);
+    auto removable = [](int s, int p, int e) {
+        const int dx = IRBPP_PX(e) - IRBPP_PX(s), dy = IRBPP_PY(e) - IRBPP_PY(s);
+        const int ux = IRBPP_PX(p) - IRBPP_PX(s), uy = IRBPP_PY(p) - IRBPP_PY(s);
+        int dist = ux * dy - uy * dx;
+        dist = dist < 0 ? -dist : dist;
+        const int inner = ux * (IRBPP_PX(e) - IRBPP_PX(p)) + uy * (IRBPP_PY(e) - IRBPP_PY(p));
+        return 2 * dist * dist <= dx * dx + dy * dy && dx != 0 && dy != 0 && inner >= 0;
+    };
+    bool T = lane < cnt && removable(a, dv, c);
+    unsigned long long tm = __ballot(T);
+    if (tm & 1ull) {                                     // (uniform) v[0] goes: the last triple ends on v[1]
+        if (lane == cnt - 1) T = removable(a, dv, v1);
+        tm = __ballot(T);
+    }
+    const unsigned long long below = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+    const unsigned long long z = ~tm & below;                                       // vertices before me that stay for sure
+    const int run_start = z != 0ull ? 64 - __clzll((long long)z) : 0;               // first vertex of my run of T's
+    const bool removed = T && ((lane - run_start) & 1) == 0;
+    const unsigned long long valid = cnt >= 64 ? ~0ull : ((1ull << cnt) - 1ull);
+    const unsigned long long kept = valid & ~__ballot(removed);
+    const int m = __popcll(kept);
+    if (m < 3) return false;
+    // find_convex_vetex on the kept vertices: neighbours = the kept vertices next to me, cyclically
+    const unsigned long long lo = kept & below, hi = kept & ~below & ~(1ull << lane);
+    const int pi = lo != 0ull ? 63 - __clzll((long long)lo) : 63 - __clzll((long long)kept);
+    const int ni = hi != 0ull ? __ffsll((long long)hi) - 1 : __ffsll((long long)kept) - 1;
+    const int pa = __shfl(dv, pi), pc = __shfl(dv, ni), pb = dv;
+    if ((kept >> lane) & 1ull) {
+        bool mark = true;
+        if (m > 3)
+            mark = (IRBPP_PX(pb) - IRBPP_PX(pa)) * (IRBPP_PY(pc) - IRBPP_PY(pa)) -
+                   (IRBPP_PY(pb) - IRBPP_PY(pa)) * (IRBPP_PX(pc) - IRBPP_PX(pa)) < 0;
+        if (mark) atomicOr(&vrows[IRBPP_PY(pb)], 1u << IRBPP_PX(pb));
+    }
+    return true;
+}
+
 // The same clean-up + convexity for a polygon of more than 64 vertices (a border of more than 64 points whose
 // polygon the clean-up changes: rarest of the rare), by one lane on a byte array it may overwrite.
 __device__ inline void cleanup_convex_serial(uint8_t* dst, int cnt, uint32_t* vrows) {
@@ -662,7 +712,18 @@ __device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) 
 template <int P>
 __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], const int (&pv)[P], const int (&j)[P],
                                                const int (&n)[P], const int (&sb)[P], const uint8_t* const (&pts)[P],
-                                               const int (&rot)[P], uint32_t* slots, uint8_t* scratch, uint32_t* vmask) {
+                                               const int (&rot)[P], uint32_t* slots, uint8_t* scratch, uint32_t* vmask
+#ifdef IRBPP_AB_POLY_ACCOUNT
+                                               , long long* acct = nullptr
+#endif
+                                               ) {
+#ifdef IRBPP_AB_POLY_ACCOUNT
+#define IRBPP_POLY_STAMP(k) if (acct) acct[k] = (long long)clock64()
+#define IRBPP_POLY_COUNT(k) if (acct) acct[k] += 1
+#else
+#define IRBPP_POLY_STAMP(k)
+#define IRBPP_POLY_COUNT(k)
+#endif
     int px[P], py[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) { px[u] = IRBPP_PX(pv[u]); py[u] = IRBPP_PY(pv[u]); }
@@ -717,6 +778,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
             }
         }
     }
+    IRBPP_POLY_STAMP(1);
     // 2. Douglas-Peucker, all slices of one recursion level per round; every lane keeps the end points of its
     // slice in registers, the split point's coordinates arrive with the arg-max
     bool keep[P], active[P];
@@ -737,6 +799,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         any_active |= active[u];
     }
     while (__ballot(any_active) != 0ull) {
+        IRBPP_POLY_COUNT(5);
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
@@ -787,6 +850,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
             any_active |= active[u];
         }
     }
+    IRBPP_POLY_STAMP(2);
     // 3. the polygon = kept points in contour order: every kept point files its index at its rank among the
     // kept points of its border (bit counts on the ballots), neighbours are the entries next to it
     unsigned long long kept[P];
@@ -845,6 +909,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     }
     // a border with a removable vertex tells all its points through its first slot word ... which holds the
     // polygon list; use the scratch bytes instead: one flag byte per border at its first position
+    IRBPP_POLY_STAMP(3);
     if (__ballot(any_redo) == 0ull) {                    // the common case: no clean-up anywhere in the wave
 #pragma unroll
         for (int u = 0; u < P; ++u)
@@ -873,17 +938,21 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         while (pending != 0ull) {
             const int l0 = __ffsll((long long)pending) - 1;
             pending &= pending - 1ull;
+            IRBPP_POLY_COUNT(6);
             const int sb0 = __builtin_amdgcn_readlane(sb[u], l0), cnt = __builtin_amdgcn_readlane(m[u], l0);
             const int s00 = __builtin_amdgcn_readlane(s0[u], l0), rot0 = __builtin_amdgcn_readlane(rot[u], l0);
             // rank of the start point s0 in the polygon list: the list is sorted by index
             int r0 = 0;
-            for (int i = 0; i < cnt; ++i) r0 += (int)(slots[sb0 + i] & 0xFFFFu) < s00 ? 1 : 0;
             if (cnt <= 64) {
+                const bool before = lane < cnt && (int)(slots[sb0 + (lane < cnt ? lane : 0)] & 0xFFFFu) < s00;
+                r0 = __popcll(__ballot(before));
                 int k = lane + r0;
                 if (k >= cnt) k -= cnt;
                 const int dv = lane < cnt ? (int)(slots[sb0 + k] >> 16) : 0;
-                cleanup_convex_wave(lane, dv, cnt, vmask + rot0 * 16);
+                if (!cleanup_convex_parallel(lane, dv, cnt, vmask + rot0 * 16))
+                    cleanup_convex_wave(lane, dv, cnt, vmask + rot0 * 16);
             } else {
+                for (int i = 0; i < cnt; ++i) r0 += (int)(slots[sb0 + i] & 0xFFFFu) < s00 ? 1 : 0;
                 for (int i = lane; i < cnt; i += 64) {
                     int k = i + r0;
                     if (k >= cnt) k -= cnt;

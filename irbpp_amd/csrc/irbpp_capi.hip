@@ -576,7 +576,11 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         if (tgrid > trace_grid_cap(env->P.N)) tgrid = trace_grid_cap(env->P.N);      // (w_big holds one scratch per wave of the grid)
         auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
         hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
+#ifdef IRBPP_AB_POLY_ACCOUNT
+        if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
+#else
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
+#endif
         hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T,
                            env->S, io, mode);
     }

@@ -1814,7 +1814,11 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
 #pragma unroll
                 for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
         }
+#ifdef IRBPP_AB_POLY_ACCOUNT
+        if (false) {
+#else
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
+#endif
             const int b0 = (int)S.w_cand[(size_t)seg * seg_cap + (size_t)(chunk - first_chunk) * TRACE_CPW].x;
             long long* row = prof + (size_t)b0 * PHASE_ROW;
             const long long t_end = (long long)clock64();
@@ -1837,8 +1841,18 @@ extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c16(const Pa
 // global memory with one atomic OR each.  The rounds of the eight lists are numbered through like the chunks of
 // the trace kernel; every round is the same amount of work, so the waves finish together.
 extern "C" __global__ void __launch_bounds__(64)
-irbpp_polygon_kernel(const Params P, const State S) {
+irbpp_polygon_kernel(const Params P, const State S
+#ifdef IRBPP_AB_POLY_ACCOUNT
+                     , long long* prof
+#endif
+                     ) {
     constexpr int PP = TRACE_P;
+#ifdef IRBPP_AB_POLY_ACCOUNT
+    long long acct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    long long* const ac = prof ? acct : nullptr;
+    const long long t_begin = (long long)clock64();
+    long long t_first_loaded = 0, cyc_hops = 0, cyc_dp = 0, cyc_rank = 0, cyc_tail = 0, rounds_done = 0;
+#endif
     __shared__ uint32_t dps[64 * PP];
     __shared__ uint8_t dpscratch[64 * PP];
     __shared__ __attribute__((aligned(16))) uint8_t lpts[64 * PP];
@@ -1880,9 +1894,29 @@ irbpp_polygon_kernel(const Params P, const State S) {
             if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; pv[u] = 0; }
             pts[u] = lpts + sbq[u];
         }
+#ifdef IRBPP_AB_POLY_ACCOUNT
+        const long long t_in = (long long)clock64();
+        if (rounds_done == 0) t_first_loaded = t_in - t_begin;
+        acct[1] = acct[2] = acct[3] = 0;
+        approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask, ac);
+        const long long t_out = (long long)clock64();
+        cyc_hops += acct[1] - t_in; cyc_dp += acct[2] - acct[1]; cyc_rank += acct[3] - acct[2]; cyc_tail += t_out - acct[3];
+        ++rounds_done;
+#else
         approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+#endif
         IRBPP_WAVE_SYNC();
     }
+#ifdef IRBPP_AB_POLY_ACCOUNT
+    if (prof && lane == 0 && (int)blockIdx.x < P.N) {
+        long long* row = prof + (size_t)blockIdx.x * PHASE_ROW;
+        row[11] = (long long)clock64() - t_begin;
+        row[12] = t_first_loaded;
+        row[13] = cyc_hops | (cyc_dp << 32);
+        row[14] = cyc_rank | (cyc_tail << 32);
+        row[15] = rounds_done | (acct[5] << 8) | (acct[6] << 24);
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------

@@ -219,6 +219,14 @@ def approx_poly_dp(curve: np.ndarray, epsilon: float, closed: bool = True) -> np
             stack.append((split, s_end))
             stack.append((s_start, split))
 
+    return np.array(cleanup_pass(dst, eps), dtype=np.int32).reshape(-1, 1, 2)
+
+
+def cleanup_pass(dst, eps: float = 1.0):
+    """Step 4 of approxPolyDP_ on its own (tests drive the device's clean-up routines with polygons of their choosing):
+    `dst` is the polygon after the Douglas-Peucker recursion, a list of (x, y), `eps` the squared tolerance; returns what the
+    pass leaves of it."""
+    dst = list(dst)
     # 4. clean-up: drop points on [almost] straight lines (in place, as OpenCV does)
     count = len(dst)
     new_count = count
@@ -249,4 +257,4 @@ def approx_poly_dp(curve: np.ndarray, epsilon: float, closed: bool = True) -> np
         wpos = (wpos + 1) % count
         pt = end_pt
         i += 1
-    return np.array(dst[:new_count], dtype=np.int32).reshape(-1, 1, 2)
+    return dst[:new_count]

@@ -114,3 +114,40 @@ extern "C" int host_approx_convex_segmented(const uint8_t* pts, const int* count
     if (points_per_lane == 4) return run_segmented<4>(pts, counts, n_borders, vrows);
     return -1;
 }
+
+// The clean-up pass + convexity of one polygon (vertex i in lane i, cnt <= 64) three ways: the loop-free routine
+// (returns 1 if it settled the polygon, 0 if it hands over to the sequential one), the wave-uniform sequential
+// routine, and the one-lane serial routine on a byte array.
+extern "C" int host_cleanup_parallel(const uint8_t* poly, int cnt, uint32_t* vrows) {
+    memset(vrows, 0, 16 * sizeof(uint32_t));
+    pthread_barrier_init(&g_bar, nullptr, 64);
+    int handled[64];
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l] {
+            threadIdx.x = (unsigned)l;
+            handled[l] = irbpp::cleanup_convex_parallel(l, l < cnt ? (int)poly[l] : 0, cnt, vrows) ? 1 : 0;
+        });
+    for (auto& t : lanes) t.join();
+    pthread_barrier_destroy(&g_bar);
+    for (int l = 1; l < 64; ++l) if (handled[l] != handled[0]) return -1;       // the verdict is uniform
+    return handled[0];
+}
+extern "C" void host_cleanup_wave(const uint8_t* poly, int cnt, uint32_t* vrows) {
+    memset(vrows, 0, 16 * sizeof(uint32_t));
+    pthread_barrier_init(&g_bar, nullptr, 64);
+    std::vector<std::thread> lanes;
+    for (int l = 0; l < 64; ++l)
+        lanes.emplace_back([&, l] {
+            threadIdx.x = (unsigned)l;
+            irbpp::cleanup_convex_wave(l, l < cnt ? (int)poly[l] : 0, cnt, vrows);
+        });
+    for (auto& t : lanes) t.join();
+    pthread_barrier_destroy(&g_bar);
+}
+extern "C" void host_cleanup_serial(const uint8_t* poly, int cnt, uint32_t* vrows) {
+    memset(vrows, 0, 16 * sizeof(uint32_t));
+    uint8_t buf[256];
+    memcpy(buf, poly, (size_t)cnt);
+    irbpp::cleanup_convex_serial(buf, cnt, vrows);
+}

@@ -283,6 +283,69 @@ def test_segmented_douglas_peucker_in_lockstep_emulation(wave, ppl):
     assert done > 300 and flagged >= 3                                # the clean-up branch was exercised
 
 
+def test_loop_free_cleanup_pass_equals_the_sequential_ones(wave):
+    """cleanup_convex_parallel (removed(i) = T(i) and not removed(i-1), by bit operations on the ballot of T) against the
+    two sequential statements of approx.cpp's clean-up pass, on polygons built to make the pass fire: vertices on
+    near-straight diagonals, runs of several removable vertices, removable first and last vertices (the in-place
+    wrap-around), and polygons the pass cuts down to two vertices (which the routine must hand over)."""
+    for f in (wave.host_cleanup_parallel, wave.host_cleanup_wave, wave.host_cleanup_serial):
+        f.argtypes = [u8p, C.c_int, u32p]
+    wave.host_cleanup_parallel.restype = C.c_int
+    rng = np.random.RandomState(5)
+    vp, vw, vs = ((C.c_uint32 * 16)() for _ in range(3))
+    settled = handed = changed = first_goes = 0
+    for case in range(1500):
+        cnt = int(rng.randint(3, 65)) if case % 3 else int(rng.randint(3, 9))
+        kind = case % 4
+        pts = []
+        x, y = int(rng.randint(0, 16)), int(rng.randint(0, 16))
+        dx, dy = 1, 1
+        while len(pts) < cnt:
+            pts.append((x, y))
+            if kind == 0:                                              # anything
+                x, y = int(rng.randint(0, 16)), int(rng.randint(0, 16))
+            else:                                                      # drifting diagonals with small kinks: many removable triples
+                if rng.rand() < (0.15 if kind == 1 else 0.4):
+                    dx, dy = int(rng.choice([-1, 1])), int(rng.choice([-1, 1]))
+                sx, sy = dx * int(rng.randint(1, 3)), dy * int(rng.randint(1, 3))
+                if rng.rand() < 0.3:
+                    sx += int(rng.choice([-1, 0, 1]))
+                x, y = int(np.clip(x + sx, 0, 15)), int(np.clip(y + sy, 0, 15))
+        arr = (C.c_uint8 * cnt)(*[px | (py << 4) for px, py in pts])
+        after = OC.cleanup_pass(pts, 1.0)                               # the oracle's statement of the pass ...
+        poly = np.array(after, dtype=np.int32).reshape(-1, 1, 2)
+        want = {tuple(int(v) for v in poly[i, 0]) for i in cvtools.find_convex_vetex(poly)}     # ... and of the convexity test
+        bits = lambda v: {(xx, yy) for yy in range(16) for xx in range(16) if (v[yy] >> xx) & 1}
+        wave.host_cleanup_serial(arr, cnt, vs)
+        assert bits(vs) == want, pts
+        if case % 10 == 0:                                             # (slow: 64 threads through ~cnt barriers)
+            wave.host_cleanup_wave(arr, cnt, vw)
+            assert bits(vw) == want, pts
+        verdict = wave.host_cleanup_parallel(arr, cnt, vp)
+        assert verdict in (0, 1)
+        if verdict == 1:
+            assert bits(vp) == want, pts
+            settled += 1
+        else:                                                          # handed over: the pass left fewer than three vertices
+            assert len(after) < 3, pts
+            handed += 1
+        changed += int(len(after) != cnt)
+        first_goes += int(_removable(pts[-1], pts[0], pts[1]))
+    assert settled > 1200 and handed >= 1 and changed > 600 and first_goes > 100
+
+
+def _removable(s, p, e):
+    dx, dy, ux, uy = e[0] - s[0], e[1] - s[1], p[0] - s[0], p[1] - s[1]
+    dist = abs(ux * dy - uy * dx)
+    inner = ux * (e[0] - p[0]) + uy * (e[1] - p[1])
+    return 2 * dist * dist <= dx * dx + dy * dy and dx != 0 and dy != 0 and inner >= 0
+
+
+def _removable_any(pts):
+    n = len(pts)
+    return any(_removable(pts[i - 1], pts[i], pts[(i + 1) % n]) for i in range(n))
+
+
 def test_register_transpose_of_a_level_image(host):
     """transpose16 (the trace kernel builds the column words of its level image with it): bit y of column word x
     == bit x of row word y, on random and extreme images."""
