@@ -123,6 +123,7 @@ void layout_lds(Params& P) {
     const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
     if (scratch < keys) scratch = keys;
     if (scratch < P.tile_words * 8) scratch = P.tile_words * 8;
+    if (scratch < 2 * CONTOUR_IPT * 16 * 16 * 2 + 512) scratch = 2 * CONTOUR_IPT * 16 * 16 * 2 + 512;   // hand-over: a batch's row words + candidate words, the list
     P.scratch_bytes = align16(scratch);
     P.o_hm = off;
     P.o_scratch = off;
@@ -264,7 +265,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
     P.heavy_cap = P.N >= 64 ? P.N / 8 : 0;                 // expensive bins the emit kernel serves first (generic data only, see launch_group)
-    P.heavy_thr = (P.S * 7) / 10;
+    P.heavy_thr = (P.S * 3) / 5;                          // (with the run-level start filter a > S bin has >= 0.70 S starts + isolated pixels, 99 % of the others < 0.65 S)
     ALLOC(w_heavy, 2 * (size_t)(XCD_STRIDE + P.heavy_cap));
 #undef ALLOC
     if (rc != IRBPP_OK) { irbpp_destroy(env); return rc; }

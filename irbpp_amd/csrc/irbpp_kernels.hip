@@ -408,10 +408,12 @@ __device__ __forceinline__ uint32_t row_candidates(const uint16_t* rows, int gg,
 }
 
 // first pass over the batch, one thread per (image, row): isolated pixels are marked as vertices on the spot; returns
-// the number of candidate starts of the whole batch (low 16 bits) and of its isolated pixels (high 16 bits).  (The candidates are recomputed by contour_list rather than kept:
-// IPT words per thread would be IPT more live registers through two barriers.)
+// the number of candidate starts of the whole batch (low 16 bits) and of its isolated pixels (high 16 bits).  The candidate
+// words go to `keep` ([images of the batch][16], next to the row words in LDS) for contour_list; without one (the hull
+// kernel's contour stage) contour_list computes them again.
 template <int IPT>
-__device__ inline int contour_candidates(const Params& P, const Lds& L, const uint16_t* const rows, int base, int ntasks) {
+__device__ inline int contour_candidates(const Params& P, const Lds& L, const uint16_t* const rows, int base, int ntasks,
+                                         uint16_t* const keep = nullptr) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, y = tid & 15;
     int my_count = 0;
@@ -421,6 +423,7 @@ __device__ inline int contour_candidates(const Params& P, const Lds& L, const ui
         uint32_t iso;
         const uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
         if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
+        if (keep) keep[gg * 16 + y] = (uint16_t)cand;
         my_count += __popc(cand) + (__popc(iso) << 16);
     }
     return block_sum_int(my_count, L.redi);
@@ -430,7 +433,7 @@ __device__ inline int contour_candidates(const Params& P, const Lds& L, const ui
 // returns their number
 template <int IPT>
 __device__ inline int contour_list(const Lds& L, const uint16_t* const rows, uint16_t* const clist, int base, int ntasks,
-                                   int nsub, int sub) {
+                                   int nsub, int sub, const uint16_t* const kept = nullptr) {
     const int tid = threadIdx.x;
     const int g = tid >> 4, y = tid & 15;
     __syncthreads();
@@ -441,7 +444,7 @@ __device__ inline int contour_list(const Lds& L, const uint16_t* const rows, uin
         const int gg = g + h * (BLOCK / 16);
         if (nsub == 1 || gg == sub) {
             uint32_t iso;
-            uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
+            uint32_t cand = kept ? (uint32_t)kept[gg * 16 + y] : row_candidates(rows, gg, y, base + gg < ntasks, iso);
             while (cand) {
                 const int x = __ffs((int)cand) - 1;
                 cand &= cand - 1u;
@@ -1450,6 +1453,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     // the batch's row words and the candidate list live in the bytes of the heightmap tile (its float32 copy is out)
     constexpr int CLIST = CONTOUR_CLIST;
     uint16_t* const rows = (uint16_t*)L.scratch;
+    uint16_t* const cwords = rows + IMGS * 16;               // the batch's candidate words, behind its row words
     uint16_t* const clist = L.clist;
     {   // naiveMask's bit rows first: they share their LDS bytes with the task index built next
         uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
@@ -1467,7 +1471,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         int batch_total = 0;
         for (int rep = 0; rep < IRBPP_REPS(9); ++rep) {
             contour_images<IPT>(P, L, rows, base, false);
-            batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks);
+            batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks, cwords);
         }
         niso += batch_total >> 16;
         batch_total &= 0xFFFF;
@@ -1486,7 +1490,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
             int total = 0;
-            for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub);
+            for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub, cwords);
             if (tid == 0) {
                 // This die's list; should it be full (the dispatcher gave this die far more than its share of speckled
                 // bins, or the device runs in a partition mode where XCC_ID does not spread the workgroups over eight
@@ -1530,7 +1534,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         // candidates mean a radix select and a sort, five times the time of an ordinary bin, and the emit kernel lasts as
         // long as the last of them.  Such bins enter a list that the emit kernel serves FIRST (its leading workgroups); the
         // count of starts + isolated pixels tracks the number of candidates closely (r = 0.997 on the "general" data set, every
-        // bin with more than S candidates has >= 390 of them against a median of 107).
+        // bin with more than S candidates has >= 350 of them against a median of 84; listed from 0.6 S on).
         int heavy = 0;
         const int turn = ka->io.heavy_turn;
         if (turn >= 0 && ncand + niso >= P.heavy_thr) {
@@ -1850,7 +1854,7 @@ irbpp_polygon_kernel(const Params P, const State S
 #ifdef IRBPP_AB_POLY_ACCOUNT
     long long acct[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     long long* const ac = prof ? acct : nullptr;
-    const long long t_begin = (long long)clock64();
+    const long long t_begin = (long long)clock64(), w_begin = (long long)wall_clock64();
     long long t_first_loaded = 0, cyc_hops = 0, cyc_dp = 0, cyc_rank = 0, cyc_tail = 0, rounds_done = 0;
 #endif
     __shared__ uint32_t dps[64 * PP];
@@ -1911,7 +1915,9 @@ irbpp_polygon_kernel(const Params P, const State S
     if (prof && lane == 0 && (int)blockIdx.x < P.N) {
         long long* row = prof + (size_t)blockIdx.x * PHASE_ROW;
         row[11] = (long long)clock64() - t_begin;
-        row[12] = t_first_loaded;
+        row[12] = t_first_loaded | (((long long)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1))) << 32);
+        row[10] = w_begin;                       // 100 MHz wall clock when this wave started / ended (one clock for all XCDs)
+        row[9] = (long long)wall_clock64();
         row[13] = cyc_hops | (cyc_dp << 32);
         row[14] = cyc_rank | (cyc_tail << 32);
         row[15] = rounds_done | (acct[5] << 8) | (acct[6] << 24);

@@ -25,10 +25,16 @@ for _ in range(a.steps):
     obs, _, _ = env.step(env.policy_minz(obs))
     torch.cuda.synchronize()
     c = cyc.cpu().numpy()
-    rows.append(c[c[:, 11] > 0][:, 11:16].copy())
+    sel = c[c[:, 11] > 0]
+    rows.append(sel[:, 11:16].copy())
+    w0, w1 = sel[:, 10], sel[:, 9]                       # 100 MHz wall clock (10 ns ticks), the same for all XCDs
+    b = (w0 - w0.min()) * 10
+    starts = {"first_start_to_last_end_ns": int((w1.max() - w0.min()) * 10), "start_ns": {"p50": int(np.percentile(b, 50)), "p90": int(np.percentile(b, 90)),
+              "p99": int(np.percentile(b, 99)), "max": int(b.max())}, "end_ns_p50": int(np.percentile((w1 - w0.min()) * 10, 50)),
+              "waves_running_at_ns": {str(t): int(((w0 - w0.min()) * 10 <= t).sum() - ((w1 - w0.min()) * 10 <= t).sum()) for t in (1000, 2000, 4000, 6000, 8000, 10000, 12000, 14000, 16000)}}
 r = np.concatenate(rows)
 M = (1 << 32) - 1
-total, load = r[:, 0], r[:, 1]
+total, load = r[:, 0], r[:, 1] & M
 hops, dp, rank, tail = r[:, 2] & M, r[:, 2] >> 32, r[:, 3] & M, r[:, 3] >> 32
 rounds, levels, cleanups = r[:, 4] & 255, (r[:, 4] >> 8) & 0xFFFF, r[:, 4] >> 24
 q = lambda v: {"mean": round(float(v.mean()), 1), "p50": float(np.percentile(v, 50)), "p99": float(np.percentile(v, 99)), "max": float(v.max())}
@@ -36,6 +42,7 @@ top = np.argsort(-total)[:8]
 print(json.dumps({"slowest_waves": [{"cycles": int(total[i]), "first_load": int(load[i]), "hops": int(hops[i]), "dp": int(dp[i]), "rank": int(rank[i]),
                                      "tail": int(tail[i]), "rounds": int(rounds[i]), "levels": int(levels[i]), "cleanups": int(cleanups[i])} for i in top]}))
 busy = rounds > 0
+print(json.dumps({"starts_last_step": starts}))
 print(json.dumps({"workload": a.workload, "bins": a.bins, "waves_sampled_per_step": int(len(r) / a.steps), "waves_with_rounds": int(busy.sum() / a.steps),
                   "total_cycles": q(total[busy]), "first_load": q(load[busy]), "hops": q(hops[busy]), "dp": q(dp[busy]), "rank": q(rank[busy]), "tail": q(tail[busy]),
                   "rounds": q(rounds[busy]), "levels_per_wave": q(levels[busy]), "cleanups": q(cleanups[busy]),
