@@ -1300,6 +1300,11 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, const doub
 // in `zsrc` (global memory, written where naiveMask is set) and naiveMask's bit rows `gvalid`; also records the
 // candidate keys for the next step's action_to_position.
 // ---------------------------------------------------------------------------------------
+#ifdef IRBPP_AB_EMIT_ACCOUNT
+#define IRBPP_EMIT_STAMP(k) do { if (io.phase_cycles && threadIdx.x == 0) io.phase_cycles[(size_t)b * PHASE_ROW + (k)] = (long long)clock64(); } while (0)
+#else
+#define IRBPP_EMIT_STAMP(k) do {} while (0)
+#endif
 __device__ inline void emit_observation(const Params& P, const State& S, const StepIO& io, const Lds& L, int b, int item,
                                         int nvalid, float* obs, const double* zsrc, const uint32_t* gvalid) {
     const int tid = threadIdx.x;
@@ -1312,18 +1317,36 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
     uint32_t* okey = keys + R * AC;                 // [S]
     uint32_t* hist = (uint32_t*)L.img;              // [256] counters of the radix select: the level images are done with
+    // One wave lists them, a lane per (rotation, column) -- four rotations at a time --: the lane gathers its column of the
+    // rotation's vertex bits (16 LDS reads of row words, bit cx of each), the columns' counts are summed over the lanes on
+    // the DPP network, and every lane writes the keys of its column, rows ascending, behind those of the columns before
+    // it.  (Until session 35: a thread per action cell and one workgroup-wide scan of the flags per rotation -- two
+    // barriers and a round of LDS each, 3.9 k of the workgroup's 11.5 k cycles, profiles/r04/s34.)
     int n = 0;
-    {
-        const int cx = fdiv(tid, Ax, P.mg_ax), cy = tid - cx * Ax;     // col-major walk: x = column (ly), y = row (lx)
-        for (int r = 0; r < R; ++r) {
-            const bool flag = tid < AC && ((L.vmask[r * 16 + cy] >> cx) & 1u);
-            int total;
-            const int pos = block_scan_flag(flag, L.redi, total);
-            if (flag) keys[n + pos] = ((uint32_t)r << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
-            n += total;
+    if (tid < 64) {
+        const int lane = tid, cx = lane & 15;
+        for (int r0 = 0; r0 < R; r0 += 4) {
+            const int r = r0 + (lane >> 4);
+            uint32_t col = 0u;
+            if (r < R && cx < Ay) {
+#pragma unroll
+                for (int cy = 0; cy < 16; ++cy) col |= ((L.vmask[r * 16 + cy] >> cx) & 1u) << cy;
+                col &= (1u << Ax) - 1u;
+            }
+            const int cnt = __popc(col), incl = wave_inclusive_sum(cnt);
+            int at = n + incl - cnt;
+            while (col != 0u) {
+                const int cy = __ffs((int)col) - 1;
+                col &= col - 1u;
+                keys[at++] = ((uint32_t)r << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+            }
+            n += __builtin_amdgcn_readlane(incl, 63);
         }
+        if (tid == 0) L.redi[34] = n;
     }
     __syncthreads();
+    n = L.redi[34];
+    IRBPP_EMIT_STAMP(11);
     int nrows;
     bool fallback = false;
     const uint32_t* rows;
@@ -1366,6 +1389,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         else rowval[i] = (float)zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];     // a candidate is a valid cell
     }
     __syncthreads();
+    IRBPP_EMIT_STAMP(12);
     // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last
     // A registered observation buffer (irbpp_register_obs_buffer) is only ever written by this library, which
     // remembers per bin how many rows it wrote last time: the rows beyond are still zero and are not written again
@@ -1391,6 +1415,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         }
         obs[e] = v;
     }
+    IRBPP_EMIT_STAMP(13);
     // candidate keys for the next apply: only the rows that exist (BinState::nrows tells apply where they end)
     for (int i = tid; i < nrows; i += BLOCK) S.cand[(size_t)b * P.S + i] = rows[i];
     if (tid == 0) {
@@ -1571,6 +1596,9 @@ __device__ __forceinline__ void emit_body(const Params P, const Tables T, const 
     // The grid's first heavy_cap workgroups serve the bins the transition kernel listed as expensive (see split_handover),
     // the rest the bins in launch order minus those: the expensive ones start at once instead of wherever their index
     // puts them.  The list of the next launch (the other one of two, used in turn) is cleared here.
+#ifdef IRBPP_AB_EMIT_ACCOUNT
+    const long long t_entry = (long long)clock64();
+#endif
     int slot = (int)blockIdx.x + io.block_off, b = 0;
     bool mapped = false;
     if constexpr (HEAVY_FIRST) {
@@ -1594,6 +1622,9 @@ __device__ __forceinline__ void emit_body(const Params P, const Tables T, const 
             if (io.heavy_turn >= 0 && b >= 0 && b < P.N && S.w_meta[(size_t)b * WMETA + 4] != 0) return;       // served by a leading workgroup
     }
     if (b < 0 || b >= P.N) return;                   // the transition kernel has flagged it already
+#ifdef IRBPP_AB_EMIT_ACCOUNT
+    if (io.phase_cycles && tid == 0) { io.phase_cycles[(size_t)b * PHASE_ROW + 6] = t_entry; io.phase_cycles[(size_t)b * PHASE_ROW + 7] = (long long)clock64(); }
+#endif
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
     const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
     for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
@@ -1601,6 +1632,7 @@ __device__ __forceinline__ void emit_body(const Params P, const Tables T, const 
     __syncthreads();
     stamp(io, b, 3);
     emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
+    IRBPP_EMIT_STAMP(14);
 }
 #define IRBPP_EMIT_KERNEL(NAME, HF)                                                                                      \
     extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))                      \
@@ -1818,7 +1850,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
 #pragma unroll
                 for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
         }
-#ifdef IRBPP_AB_POLY_ACCOUNT
+#if defined(IRBPP_AB_POLY_ACCOUNT) || defined(IRBPP_AB_EMIT_ACCOUNT)
         if (false) {
 #else
         if (prof && lane == 0) {                 // tooling: this wave's account of its first chunk, in the row of that chunk's first bin
