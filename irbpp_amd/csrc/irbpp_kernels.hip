@@ -1289,7 +1289,13 @@ __device__ inline void select_smallest(const Params& P, const Lds& L, const doub
                     khi[l] = ah; klo[l] = al; kps[l] = (uint16_t)ap;
                 }
             }
-            __syncthreads();
+            // A stride below 128 pairs elements of one 128-element block, and block t >> 6 belongs to the wave of thread t
+            // (t = tid + m * BLOCK: blocks w, w + 4, ...): such a round reads and writes only what this wave wrote, and a
+            // wave's LDS operations execute in order.  The workgroup meets only around the rounds that cross blocks: 3 of
+            // the 45 rounds of a 512-element sort.
+            const int j_next = j > 1 ? (j >> 1) : k;                 // (the next merge starts at stride 2k / 2)
+            if (j >= 128 || j_next >= 128 || (j == 1 && k == npad)) __syncthreads();
+            else IRBPP_WAVE_SYNC();
         }
     for (int r = tid; r < want; r += BLOCK) out[r] = sel[kps[r]];
     __syncthreads();
