@@ -1405,21 +1405,24 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         if (prev_rows >= 0) write_rows = prev_rows > nrows ? prev_rows : nrows;
         if (tid == 0) io.obs_rows[b] = nrows;        // (everyone read the old count at the top of the function, barriers ago)
     }
+    // a thread per ROW (five stores of one float each, 20 bytes apart between lanes): the hundred rows of an ordinary bin
+    // are the work of two waves, ~15 vector instructions each.  (A thread per float -- coalesced stores, but a division by
+    // five, a five-way select and two LDS reads per float on all four waves, twice -- was 2.5 k of the workgroup's 10 k
+    // cycles in a kernel that is bound by instruction issue, profiles/r04/s34 - s37.)
     for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
-    for (int e = tid; e < 5 * write_rows; e += BLOCK) {
-        const int row = e / 5, col = e - row * 5;
-        float v = 0.0f;
+    for (int row = tid; row < write_rows; row += BLOCK) {
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
         if (row < nrows) {
             const uint32_t k = rows[row];
-            switch (col) {
-                case 0: v = (float)(k >> 16); break;
-                case 1: v = (float)((k >> 8) & 255u); break;
-                case 2: v = (float)(k & 255u); break;
-                case 3: v = fallback ? (float)P.bin_z : rowval[row]; break;
-                default: v = fallback ? rowval[row] : 1.0f; break;
-            }
+            const float rv = rowval[row];
+            v0 = (float)(k >> 16);
+            v1 = (float)((k >> 8) & 255u);
+            v2 = (float)(k & 255u);
+            v3 = fallback ? (float)P.bin_z : rv;
+            v4 = fallback ? rv : 1.0f;
         }
-        obs[e] = v;
+        float* const o = obs + 5 * row;
+        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
     }
     IRBPP_EMIT_STAMP(13);
     // candidate keys for the next apply: only the rows that exist (BinState::nrows tells apply where they end)
