@@ -1320,6 +1320,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     // the candidate rows the buffer holds from last time (registered buffers): asked for first -- nothing depends on it until
     // the rows are stored, and as a load in front of them it was one more memory round trip on a path made of those
     const int prev_rows = io.obs_rows != nullptr ? io.obs_rows[b] : -1;
+    if (tid == 0) ((unsigned long long*)L.redd)[7] = ~0ull;         // the MINZ bids' word (see the end; several barriers lie between)
     uint32_t* keys = (uint32_t*)L.scratch;          // [R*AC]
     uint32_t* okey = keys + R * AC;                 // [S]
     uint32_t* hist = (uint32_t*)L.img;              // [256] counters of the radix select: the level images are done with
@@ -1385,18 +1386,8 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         __syncthreads();
     }
 
-    // ---- the rows' one data-dependent float: H = (float) posZValid of the row, or in the fallback its validity flag.
-    // posZValid is read where it lies (global memory, L2 / Infinity Cache): only the ~100 rows of the bin, not the
-    // whole [R][AC] grid -- the emit kernel is bandwidth-bound and the grid was 40 % of what it moved.
-    float* rowval = (float*)hist;                   // [S]: the radix counters / sort keys are done with
-    for (int i = tid; i < nrows; i += BLOCK) {
-        const uint32_t k = rows[i];
-        if (fallback) rowval[i] = (float)((gvalid[(k >> 16) * 16 + ((k >> 8) & 255u)] >> (k & 255u)) & 1u);
-        else rowval[i] = (float)zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];     // a candidate is a valid cell
-    }
-    __syncthreads();
     IRBPP_EMIT_STAMP(12);
-    // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last
+    // ---- emit: candidate block [S][5] (item vector and heightmap were written by the transition kernel); float32 cast last.
     // A registered observation buffer (irbpp_register_obs_buffer) is only ever written by this library, which
     // remembers per bin how many rows it wrote last time: the rows beyond are still zero and are not written again
     // (typically 100 of 500 rows exist).
@@ -1405,44 +1396,42 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
         if (prev_rows >= 0) write_rows = prev_rows > nrows ? prev_rows : nrows;
         if (tid == 0) io.obs_rows[b] = nrows;        // (everyone read the old count at the top of the function, barriers ago)
     }
-    // a thread per ROW (five stores of one float each, 20 bytes apart between lanes): the hundred rows of an ordinary bin
-    // are the work of two waves, ~15 vector instructions each.  (A thread per float -- coalesced stores, but a division by
-    // five, a five-way select and two LDS reads per float on all four waves, twice -- was 2.5 k of the workgroup's 10 k
-    // cycles in a kernel that is bound by instruction issue, profiles/r04/s34 - s37.)
+    // A thread per ROW, once: the row's one data-dependent float -- H = (float) posZValid of its cell, read where it lies
+    // (global memory, L2 / Infinity Cache: only the ~100 rows of the bin, not the whole [R][AC] grid), or in the fallback the
+    // cell's validity flag --, its five floats (five stores, 20 bytes apart between lanes), its key for the next apply and
+    // its bid for the MINZ policy.  The hundred rows of an ordinary bin are the work of two waves.  (As separate loops -- row
+    // values into LDS, a barrier, a thread per FLOAT with a division by five and a five-way select, keys, policy -- this was
+    // half of the workgroup's cycles in a kernel bound by instruction issue, profiles/r04/s34 - s38.)
+    float best = INFINITY;                            // MINZ: the lowest float32 H among V == 1, first on ties (ascending rows per thread)
+    int bi = 0x7fffffff;
     for (int rep = 0; rep < IRBPP_REPS(3); ++rep)
     for (int row = tid; row < write_rows; row += BLOCK) {
         float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
         if (row < nrows) {
             const uint32_t k = rows[row];
-            const float rv = rowval[row];
+            float rv;
+            if (fallback) rv = (float)((gvalid[(k >> 16) * 16 + ((k >> 8) & 255u)] >> (k & 255u)) & 1u);
+            else rv = (float)zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];       // a candidate is a valid cell
             v0 = (float)(k >> 16);
             v1 = (float)((k >> 8) & 255u);
             v2 = (float)(k & 255u);
             v3 = fallback ? (float)P.bin_z : rv;
             v4 = fallback ? rv : 1.0f;
+            S.cand[(size_t)b * P.S + row] = k;       // candidate keys for the next apply: only the rows that exist (BinState::nrows tells apply where they end)
+            if (!fallback && rv < best) { best = rv; bi = row; }
         }
         float* const o = obs + 5 * row;
         o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
     }
     IRBPP_EMIT_STAMP(13);
-    // candidate keys for the next apply: only the rows that exist (BinState::nrows tells apply where they end)
-    for (int i = tid; i < nrows; i += BLOCK) S.cand[(size_t)b * P.S + i] = rows[i];
     if (tid == 0) {
         S.bs[b].cur_item = item;
         S.bs[b].nvalid = nvalid;
         S.bs[b].nrows = nrows;
     }
-    // The scripted MINZ policy on the rows just written (irbpp_policy_minz on this observation gives the same):
-    // the row with the lowest float32 H among V == 1, first on ties.  Fallback rows all carry H = bin_z and are
-    // sorted valid-first, so the answer there is row 0 (or "none" = 0).
+    // The scripted MINZ policy on the rows just written (irbpp_policy_minz on this observation gives the same).  Fallback
+    // rows all carry H = bin_z and are sorted valid-first, so the answer there is row 0 (or "none" = 0).
     if (io.auto_action != nullptr) {
-        float best = INFINITY;
-        int bi = 0x7fffffff;
-        if (!fallback)
-            for (int i = tid; i < nrows; i += BLOCK) {
-                const float h = rowval[i];
-                if (h < best) { best = h; bi = i; }              // ascending i per thread: the first of equals stays
-            }
         {   // the wave's (lowest H, lowest row) on the DPP network: lane 63 ends up with it (see wave_max_f64)
 #define IRBPP_ARGMIN_STEP(CTRL, ROWS)                                                                                          \
             {                                                                                                                  \
@@ -1453,19 +1442,18 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
             IRBPP_ARGMIN_STEP(0x111, 0xF) IRBPP_ARGMIN_STEP(0x112, 0xF) IRBPP_ARGMIN_STEP(0x114, 0xF) IRBPP_ARGMIN_STEP(0x118, 0xF)
             IRBPP_ARGMIN_STEP(0x142, 0xA) IRBPP_ARGMIN_STEP(0x143, 0xC)
 #undef IRBPP_ARGMIN_STEP
-            best = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(best), 63));
-            bi = __builtin_amdgcn_readlane(bi, 63);
+        }
+        // the waves' bids meet in one 64-bit LDS word: H as an unsigned number that orders like the float (-0 made +0 first:
+        // the two compare equal) above the row; a wave without a bid offers +inf | 0x7fffffff, the word starts above that
+        if ((tid & 63) == 63) {
+            const uint32_t fb = (uint32_t)__float_as_int(best + 0.0f);
+            const uint32_t su = fb ^ ((fb >> 31) != 0u ? 0xFFFFFFFFu : 0x80000000u);
+            atomicMin((unsigned long long*)L.redd + 7, ((unsigned long long)su << 32) | (uint32_t)bi);
         }
         __syncthreads();
-        if ((tid & 63) == 0) { ((float*)L.redi)[4 + (tid >> 6)] = best; L.redi[8 + (tid >> 6)] = bi; }
-        __syncthreads();
         if (tid == 0) {
-            for (int w = 1; w < WAVES; ++w) {
-                const float ob = ((float*)L.redi)[4 + w];
-                const int oi = L.redi[8 + w];
-                if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-            }
-            io.auto_action[b] = bi == 0x7fffffff ? 0 : bi;
+            const int won = (int)(uint32_t)(((const unsigned long long*)L.redd)[7] & 0xFFFFFFFFull);
+            io.auto_action[b] = won == 0x7fffffff ? 0 : won;
         }
     }
     stamp(io, b, 4);
