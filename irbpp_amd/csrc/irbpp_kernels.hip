@@ -344,6 +344,10 @@ __device__ inline int contour_tasks(const Params& P, const Lds& L) {
     const int tid = threadIdx.x, R = P.R;
     int ntasks = 0;
     for (int r = 0; r < R; ++r) ntasks += __popcll(L.present[r]);
+    // (`#pragma unroll 1` on the workgroup-strided loops that run once or twice: left to itself the compiler unrolls them
+    // sixteen-fold with a remainder loop, and a wave that makes one trip still walks ~25 vector and ~20 scalar instructions of
+    // trip-count arithmetic and skipped bodies per loop -- a dozen such loops in a kernel bound by instruction issue)
+#pragma unroll 1
     for (int t = tid; t < R * 64; t += BLOCK) {
         const int r = t >> 6, l = t & 63;
         const unsigned long long m = L.present[r];
@@ -368,6 +372,7 @@ __device__ inline void contour_images(const Params& P, const Lds& L, uint16_t* c
     const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
     uint16_t* const cols = rows + IMGS * 16;         // [IMGS][16] column words (bit y of word x), after the row words
+#pragma unroll 1
     for (int i = tid; i < IMGS * 16; i += BLOCK) rows[i] = 0;             // the column copy is derived below
     __syncthreads();
     // Image rows: thread tid holds action cell (X, Y), bit Y of row word X of the image its level belongs to.  One
@@ -758,11 +763,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
     int* srw = L.sr;                                         // all R ShapeRots of the item in ONE coalesced load
     if (item >= 0 && !sr_staged)                             // (the transition kernel may have them in place already)
+#pragma unroll 1
         for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
     for (int rep = 0; rep < IRBPP_REPS(13); ++rep) {
     if (tid < R) L.present[tid] = 0ull;
     if (tid == 0) L.redi[GENERIC_TICKET] = WAVES;            // generic path: the first WAVES tasks are taken without a ticket
+#pragma unroll 1
     for (int i = tid; i < R * 16; i += BLOCK) { L.vmask[i] = 0u; L.vbits[i] = 0u; }
+#pragma unroll 1
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     }
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
@@ -774,12 +782,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         // (2) a b x b block is (b / step)^2 neighbouring action cells.  (Reading the b^2 cells of every block straight from
         // the planes took 16 scattered reads with their index arithmetic per block at b = 4, step = 2.)
         const int planes = P.pp * P.pp, mq = P.block_b / P.step;
+#pragma unroll 1
         for (int t = tid; t < AC; t += BLOCK) {
             double m = L.hm[t];
             for (int pl = 1; pl < planes; ++pl) m = fmax(m, L.hm[pl * P.PL + t]);
             L.c2[t] = m;
         }
         __syncthreads();
+#pragma unroll 1
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
             const double* c = L.c2 + pi * Ay + pj;
@@ -1480,6 +1490,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     {   // naiveMask's bit rows first: they share their LDS bytes with the task index built next
         uint32_t* gb = ka->S.w_valid + (size_t)b * P.R * 16;
         for (int rep = 0; rep < IRBPP_REPS(14); ++rep)
+#pragma unroll 1
         for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
         __syncthreads();
     }
@@ -1501,7 +1512,9 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)rows;
         for (int rep = 0; rep < IRBPP_REPS(14); ++rep) {
+#pragma unroll 1
         for (int i = tid; i < nb * 8; i += BLOCK) gi[(size_t)base * 8 + i] = lr[i];
+#pragma unroll 1
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
         }
         // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
@@ -1534,6 +1547,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
             __syncthreads();
             if (L.redi[11] >= 0) {
                 uint2* flat = ka->S.w_cand + (size_t)L.redi[12] * P.seg_cap + L.redi[11];
+#pragma unroll 1
                 for (int i = tid; i < total; i += BLOCK) {
                     const uint32_t e = clist[i];
                     flat[i] = make_uint2((uint32_t)b, ((uint32_t)(base + (e & 127u)) << 8) | (((e >> 11) & 15u) << 4) | ((e >> 7) & 15u));
@@ -1545,6 +1559,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     }
     uint32_t* gv = ka->S.w_vmask + (size_t)b * P.R * 16;
     for (int rep = 0; rep < IRBPP_REPS(14); ++rep)
+#pragma unroll 1
     for (int i = tid; i < P.R * 16; i += BLOCK) gv[i] = L.vmask[i];
     if (tid == 0) {
         int32_t* m = ka->S.w_meta + (size_t)b * WMETA;
@@ -1624,6 +1639,7 @@ __device__ __forceinline__ void emit_body(const Params P, const Tables T, const 
 #endif
     float* obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
     const uint32_t* gv = S.w_vmask + (size_t)b * P.R * 16;
+#pragma unroll 1
     for (int i = tid; i < P.R * 16; i += BLOCK) L.vmask[i] = gv[i];
     const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
     __syncthreads();
@@ -2115,6 +2131,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             const Cell* cells = T.bcell + sr.ob;
             for (int rep = 0; rep < IRBPP_REPS(11); ++rep) {
             double m = sr.has_out ? 0.0 : -1e300;
+#pragma unroll 1
             for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v);
             z = block_max_f64(m, L.redd);
             }
@@ -2159,6 +2176,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
             const Cell* cells = T.tcell + sr.ot;
             for (int rep = 0; rep < IRBPP_REPS(12); ++rep)
+#pragma unroll 1
             for (int e = tid; e < sr.nt; e += BLOCK) {
                 const Cell tc = e == tid ? tc0 : cells[e];
                 const int ij = tc.ij;

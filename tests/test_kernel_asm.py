@@ -54,8 +54,9 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
     1.1 us): a build that spills more than the state the profiles were taken on fails here instead of shipping."""
     sizes = asmcheck.scratch_sizes(build.build(force=False))
     limits = {"irbpp_emit_kernel": 0, "irbpp_trace_kernel": 0, "irbpp_trace_kernel_c32": 0, "irbpp_trace_kernel_c16": 0,
-              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 12, "irbpp_env_kernel_box8": 12, "irbpp_env_kernel_generic8": 60,
-              "irbpp_env_kernel_generic": 0, "irbpp_env_kernel_box": 0, "irbpp_env_kernel_wide": 0}
+              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 0, "irbpp_env_kernel_box8": 0, "irbpp_env_kernel_generic8": 60,
+              "irbpp_env_kernel_generic": 0, "irbpp_env_kernel_box": 0,
+              "irbpp_env_kernel_wide": 36}           # (_wide: the A/B build that decides the overlap path at run time; not a default)
     for kernel, limit in limits.items():
         assert kernel in sizes, kernel
         assert sizes[kernel] <= limit, (kernel, sizes[kernel], limit)

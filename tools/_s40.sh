@@ -1,0 +1,6 @@
+#!/bin/bash
+# Tooling: round-4 session 40: `#pragma unroll 1` on the workgroup-strided loops that run once or twice (the compiler unrolled them sixteen-fold)
+O=gpurun_out/r04_s40; mkdir -p $O
+timeout 1200 python -m pytest tests -m gpu -q > $O/pytest_gpu.txt 2>&1; echo "pytest rc=$?" >> $O/pytest_gpu.txt; tail -3 $O/pytest_gpu.txt | cut -c1-200
+bash tools/gpu_kernel_stats.sh r04_s40 blockout general cube 2>&1 | grep "irbpp_env\|irbpp_emit" | cut -c1-110
+timeout 300 python tools/ab_matrix.py --repeat 2 blockout:4096:1:0 general:4096:1:0 cube:4096:1:0 blockout_k10:1024:1:0 abc_fine:2048:1:0 > $O/ab_matrix.jsonl 2> $O/ab_matrix.err; cat $O/ab_matrix.jsonl | cut -c1-150
