@@ -70,7 +70,7 @@ int dev_upload(irbpp_env* env, const T** out, const T* host, size_t count) {
 inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np.round(x, 6)
 constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
 constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
-constexpr int TRACE_CPW32_BINS = 0;         // ... 32 per wave (0: never; set from the A/B runs in profiles/r04)
+constexpr int TRACE_CPW32_BINS = 1024;      // ... 32 per wave (profiles/r04 session 41: +1.5 ... 1.9 % at 512 / 1024 bins, -0.3 % at 2048; 16 per wave loses everywhere)
 inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
 
 inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
