@@ -476,6 +476,18 @@ def main():
             grouped["ms_per_step"] = float(np.mean([r["ms_per_step"] for r in runs]))
             grouped["instances"] = [r["value"] for r in runs]
             grouped["note"] = "mean of two instances (both listed); see bench.py"
+            # ... and the same in a child process that asks the runtime for eight hardware queues (GPU_MAX_HW_QUEUES, read when
+            # a process initialises HIP -- irbpp_amd.use_hardware_queues): with the default four the group streams share queues
+            try:
+                import subprocess
+                child_env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+                res = subprocess.run([sys.executable, os.path.abspath(__file__), "--groups", "4", "--bins", str(bins), "--no-extra",
+                                      "--no-cpu-baseline", "--min-seconds", "0.3"], env=child_env, capture_output=True, text=True, timeout=240)
+                line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+                grouped["with_8_hardware_queues"] = {"value": json.loads(line)["value"], "ms_per_step": json.loads(line)["ms_per_step"],
+                                                     "note": "child process, GPU_MAX_HW_QUEUES=8, four groups"}
+            except Exception as exc:                                     # noqa: BLE001 -- an extra, never the measurement
+                grouped["with_8_hardware_queues"] = {"error": repr(exc)[:200]}
         if workload == "blockout":
             if bins != 8192:
                 extra["bins8192_one_gpu"] = side_run("blockout", 8192)
