@@ -13,6 +13,7 @@ libirbpp_hip.so.  Without that library this module raises -- there is no CPU pat
 from __future__ import annotations
 
 import ctypes as C
+import os
 import time
 from collections.abc import Sequence
 from typing import Optional
@@ -456,10 +457,20 @@ def groups_for(workload_kind: str, num_bins: int) -> int:
     with 2 groups at 4096 bins, abc_fine 5.6 -> 6.2 / 6.7 M with 2 / 4 groups at 2048 -- whereas a buffered BlockOut step
     at 1024 bins is a chain of six short latency-bound kernels whose length does not depend on the number of bins:
     groups change nothing there (10.8 / 11.0 / 6.1 M for 1 / 2 / 4 groups, the last one hit by stream-to-queue aliasing).
-    Lattice data at full width gains from four groups (29.0 -> 35.3 M at 4096 bins) when the caller can work on one
-    group while the others step; ``value`` of bench.py stays the one-group figure."""
+    Lattice data at full width gains from four groups ONLY if the group streams get hardware queues of their own: with the
+    runtime's default of four queues they share them (BlockOut at 4096 bins: 27 M as four groups against 35 M as one), with
+    ``GPU_MAX_HW_QUEUES=8`` (irbpp_amd.use_hardware_queues, before the process initialises HIP) four groups run at 38 - 41 M
+    (profiles/r04/s42, s43) -- so the answer for lattice data is 4 from 4096 bins on when that variable says eight or more,
+    else 1.  ``value`` of bench.py stays the one-group figure."""
     if workload_kind in ("general", "abc_fine") and num_bins >= 1024 and num_bins % 4 == 0:
         return 4 if workload_kind == "abc_fine" else 2
+    if workload_kind not in ("general", "abc_fine") and num_bins >= 4096 and num_bins % 4 == 0:
+        try:
+            queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            queues = 4
+        if queues >= 8:
+            return 4
     return 1
 
 
