@@ -237,9 +237,50 @@ def minz_action(obs, S):
     return int(np.argmin(np.where(v, c[:, 3], np.inf)))
 
 
-def run_online(shapes, sequences, steps, S=500, res_h=0.01):
+class _CandidateTap(object):
+    """Wraps the reference's getConvexHullActions as binPhy.py calls it (:205) and remembers the row count and the
+    placement heights of the last call: the generator needs to know when the ``> S`` selection (np.argsort,
+    binPhy.py:209-212) had to order EQUAL heights -- the one place where numpy's pinned 1.21.3 and this container's
+    numpy may legitimately differ -- so that a recording can stop in front of it."""
+
+    def __init__(self):
+        self.real = ref_cvtools.getConvexHullActions
+        self.n = 0
+        self.ambiguous = False
+
+    def __call__(self, posZValid, naiveMask, res):
+        c = self.real(posZValid, naiveMask, res)
+        self.n = 0 if c is None else len(c)
+        self.ambiguous = False
+        if c is not None and len(c) > self.S:
+            h = np.sort(c[:, 3])[:self.S + 1]
+            self.ambiguous = bool((np.diff(h) == 0).any())        # a tie among the S + 1 lowest: order or cut unspecified
+        return c
+
+    def install(self, S):
+        self.S = S
+        ref_binphy.getConvexHullActions = self
+        return self
+
+    def remove(self):
+        ref_binphy.getConvexHullActions = self.real
+
+
+def run_online(shapes, sequences, steps, S=500, res_h=0.01, tap=False):
+    """``tap``: also record the candidate row count in front of every observation (``ncand``) and END the recording in
+    front of the first observation whose > S selection had ties among its S + 1 lowest heights (see _CandidateTap)."""
+    ct = _CandidateTap().install(S) if tap else None
+    try:
+        return _run_online(shapes, sequences, steps, S, res_h, ct)
+    finally:
+        if ct is not None:
+            ct.remove()
+
+
+def _run_online(shapes, sequences, steps, S, res_h, ct):
     env = make_reference_env(shapes, sequences, 1, S, res_h=res_h)
     obs = env.reset()
+    ncand = [ct.n] if ct else None
     rec = dict(obs=[obs.copy()], act=[], rew=[], done=[], counter=[], ratio=[], ep_r=[],
                mask=[env.space.naiveMask.copy()], posz=[env.space.posZmap.copy()])
     rewards = []
@@ -249,14 +290,25 @@ def run_online(shapes, sequences, steps, S=500, res_h=0.01):
         rewards.append(r)
         rec["act"].append(a); rec["rew"].append(r); rec["done"].append(d)
         rec["counter"].append(info.get("counter", -1)); rec["ratio"].append(info.get("ratio", -1.0))
+        if ct is not None and ct.ambiguous and not d:   # the observation this step returned is numpy-build dependent
+            for key in ("act", "rew", "done", "counter", "ratio"):
+                rec[key].pop()
+            break
         if d:                                           # shmem_vec_env.py:142-144, monitor.py:62-64
             rec["ep_r"].append(round(sum(rewards), 6)); rewards = []
             obs = env.reset()
+            if ct is not None and ct.ambiguous:
+                raise RuntimeError("ambiguous > S selection in a reset observation: pick another seed")
         else:
             rec["ep_r"].append(-1.0)
         rec["obs"].append(obs.copy())
         rec["mask"].append(env.space.naiveMask.copy()); rec["posz"].append(env.space.posZmap.copy())
-    return {k: np.array(v) for k, v in rec.items()}
+        if ct is not None:
+            ncand.append(ct.n)
+    out = {k: np.array(v) for k, v in rec.items()}
+    if ct is not None:
+        out["ncand"] = np.array(ncand)
+    return out
 
 
 def run_hier(shapes, sequences, steps, k, S=500):
@@ -276,6 +328,85 @@ def run_hier(shapes, sequences, steps, k, S=500):
             order_obs = env.reset()
         rec["order_obs"].append(order_obs.copy())
     return {k2: np.array(v) for k2, v in rec.items()}
+
+
+def more_than_s_cases(n_cases=6, S=500):
+    """The ``> S`` branch of cur_observation (binPhy.py:209-212) with PAIRWISE DISTINCT placement heights, so that
+    ``np.argsort(candidates[:,3])[:S]`` has one answer whatever the numpy build: random float heightmaps are written
+    into the reference's own Space (every valid cell becomes a level component of its own -> far more than S rows),
+    the location observation is taken through the reference's get_action_candidates (which recomputes posZmap from
+    the heightmap as it stands, binPhy.py:161-169) and the placement is stepped.  A consumer does the same."""
+    shapes = more_than_s_shapes()
+    seqs = synthetic.make_sequences(shapes.n_shapes, 16, 40, seed=3)
+    k = 2
+    ct = _CandidateTap().install(S)
+    try:
+        env = make_reference_env(shapes, seqs, k, S)
+        order = env.reset()
+        rng = np.random.RandomState(5)
+        rec = dict(order_obs0=order.copy(), hm=[], order_act=[], loc_obs=[], ncand=[], act=[], rew=[], done=[], order_obs=[])
+        t = 0
+        while len(rec["hm"]) < n_cases:
+            assert t < 10 * n_cases, "heightmaps keep missing the > S branch"
+            hm = rng.uniform(0.0, 0.12, size=(32, 32))
+            env.space.heightmapC[:] = hm
+            oa = t % k
+            t += 1
+            loc = env.get_action_candidates(oa)
+            rows = np.asarray(loc[:5 * S]).reshape(S, 5)
+            if ct.n <= S or ct.ambiguous:               # not the branch / not decidable: another heightmap, same item
+                continue
+            assert len(np.unique(rows[:, 3])) == S and (np.diff(rows[:, 3]) > 0).all()
+            a = minz_action(loc, S)
+            order, r, d, info = env.step(a)
+            assert not d
+            rec["hm"].append(hm); rec["order_act"].append(oa); rec["loc_obs"].append(np.array(loc)); rec["ncand"].append(ct.n)
+            rec["act"].append(a); rec["rew"].append(r); rec["done"].append(d); rec["order_obs"].append(order.copy())
+    finally:
+        ct.remove()
+    return dict(seq=seqs, **{k2: np.array(v) for k2, v in rec.items()})
+
+
+def more_than_s_shapes():
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import distinct_rotation_shapes
+    return distinct_rotation_shapes()
+
+
+def bench_workload(name, n_traj=16):
+    """The shape set and item trajectories ``bench.py`` measures under this name (BASELINE.json's configs as bench
+    workloads), with the first ``n_traj`` of its 10 000 trajectories: one reference env plays trajectory 1, 2, ..."""
+    sys.path.insert(0, ROOT)
+    from bench import make_workload
+    shapes, seqs, kw = make_workload(name)
+    return shapes, np.ascontiguousarray(seqs[:n_traj]), kw
+
+
+def baseline_config_goldens():
+    """One reference-played recording per BASELINE.json config ON THE BENCH'S OWN SHAPE SETS (the small scenarios of
+    main() have their own sets): cfg 2 (BlockOut 64 polycubes x 4 cm, R = 4, and R = 8 as in README.md:100), cfg 3
+    (general, 256 solids, R = 8; recorded up to the first > S selection with tied heights), cfg 4 (k = 10 buffer,
+    hierarchical), cfg 5 (resolutionH 0.005: the bench's 256-solid abc_fine set and a 12-solid set)."""
+    out = {}
+    sh, sq, kw = bench_workload("blockout")
+    out["bench_blockout_r4"] = dict(seq=sq, **run_online(sh, sq, 260, tap=True))
+    sh, sq, kw = bench_workload("blockout_r8")
+    out["bench_blockout_r8"] = dict(seq=sq, **run_online(sh, sq, 220, tap=True))
+    sh, sq, kw = bench_workload("blockout_k10")
+    out["bench_blockout_k10"] = dict(seq=sq, **run_hier(sh, sq, 320, 10))
+    sh, sq, kw = bench_workload("general")
+    out["bench_general"] = dict(seq=sq, **run_online(sh, sq, 90, tap=True))
+    sh, sq, kw = bench_workload("abc_fine")
+    out["bench_abc_fine"] = dict(seq=sq, **run_online(sh, sq, 40, res_h=0.005, tap=True))
+    fine = fine12_shapes()
+    sq = synthetic.make_sequences(fine.n_shapes, 16, 60, seed=2)
+    out["online_fine12"] = dict(seq=sq, **run_online(fine, sq, 45, res_h=0.005, tap=True))
+    out["more_than_s"] = more_than_s_cases()
+    return out
+
+
+def fine12_shapes():
+    return synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=4)
 
 
 def cvtools_cases(n_cases=48, seed=7):
@@ -523,6 +654,9 @@ def main():
     np.savez_compressed(os.path.join(OUT, "tools_test_hier.npz"), **tools_test_hier_golden())
     np.savez_compressed(os.path.join(OUT, "random_creators.npz"), **random_creator_golden())
     np.savez_compressed(os.path.join(OUT, "heuristic_cases.npz"), **heuristic_cases())
+    if "--skip-baseline-configs" not in sys.argv:
+        for name, rec in baseline_config_goldens().items():
+            np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)
     for f in sorted(os.listdir(OUT)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -14,6 +14,32 @@ def minz_action(obs, S=500):
     return int(np.argmin(np.where(v, c[:, 3], np.inf)))
 
 
+def distinct_rotation_shapes(n_items=6, n_rot=8, seed=11):
+    """Items whose rotations are UNRELATED tables (rotation r of item k is solid k*n_rot + r of a one-rotation
+    free-form set, lifted by a rotation-specific amount): no two rotations carry the same bottom height anywhere, so on
+    a heightmap of distinct random heights every candidate row has its own placement height and the > S selection
+    (np.argsort, binPhy.py:209-212) has exactly one answer.  The reference's tables are whatever shotInfo holds per
+    (item, rotation); nothing asks them to be rotated copies of each other."""
+    from irbpp_amd.shapes import ShapeSet
+    base = synthetic.general_shapes(n_shapes=n_items * n_rot, n_rot=1, fmin=4, fmax=8, seed=seed)
+    rng = np.random.RandomState(seed + 1)
+    extents, volumes, tables = [], [], []
+    for k in range(n_items):
+        ext, tab = [], []
+        for r in range(n_rot):
+            T, B, mH, mB = base.tables[k * n_rot + r][0]
+            lift = float(rng.uniform(0.0005, 0.004))
+            e = base.extents[k * n_rot + r, 0].copy()
+            e[2] += lift
+            ext.append(e)
+            tab.append(((T + lift) * mH, (B + lift) * mB, mH.copy(), mB.copy()))
+        extents.append(ext)
+        tables.append(tab)
+        volumes.append(float(base.volumes[k * n_rot]))
+    return ShapeSet(np.array(extents), np.array(volumes), tables, name="distinct_rotations",
+                    meta={"res_h": 0.01, "n_rot": n_rot, "seed": seed})
+
+
 def golden_scenario(name):
     if name == "online_cube":
         sh = synthetic.cube_shapes()
@@ -25,6 +51,47 @@ def golden_scenario(name):
         sh = synthetic.general_shapes(n_shapes=16, n_rot=4, seed=21)
     elif name == "heuristic_blockout":
         sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    elif name in BENCH_GOLDENS:
+        sh = _bench_workload(BENCH_GOLDENS[name])[0]
+    elif name == "online_fine12":
+        sh = synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=8, fmax=40, res_h=0.005, seed=4)
+    elif name == "more_than_s":
+        sh = distinct_rotation_shapes()
     else:
         raise KeyError(name)
     return sh
+
+
+# reference-played recordings on the bench's own shape sets, one per BASELINE.json config (make_golden.py:
+# baseline_config_goldens): golden name -> bench workload
+BENCH_GOLDENS = {"bench_blockout_r4": "blockout", "bench_blockout_r8": "blockout_r8", "bench_blockout_k10": "blockout_k10",
+                 "bench_general": "general", "bench_abc_fine": "abc_fine"}
+ONLINE_GOLDENS = ["online_cube", "online_blockout", "online_general", "bench_blockout_r4", "bench_blockout_r8",
+                  "bench_general", "bench_abc_fine", "online_fine12"]
+HIER_GOLDENS = [("hier_blockout_k3", 3), ("bench_blockout_k10", 10)]
+
+
+def _bench_workload(name):
+    from bench import make_workload
+    return make_workload(name)
+
+
+def golden_kwargs(name):
+    """Environment arguments of a golden scenario besides shapes and sequences."""
+    if name in ("bench_abc_fine", "online_fine12"):
+        return {"resolutionH": 0.005}
+    return {}
+
+
+def assert_fallback_rows_legal(rows, n_rot, ax=16, ay=16, bin_z=0.30):
+    """The no-candidate fallback of cur_observation (binPhy.py:217-225): S rows [ROT, X, Y, H := bin height, V = 0],
+    taken from an argsort prefix of the (all-invalid, all-1e3) posZValid: whatever the tie order, S DISTINCT in-range
+    cells."""
+    rows = np.asarray(rows, dtype=np.float64)
+    assert (rows[:, 3] == np.float32(bin_z)).all() or (rows[:, 3] == bin_z).all()
+    assert (rows[:, 4] == 0).all()
+    r, x, y = rows[:, 0], rows[:, 1], rows[:, 2]
+    assert (r == np.floor(r)).all() and (x == np.floor(x)).all() and (y == np.floor(y)).all()
+    assert (r >= 0).all() and (r < n_rot).all() and (x >= 0).all() and (x < ax).all() and (y >= 0).all() and (y < ay).all()
+    cells = {(int(a), int(b), int(c)) for a, b, c in zip(r, x, y)}
+    assert len(cells) == len(rows) or len(cells) == n_rot * ax * ay

@@ -9,7 +9,7 @@ import irbpp_amd  # noqa: F401
 from irbpp_amd import synthetic
 from oracle.c_oracle import COracleVecEnv, CPackingGame
 from oracle.packing import OracleVecEnv
-from helpers import golden_scenario, minz_action
+from helpers import HIER_GOLDENS, ONLINE_GOLDENS, assert_fallback_rows_legal, golden_kwargs, golden_scenario, minz_action
 
 S = 500
 
@@ -59,10 +59,11 @@ def test_c_oracle_equals_numpy_oracle_hierarchical():
         np.testing.assert_array_equal(cd, pd)
 
 
-@pytest.mark.parametrize("name", ["online_cube", "online_blockout", "online_general"])
+@pytest.mark.parametrize("name", ONLINE_GOLDENS)
 def test_c_oracle_matches_reference_golden(golden_dir, name):
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    env = CPackingGame(golden_scenario(name), g["seq"])
+    sh = golden_scenario(name)
+    env = CPackingGame(sh, g["seq"], **golden_kwargs(name))
     obs = env.reset()
     np.testing.assert_array_equal(obs, g["obs"][0])
     for t in range(len(g["act"])):
@@ -76,6 +77,44 @@ def test_c_oracle_matches_reference_golden(golden_dir, name):
         np.testing.assert_array_equal(obs[5 * S:], g["obs"][t + 1][5 * S:])
         if (obs[:5 * S].reshape(S, 5)[:, 4] == 1).any():
             np.testing.assert_array_equal(obs, g["obs"][t + 1])
+        else:
+            assert_fallback_rows_legal(obs[:5 * S].reshape(S, 5), sh.n_rot)
+        pz, mk = env.grids()
+        np.testing.assert_array_equal(pz, g["posz"][t + 1])
+        np.testing.assert_array_equal(mk, g["mask"][t + 1])
+
+
+@pytest.mark.parametrize("name,k", HIER_GOLDENS)
+def test_c_oracle_matches_reference_hierarchical_golden(golden_dir, name, k):
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    env = CPackingGame(golden_scenario(name), g["seq"], bufferSize=k)
+    np.testing.assert_array_equal(env.reset(), g["order_obs"][0])
+    for t in range(len(g["act"])):
+        loc = env.get_action_candidates(int(g["order_act"][t]))
+        if (loc[:5 * S].reshape(S, 5)[:, 4] == 1).any():
+            np.testing.assert_array_equal(loc, g["loc_obs"][t])
+        a = minz_action(loc, S)
+        assert a == g["act"][t]
+        order, r, d, info = env.step(a)
+        assert r == g["rew"][t] and d == g["done"][t]
+        if d:
+            assert info["counter"] == g["counter"][t] and info["ratio"] == g["ratio"][t]
+            order = env.reset()
+        np.testing.assert_array_equal(order, g["order_obs"][t + 1])
+    assert g["done"].sum() >= 1
+
+
+def test_c_oracle_more_than_S_selection_matches_reference(golden_dir):
+    g = np.load(os.path.join(golden_dir, "more_than_s.npz"))
+    env = CPackingGame(golden_scenario("more_than_s"), g["seq"], bufferSize=2)
+    np.testing.assert_array_equal(env.reset(), g["order_obs0"])
+    for t in range(len(g["act"])):
+        env.set_heightmap(g["hm"][t])
+        loc = env.get_action_candidates(int(g["order_act"][t]))
+        np.testing.assert_array_equal(loc, g["loc_obs"][t])
+        order, r, d, _ = env.step(int(g["act"][t]))
+        assert r == g["rew"][t] and d == g["done"][t]
+        np.testing.assert_array_equal(order, g["order_obs"][t])
 
 
 def test_c_oracle_more_than_S_candidates_and_speed():

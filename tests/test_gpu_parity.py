@@ -13,7 +13,8 @@ from irbpp_amd.vec_env import GpuPackingEnv, GpuVecEnv
 from oracle import cvtools
 from oracle.packing import OracleVecEnv
 from oracle.space import Space
-from helpers import golden_scenario, minz_action
+from helpers import (HIER_GOLDENS, ONLINE_GOLDENS, assert_fallback_rows_legal, golden_kwargs, golden_scenario,
+                     minz_action)
 
 pytestmark = pytest.mark.gpu
 GpuVecEnv.candidates_on_device = True        # these tests feed the location observations back to device kernels
@@ -148,12 +149,17 @@ def test_hierarchical_matches_oracle():
     assert ndone >= 2
 
 
-@pytest.mark.parametrize("name", ["online_cube", "online_blockout", "online_general"])
+@pytest.mark.parametrize("name", ONLINE_GOLDENS)
 def test_online_matches_reference_golden(golden_dir, name):
+    """The HIP path against episodes the REFERENCE'S OWN PackingGame played (tests/golden/make_golden.py): the small
+    scenarios and one recording per BASELINE.json config on the bench's own shape sets (cfg 2 R = 4 / R = 8, cfg 3, cfg 5
+    at resolutionH 0.005 on the bench's 256 solids and on a 12-solid set)."""
     g = np.load(os.path.join(golden_dir, name + ".npz"))
-    genv = GpuVecEnv(golden_scenario(name), g["seq"], 1, device=DEV)
+    sh = golden_scenario(name)
+    genv = GpuVecEnv(sh, g["seq"], 1, device=DEV, **golden_kwargs(name))
     obs = genv.reset().cpu().numpy()[0]
     np.testing.assert_array_equal(obs, _f32(g["obs"][0]))
+    fallbacks = 0
     for t in range(len(g["act"])):
         a = minz_action(obs, S)
         assert a == g["act"][t]
@@ -167,6 +173,59 @@ def test_online_matches_reference_golden(golden_dir, name):
         np.testing.assert_array_equal(obs[5 * S:], ref[5 * S:])
         if (ref[:5 * S].reshape(S, 5)[:, 4] == 1).any():
             np.testing.assert_array_equal(obs, ref)
+        else:
+            # binPhy.py:217-225: np.argsort over an all-equal vector -- the reference's row ORDER is its numpy build's; the
+            # rows must be S distinct in-range cells with H = bin height, V = 0, and here they are the stable prefix
+            rows = obs[:5 * S].reshape(S, 5)
+            assert_fallback_rows_legal(rows, sh.n_rot)
+            want = np.array([[c // 256, (c % 256) // 16, c % 16, 0.30, 0.0] for c in range(S)]).astype(np.float32)
+            np.testing.assert_array_equal(rows, want)
+            fallbacks += 1
+    assert fallbacks >= 1
+    genv.env.check_device_error()
+    genv.close()
+
+
+@pytest.mark.parametrize("name,k", HIER_GOLDENS)
+def test_hierarchical_matches_reference_golden(golden_dir, name, k):
+    """get_action_candidates + step against the reference's own hierarchical episodes: k = 3 on the small BlockOut set
+    and BASELINE config 4 (k = 10) on the bench's BlockOut set, order actions cycling over every buffer slot."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    genv = GpuVecEnv(golden_scenario(name), g["seq"], 1, device=DEV, bufferSize=k)
+    order = genv.reset().cpu().numpy()[0]
+    np.testing.assert_array_equal(order, _f32(g["order_obs"][0]))
+    for t in range(len(g["act"])):
+        loc = genv.get_action_candidates(np.array([int(g["order_act"][t])])).cpu().numpy()[0]
+        ref = _f32(g["loc_obs"][t])
+        np.testing.assert_array_equal(loc[5 * S:], ref[5 * S:])
+        if (ref[:5 * S].reshape(S, 5)[:, 4] == 1).any():
+            np.testing.assert_array_equal(loc, ref)
+        a = minz_action(loc, S)
+        assert a == g["act"][t]
+        o, r, d, info = genv.step(np.array([a]))
+        assert d[0] == g["done"][t] and r.numpy()[0, 0] == np.float32(g["rew"][t])
+        if d[0]:
+            assert info[0]["counter"] == g["counter"][t] and info[0]["ratio"] == g["ratio"][t]
+        np.testing.assert_array_equal(o.cpu().numpy()[0], _f32(g["order_obs"][t + 1]))
+    assert g["done"].sum() >= 1
+    genv.env.check_device_error()
+    genv.close()
+
+
+def test_more_than_S_selection_matches_reference_golden(golden_dir):
+    """binPhy.py:209-212 where the answer does not depend on a tie rule: more than S candidates with pairwise distinct
+    placement heights, rows and their order as the reference's own np.argsort left them."""
+    g = np.load(os.path.join(golden_dir, "more_than_s.npz"))
+    genv = GpuVecEnv(golden_scenario("more_than_s"), g["seq"], 1, device=DEV, bufferSize=2)
+    np.testing.assert_array_equal(genv.reset().cpu().numpy()[0], _f32(g["order_obs0"]))
+    for t in range(len(g["act"])):
+        genv.env.set_heightmaps(torch.from_numpy(g["hm"][t][None]).to(DEV))
+        loc = genv.get_action_candidates(np.array([int(g["order_act"][t])])).cpu().numpy()[0]
+        np.testing.assert_array_equal(loc, _f32(g["loc_obs"][t]))
+        o, r, d, _ = genv.step(np.array([int(g["act"][t])]))
+        assert d[0] == g["done"][t] and r.numpy()[0, 0] == np.float32(g["rew"][t])
+        np.testing.assert_array_equal(o.cpu().numpy()[0], _f32(g["order_obs"][t]))
+    genv.env.check_device_error()
     genv.close()
 
 
