@@ -7,10 +7,11 @@ observation and, fused into the emit kernel, the scripted MINZ policy's action o
 (shape tables, trajectories, heightmaps, observations) are resident in HBM before the timed
 region; nothing crosses PCIe inside it.
 
-Workload at N=1: BASELINE.json configs[1] -- BlockOut online (bufferSize=1), 4096 bins per
-GPU, resolutionA=0.02, resolutionH=0.01, R=4, S=500 (synthetic polycubes).
+Workload at N=1: the configuration BASELINE.json's north_star quotes its target on -- BlockOut online (bufferSize=1,
+configs[1]'s data) with 8192 bins on one GPU, resolutionA=0.02, resolutionH=0.01, R=4, S=500 (synthetic polycubes,
+SURVEY.md 8d); configs[1]'s own 4096 bins are measured beside it (`extra.bins4096_one_gpu`).
 Multi-GPU: bins are sharded, no data-path collective; one RCCL all-reduce of the episode
-totals after the timed region.  Default: "weak" scaling, 4096 bins per GPU; `--config cfg4|cfg5` are north_star's
+totals after the timed region.  Default: "weak" scaling, 8192 bins per GPU; `--config cfg4|cfg5` are north_star's
 sharded configs (8192 k=10 bins / 16384 fine-heightmap bins divided over the GPUs: "strong").
 The timed region is repeated in blocks of --steps steps until it adds up to --min-seconds, so the figure does
 not depend on how few steps the caller asked for.
@@ -320,7 +321,7 @@ def timed_run(env, a, dev, k, barrier, steps, prefill, warmup, min_seconds=0.0, 
 
 # BASELINE.json configs as bench modes: (workload, global bins or None = --bins per GPU, default scaling)
 CONFIGS = {
-    "cfg2": ("blockout", None, "weak"),            # BlockOut online, 4096 bins per GPU (the headline, `value` at N=1)
+    "cfg2": ("blockout", None, "weak"),            # BlockOut online, 4096 bins per GPU (configs[1] to the letter)
     "cfg3": ("general", None, "weak"),             # General dataset, 4096 bins per GPU
     "cfg4": ("blockout_k10", 8192, "strong"),      # BlockOut buffered k=10, 8192 bins sharded over the GPUs
     "cfg5": ("abc_fine", 16384, "strong"),         # ABC fine heightmap, 16384 bins sharded over the GPUs
@@ -371,7 +372,8 @@ def main():
                     help="repeat the timed block of --steps steps until the timed blocks add up to this (0 = one block)")
     ap.add_argument("--prefill", type=int, default=300,
                     help="untimed steps before the warm-up that bring every bin to a steady-state episode mix")
-    ap.add_argument("--bins", type=int, default=4096, help="bins per GPU (weak scaling) / ignored for a sharded --config")
+    ap.add_argument("--bins", type=int, default=None, help="bins per GPU (weak scaling; default 8192 = north_star's target "
+                    "configuration, 4096 under --config cfg2/cfg3) / ignored for a sharded --config")
     ap.add_argument("--workload", default=None)
     ap.add_argument("--config", default=None, choices=sorted(CONFIGS), help="a BASELINE.json config as a bench mode")
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
@@ -390,6 +392,8 @@ def main():
         respawn_under_torchrun(a)                          # does not return
 
     cfg_workload, cfg_global, cfg_scaling = CONFIGS[a.config] if a.config else (None, None, None)
+    if a.bins is None:
+        a.bins = 4096 if a.config in ("cfg2", "cfg3") else 8192
     workload = a.workload or cfg_workload or "blockout"
     scaling = a.scaling or cfg_scaling or "weak"
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -489,6 +493,8 @@ def main():
             except Exception as exc:                                     # noqa: BLE001 -- an extra, never the measurement
                 grouped["with_8_hardware_queues"] = {"error": repr(exc)[:200]}
         if workload == "blockout":
+            if bins != 4096:
+                extra["bins4096_one_gpu"] = side_run("blockout", 4096)        # BASELINE configs[1] at its own size
             if bins != 8192:
                 extra["bins8192_one_gpu"] = side_run("blockout", 8192)
             extra["cfg3_general_4096"] = side_run("general", 4096)
@@ -520,7 +526,8 @@ def main():
         out = {
             "metric": "env steps/sec (placements/sec) across N parallel bins",
             "value": total_steps / elapsed, "unit": "placement-steps/s",
-            "n_gpus": world, "steps": timed_steps, "steps_per_block": a.steps, "min_seconds": a.min_seconds,
+            "n_gpus": world, "steps": timed_steps, "steps_requested": a.steps, "steps_per_block": a.steps,
+            "timed_blocks": timed_steps // a.steps, "min_seconds": a.min_seconds,
             "warmup": a.warmup, "prefill_steps": a.prefill,
             "ms_per_step": elapsed / timed_steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -87,6 +87,9 @@ typedef struct {
 #define IRBPP_TUNE_INLINE_POLYGON 256 /* every trace wave approximates the borders it followed itself; no polygon kernel (the
                                          path a full record list takes, forced for the parity tests; measured slower at every size) */
 #define IRBPP_TUNE_NO_HEAVY_FIRST 512 /* emit kernel: the bins in launch order, speckled ones not first                        */
+#define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
+                                         geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
+                                         S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */
 
 /* Per-step outputs beyond the observation: what PackingGame.step returns and what Monitor
  * adds on `done` (binPhy.py:299-311,327; monitor.py:58-75).  All device pointers, one entry
@@ -101,11 +104,23 @@ typedef struct {
     uint8_t* stable_dev;      /* irbpp_config::stability >= 1: 1 iff the placement of this step rests stably
                                  (0 also where the step placed nothing); NULL to skip                    */
     int32_t* err_dev;         /* copy of the device error word after this step (one int32, not per bin):
-                                 callers that fetch the outputs with one D2H copy get it for free   */
+                                 callers that fetch the outputs with one D2H copy get it for free.
+                                 LIFETIME: the library keeps this pointer after irbpp_step returns and ORs
+                                 error bits into the word as later launches of this environment raise them
+                                 (irbpp_get_action_candidates writes through it): it must stay allocated and
+                                 must not be written by the caller until the next irbpp_step with another
+                                 err_dev (or NULL), irbpp_reset / irbpp_reset_bins, or irbpp_destroy.  The word
+                                 always holds every sticky bit of the device error word when a step's
+                                 kernels have run (it is re-seeded whenever the pointer changes and after
+                                 every reset / stream write)                                          */
 } irbpp_step_out;
 
 const char* irbpp_status_string(int status);
 int irbpp_version(void);
+/* Hash of the sources and compiler flags this binary was built from (irbpp_amd/build.py: source_hash(), passed in as
+ * -DIRBPP_SOURCE_HASH); "unstamped" for a build made some other way.  The Python loader refuses a binary whose stamp is
+ * not the hash of the sources lying next to it: a stale .so can then never be measured or tested by mistake. */
+const char* irbpp_source_hash(void);
 
 /* replaces: gym.make('Physics-v0', args=args) x num_processes + ShmemVecEnv.__init__
  * (envs.py:67-99, shmem_vec_env.py:25-59) */
@@ -320,6 +335,10 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
 /* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and the name of the build of it that
  * launches (one per overlap path, with and without the 64-VGPR cap; a static string).  Valid after irbpp_load_shapes. */
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name);
+/* The overlap path irbpp_load_shapes chose for the data set: 1 block path (every footprint a union of uniform b x b
+ * tiles: lattice data), 2 box path (every footprint a solid box), 3 generic cell lists; IRBPP_ERR_STATE before the
+ * shapes are loaded.  (vec_env.groups_for decides by it how many groups of bins to step a data set as.) */
+int irbpp_overlap_path(const irbpp_env* env);
 int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);
 /* events around every `every`-th transition only (default 1): two event packets per step cost the stream ~5 % at
  * 0.15 ms per step, so bench.py samples every fourth step of its timed region */

@@ -23,6 +23,7 @@ class IrbppConfig(C.Structure):
 
 TUNE_NO_BLOCK_PATH, TUNE_WIDE_KERNEL, TUNE_NARROW_KERNEL, TUNE_NO_BOX_PATH, TUNE_NO_ITEM_ORDER = 1, 2, 4, 8, 16
 TUNE_TRACE_CPW64, TUNE_TRACE_CPW32, TUNE_TRACE_CPW16, TUNE_INLINE_POLYGON, TUNE_NO_HEAVY_FIRST = 32, 64, 128, 256, 512
+TUNE_NO_SPECIALISED = 1024
 
 
 class IrbppReplayView(C.Structure):
@@ -42,6 +43,8 @@ class IrbppStepOut(C.Structure):
 SIGNATURES = {
     "irbpp_status_string": (C.c_char_p, [C.c_int]),
     "irbpp_version": (C.c_int, []),
+    "irbpp_source_hash": (C.c_char_p, []),
+    "irbpp_overlap_path": (C.c_int, [C.c_void_p]),
     "irbpp_create": (C.c_int, [C.POINTER(IrbppConfig), C.POINTER(C.c_void_p)]),
     "irbpp_destroy": (C.c_int, [C.c_void_p]),
     "irbpp_load_shapes": (C.c_int, [C.c_void_p, C.c_int32, c_f64_p, c_f64_p, c_i32_p, C.POINTER(C.c_int64),
@@ -112,6 +115,16 @@ def load(path: str = "") -> C.CDLL:
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
+    # A binary built from other sources than the ones lying here is refused: every number and every test would be about
+    # code nobody is looking at.  (IRBPP_LIBRARY names an A/B variant built with extra flags by tools/build_variant.sh: its
+    # stamp is its own business.)
+    if not os.environ.get("IRBPP_LIBRARY") and not os.environ.get("IRBPP_ALLOW_STALE_LIBRARY"):
+        from . import build
+        have, want = lib.irbpp_source_hash().decode(), build.source_hash()
+        if have != want:
+            raise RuntimeError(
+                f"{path} was built from sources {have}, the sources in {build.CSRC} hash to {want}: rebuild with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (IRBPP_ALLOW_STALE_LIBRARY=1 overrides)")
     _lib = lib
     return lib
 

@@ -34,11 +34,22 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found: the HIP library cannot be built on this machine")
 
 
+def built_hash(path: str = LIB_PATH) -> str:
+    """The stamp inside a built library (irbpp_source_hash), read without loading it into this process: the string
+    follows the marker the C side puts in front of it."""
+    try:
+        with open(path, "rb") as f:
+            blob = f.read()
+    except OSError:
+        return ""
+    i = blob.find(b"irbpp-source-hash:")
+    return blob[i + 18:i + 34].decode("ascii", "replace") if i >= 0 else ""
+
+
 def needs_build(path: str = LIB_PATH) -> bool:
-    if not os.path.exists(path):
-        return True
-    t = os.path.getmtime(path)
-    return any(os.path.getmtime(os.path.join(CSRC, s)) > t for s in SOURCES)
+    """True unless `path` carries the stamp of the present sources (not a question of file times: a checkout, a copy to
+    the GPU box or an editor can leave any order of mtimes behind)."""
+    return built_hash(path) != source_hash()
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
@@ -47,7 +58,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     out = LIB_PATH
     if not force and not needs_build(out):
         return out
-    cmd = [_hipcc()] + HIPCC_FLAGS + [os.path.join(CSRC, "irbpp_capi.hip"), "-o", out]
+    cmd = [_hipcc()] + HIPCC_FLAGS + [f'-DIRBPP_SOURCE_HASH="{source_hash()}"', os.path.join(CSRC, "irbpp_capi.hip"), "-o", out]
     if verbose:
         print(" ".join(cmd))
     res = subprocess.run(cmd, capture_output=True, text=True)

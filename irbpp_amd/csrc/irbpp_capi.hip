@@ -71,83 +71,13 @@ inline double round6_host(double x) { return nearbyint(x * 1e6) / 1e6; }   // np
 constexpr int TRACE_SMALL_GRID = 8192;      // waves of a trace launch over few bins (16 or 32 candidates per wave)
 constexpr int TRACE_CPW16_BINS = 0;         // launches over at most this many bins trace 16 candidates per wave ...
 constexpr int TRACE_CPW32_BINS = 1024;      // ... 32 per wave (profiles/r04 session 41: +1.5 ... 1.9 % at 512 / 1024 bins, -0.3 % at 2048; 16 per wave loses everywhere)
-inline int32_t align16(int32_t v) { return (v + 15) & ~15; }
-
-inline uint32_t div_magic(int32_t d) { return d >= 2 ? (uint32_t)((1ull << 32) / (uint64_t)d + 1ull) : 0u; }
-
-// dynamic-LDS carve-up of the transition kernel (and the division constants of its grid sizes)
-void layout_lds(Params& P) {
-    P.mg_hy = div_magic(P.Hy);
-    P.mg_step = div_magic(P.step);
-    P.mg_ay = div_magic(P.Ay);
-    P.mg_ax = div_magic(P.Ax);
-    P.mg_ac = div_magic(P.AC);
-    P.mg_mbw = div_magic(P.mb_w);
-    // heightmap tile: phase planes of period step, one entry per action cell (= per lane of the generic overlap test)
-    P.pp = P.step;
-    P.LX = P.Ax;
-    P.LY = P.Ay;
-    P.PL = P.LX * P.LY;
-    P.tile_words = P.pp * P.pp * P.PL;                                 // == Hc: no padding entries
-    P.mg_pp = div_magic(P.pp);
-    P.mg_ly = div_magic(P.LY);
-    P.g_ysh = 0;
-    while ((1 << P.g_ysh) < P.Ay) ++P.g_ysh;                           // Ay <= 16: at least four rows of action cells per wave
-    P.nslot = 64;                                                     // candidate starts traced per pass (16 per wave)
-    P.slot_cap = 64;                                                  // points of a border: one lane each in the segmented Douglas-Peucker
-    P.slot_bytes = P.slot_cap + 4;                                    // 68 B = 17 dwords: odd stride, lanes hit distinct LDS banks
-    int32_t off = 0;
-    P.o_sr = off;        off += align16(P.R * (int32_t)sizeof(ShapeRot));
-    P.o_lev = off;       off += align16(P.R * P.AC);
-    P.o_present = off;   off += align16(P.R * 8);
-    P.o_taskidx = off;   off += align16(P.R * 64 * 2);
-    P.o_tasklist = off;  off += align16(P.R * 64 * 2);
-    const int32_t img_bytes = align16(2 * CONTOUR_IPT * 16 * 16 * 2);  // level images of a batch: 16-bit row words + column words
-    P.o_img = off;       off += img_bytes;
-    // block-max grid of the overlap test (0 bytes on the generic path): dead before the contour
-    // stage builds its images, so it shares their bytes when it fits
-    const int32_t mb_bytes = align16(P.mb_w * P.mb_h * 8);
-    if (mb_bytes <= img_bytes) P.o_mb = P.o_img;
-    else { P.o_mb = off; off += mb_bytes; }
-    P.o_c2 = off;        off += mb_bytes ? align16(P.AC * 8) : 0;     // block path: per-action-cell maxima, the grid's first step
-    P.o_vmask = off;     off += align16(P.R * 16 * 4);
-    P.o_vbits = P.o_taskidx;                           // naiveMask bit rows: handed over before the task index is built (split_handover)
-    P.o_m1 = off;        off += P.box ? align16(P.Hx * P.Ay * 8) : 0; // box path: row maxima of the tile, [Hx][Ay]
-    P.o_red = off;       off += 256;                                  // reductions, flags, queue copy
-    // one region serves, in turn, the heightmap tile (apply + overlap test), the contour stage (border
-    // slots, the arg-max words of the segmented Douglas-Peucker, and at its end the 256 candidate starts of
-    // an image batch) and the candidate keys: the tile's float32 copy is written out before the reuse
-    const int32_t slots = align16(P.nslot * P.slot_bytes);
-    const int32_t dps = 4 * 64 * 4 + 4 * 64;           // arg-max words and scratch bytes of the segmented Douglas-Peucker
-    int32_t scratch = slots + dps + 512;
-    const int32_t keys = (P.R * P.AC + P.S) * 4 + 64;
-    if (scratch < keys) scratch = keys;
-    if (scratch < P.tile_words * 8) scratch = P.tile_words * 8;
-    if (scratch < 2 * CONTOUR_IPT * 16 * 16 * 2 + 512) scratch = 2 * CONTOUR_IPT * 16 * 16 * 2 + 512;   // hand-over: a batch's row words + candidate words, the list
-    P.scratch_bytes = align16(scratch);
-    P.o_hm = off;
-    P.o_scratch = off;
-    P.o_dps = off + slots;
-    P.o_clist = off + P.scratch_bytes - 512;
-    P.big_slot_bytes = P.scratch_bytes - 512;          // the serial redo of a border may use everything below the candidate list
-    off += P.scratch_bytes;
+// dynamic-LDS carve-up of the transition kernel: irbpp::layout_lds (irbpp_device.h, shared with the specialised builds)
+void layout_lds_host(Params& P) {
+    int pad = 0;
 #ifdef IRBPP_ABLATE
-    if (const char* pad = getenv("IRBPP_LDS_PAD")) off += align16(atoi(pad));   // tooling build only: caps workgroups per CU
+    if (const char* e = getenv("IRBPP_LDS_PAD")) pad = atoi(e);   // tooling build only: caps workgroups per CU
 #endif
-    P.lds_bytes = off;
-    P.o_posz = off;                                    // only the heuristic kernel keeps posZValid in LDS
-    P.lds_bytes_full = off + align16(P.R * P.AC * 8);
-    // emit kernel: vertex bits, reductions, the radix-select counters / sort keys / row values, candidate keys + selected keys
-    int32_t e = 0;
-    P.e_vmask = e;  e += align16(P.R * 16 * 4);
-    P.e_red = e;    e += 256;
-    {   // 256 radix counters, later the sort keys of the selected rows: 10 bytes per entry of the next power of two
-        int32_t npad = 64;
-        while (npad < P.S) npad <<= 1;
-        P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);       // >= 4 * S bytes for the rows' values too
-    }
-    P.e_keys = e;   e += align16(keys);
-    P.emit_lds_bytes = e;
+    irbpp::layout_lds(P, pad);
 }
 
 // The dynamic-LDS limit is an attribute of the kernel on the device, not of an environment: always raise it to the
@@ -156,6 +86,11 @@ int raise_lds_limits() {
     const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_env_kernel_box,
                              (const void*)irbpp_env_kernel_box8, (const void*)irbpp_env_kernel_generic,
                              (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_hull_kernel,
+#if !defined(IRBPP_NO_SPEC)
+                             (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
+                             (const void*)irbpp_env_kernel_s4, (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
+                             (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
+#endif
                              (const void*)irbpp_emit_kernel, (const void*)irbpp_heuristic_kernel};
     for (const void* k : kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return IRBPP_ERR_HIP;
@@ -180,7 +115,13 @@ const char* irbpp_status_string(int status) {
     }
 }
 
-int irbpp_version(void) { return 400; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen
+int irbpp_version(void) { return 500; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen; 5xx: source hash, overlap path, specialised builds
+
+#ifndef IRBPP_SOURCE_HASH
+#define IRBPP_SOURCE_HASH "unstamped"
+#endif
+// (the marker lets build.py find the stamp in the file without loading the library)
+const char* irbpp_source_hash(void) { static const char stamp[] = "irbpp-source-hash:" IRBPP_SOURCE_HASH; return stamp + 18; }
 
 int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     if (!cfg || !out) return IRBPP_ERR_ARG;
@@ -237,7 +178,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.wimg = P.R * 64;
     P.seg_cap = 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;
     P.round_cap = (P.N / NXCD + 64) * 16;
-    layout_lds(P);                      // redone by irbpp_load_shapes if the block path applies
+    layout_lds_host(P);                 // redone by irbpp_load_shapes if the block path applies
     if (P.lds_bytes_full > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
@@ -445,7 +386,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         env->P.mb_h = mb_h;
         env->P.mb_w = mb_w;
         env->P.box = box ? 1 : 0;
-        layout_lds(env->P);
+        layout_lds_host(env->P);
         if (env->P.lds_bytes_full > 160 * 1024) return IRBPP_ERR_ARG;
         if (raise_lds_limits() != IRBPP_OK) return IRBPP_ERR_HIP;
     }
@@ -484,6 +425,7 @@ int irbpp_stream_write(irbpp_env* env, const int32_t* ids_dev, const int32_t* fi
     if (!env->cfg.item_stream || !env->seq_loaded) return IRBPP_ERR_STATE;
     if (width > env->T.seq_len) return IRBPP_ERR_ARG;
     if (width == 0) return IRBPP_OK;
+    env->err_mirror = nullptr;                    // the caller may have cleared a STREAM_DRY condition: seed the next step's word anew
     const long long n = (long long)env->T.n_traj * width;
     hipLaunchKernelGGL(irbpp_stream_write_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                        const_cast<int32_t*>(env->T.seq), env->T.n_traj, env->T.seq_len, ids_dev, first_dev, count_dev, width);
@@ -499,10 +441,34 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 // without the 64-VGPR cap that makes eight workgroups per CU resident, plus one build that decides at run time.
 typedef void (*env_kernel_fn)(const Params, const Tables, const State, const StepIO, const int);
 struct EnvKernel { env_kernel_fn fn; const char* name; };
+// Specialised builds (irbpp_device.h): SPEC index whose compile-time constants equal this environment's Params, or 0.
+static int pick_spec(const irbpp_env* env) {
+#if defined(IRBPP_NO_SPEC) || defined(IRBPP_ABLATE)
+    return 0;
+#else
+    if (env->cfg.tuning & (IRBPP_TUNE_NO_SPECIALISED | IRBPP_TUNE_WIDE_KERNEL | IRBPP_TUNE_NARROW_KERNEL)) return 0;
+    static const Params spec[N_SPECS] = {Params{}, spec_params(SPEC_KEYS[1]), spec_params(SPEC_KEYS[2]), spec_params(SPEC_KEYS[3]),
+                                         spec_params(SPEC_KEYS[4])};
+    static_assert(N_SPECS == 5, "one table entry and one kernel per SPEC_KEYS row");
+    for (int i = 1; i < N_SPECS; ++i)
+        if (spec_matches(env->P, spec[i])) return i;
+    return 0;
+#endif
+}
+
 static EnvKernel pick_env_kernel(const irbpp_env* env) {
     const Params& P = env->P;
     const int t = env->cfg.tuning;
     const bool lds_allows_8 = 8 * P.lds_bytes <= 160 * 1024;
+#if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
+    switch (pick_spec(env)) {            // (a key fixes the overlap path: block_b and box are pinned fields)
+        case 1: return {irbpp_env_kernel_s1, "irbpp_env_kernel_s1"};
+        case 2: return {irbpp_env_kernel_s2, "irbpp_env_kernel_s2"};
+        case 3: return {irbpp_env_kernel_s3, "irbpp_env_kernel_s3"};
+        case 4: return {irbpp_env_kernel_s4, "irbpp_env_kernel_s4"};
+        default: break;
+    }
+#endif
     if (P.block_b > 0) {
         if ((t & IRBPP_TUNE_WIDE_KERNEL) || 6 * P.lds_bytes > 150 * 1024) return {irbpp_env_kernel_wide, "irbpp_env_kernel_wide"};
         return {irbpp_env_kernel, "irbpp_env_kernel"};
@@ -582,7 +548,17 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
 #else
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
 #endif
-        hipLaunchKernelGGL(irbpp_emit_kernel, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T,
+        env_kernel_fn emit_fn = irbpp_emit_kernel;
+#if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
+        switch (pick_spec(env)) {
+            case 1: emit_fn = irbpp_emit_kernel_s1; break;
+            case 2: emit_fn = irbpp_emit_kernel_s2; break;
+            case 3: emit_fn = irbpp_emit_kernel_s3; break;
+            case 4: emit_fn = irbpp_emit_kernel_s4; break;
+            default: break;
+        }
+#endif
+        hipLaunchKernelGGL(emit_fn, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T,
                            env->S, io, mode);
     }
 }
@@ -617,6 +593,7 @@ int irbpp_reset(irbpp_env* env, float* obs_dev, void* stream) {
     io.obs = obs_dev;
     io.obs_stride = env->P.obs_len0;
     io.reset_next = env->was_reset ? 1 : 0;       // a later reset() moves every bin on to its next trajectory (IRcreator.py:86-92)
+    env->err_mirror = nullptr;                    // bits a reset raises reach S.err only: the next step seeds its error word again
     const int rc = launch_env(env, io, MODE_RESET, stream);
     if (rc == IRBPP_OK) env->was_reset = true;
     return rc;
@@ -631,6 +608,7 @@ int irbpp_reset_bins(irbpp_env* env, const int32_t* bins_dev, int32_t count, flo
     io.obs = obs_dev;
     io.obs_stride = env->P.obs_len0;
     io.bin_list = bins_dev;
+    env->err_mirror = nullptr;                    // (as irbpp_reset)
     return launch_env(env, io, MODE_RESET, stream, count);
 }
 
@@ -876,6 +854,12 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
     *lds_bytes = env->P.lds_bytes;
     *kernel_name = pick_env_kernel(env).name;
     return IRBPP_OK;
+}
+
+int irbpp_overlap_path(const irbpp_env* env) {
+    if (!env) return IRBPP_ERR_ARG;
+    if (!env->shapes_loaded) return IRBPP_ERR_STATE;
+    return env->P.block_b > 0 ? 1 : (env->P.box ? 2 : 3);
 }
 
 int irbpp_debug_kernel_timing_every(irbpp_env* env, int32_t every) {

@@ -945,7 +945,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
                 if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                     const int idx = li + 32;
-                    if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                    if (idx < 0 || idx > 63) raise_error(S, IRBPP_DEVERR_LEVEL_RANGE);
                     else code = idx;
                 }
                 ++my_valid;
@@ -1035,7 +1035,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
             if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                 const int idx = li + 32;
-                if (idx < 0 || idx > 63) atomicOr(S.err, IRBPP_DEVERR_LEVEL_RANGE);
+                if (idx < 0 || idx > 63) raise_error(S, IRBPP_DEVERR_LEVEL_RANGE);
                 else {
                     L.lev[r * AC + cell] = (uint8_t)idx;
                     if (idx < 32) bits_lo = 1u << idx; else bits_hi = 1u << (idx - 32);
@@ -1539,7 +1539,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
                         if (got + total <= P.seg_cap) at = got;
                         else atomicSub(ka->S.w_total + seg * XCD_STRIDE, total);
                     }
-                    if (at < 0) atomicOr(S.err, IRBPP_DEVERR_CAPACITY);
+                    if (at < 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
                 }
                 L.redi[11] = at;
                 L.redi[12] = seg;
@@ -1590,8 +1590,10 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // One build serves all data: with this code in, the register allocator happens to fit the kernel into its 64 VGPRs; the
 // build without it spilled four of them and cost the BlockOut step 1.1 us (19.1 vs 18.0 us, profiles/r04/s8) --
 // tests/test_kernel_asm.py watches the scratch sizes of the step's kernels.
-template <bool HEAVY_FIRST>
-__device__ __forceinline__ void emit_body(const Params P, const Tables T, const State S, const StepIO io, const int mode, unsigned char* smem) {
+template <bool HEAVY_FIRST, int SPEC>
+__device__ __forceinline__ void emit_body(const Params& P_run, const Tables& T, const State& S, const StepIO& io, const int mode, unsigned char* smem) {
+    Params P_spec;
+    const Params& P = SPEC == 0 ? P_run : (P_spec = specialise<SPEC>(P_run), P_spec);
     Lds L = {};                                      // the emit kernel's own, small carve-up (Params.e_*)
     L.vmask = (uint32_t*)(smem + P.e_vmask);
     L.redd = (double*)(smem + P.e_red);
@@ -1647,13 +1649,19 @@ __device__ __forceinline__ void emit_body(const Params P, const Tables T, const 
     emit_observation(P, S, io, L, b, item, nvalid, obs, S.w_posz + (size_t)b * P.R * P.AC, S.w_valid + (size_t)b * P.R * 16);
     IRBPP_EMIT_STAMP(14);
 }
-#define IRBPP_EMIT_KERNEL(NAME, HF)                                                                                      \
+#define IRBPP_EMIT_KERNEL(NAME, HF, SPEC)                                                                                \
     extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))                      \
     NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                              \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                            \
-        emit_body<HF>(P, T, S, io, mode, smem);                                                                         \
+        emit_body<HF, SPEC>(P, T, S, io, mode, smem);                                                                   \
     }
-IRBPP_EMIT_KERNEL(irbpp_emit_kernel, true)
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel, true, 0)
+#ifndef IRBPP_NO_SPEC
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s1, true, 1)
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s2, true, 2)
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s3, true, 3)
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s4, true, 4)
+#endif
 
 // ---------------------------------------------------------------------------------------
 // Split pipeline, middle kernels: border following + approxPolyDP + convexity over the candidate starts of ALL
@@ -1978,33 +1986,44 @@ irbpp_polygon_kernel(const Params P, const State S
 // are exactly two rounds of the chip (measured on the block path: 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups
 // per CU).  irbpp_env_kernel_wide decides the path at run time and lets the register allocator have what it wants: the
 // fallback that irbpp_config::tuning can force for A/B measurements (see pick_env_kernel in irbpp_capi.hip).
-template <int PATH>
-__device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
+template <int PATH, int SPEC>
+__device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
 #ifndef IRBPP_ENV_WAVES
 #define IRBPP_ENV_WAVES 8
 #endif
-#define IRBPP_ENV_KERNEL(NAME, PATH, ATTR)                                                                              \
+#define IRBPP_ENV_KERNEL(NAME, PATH, SPEC, ATTR)                                                                        \
     extern "C" __global__ void __launch_bounds__(BLOCK) ATTR                                                           \
     NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                             \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                           \
-        env_transition<PATH>(P, T, S, io, mode, smem);                                                                 \
+        env_transition<PATH, SPEC>(P, T, S, io, mode, smem);                                                           \
     }
 // (eight waves per SIMD need <= 64 VGPRs AND <= 96 SGPRs of the SIMD's 800: the cap is on both)
 #define IRBPP_CAPPED __attribute__((amdgpu_waves_per_eu(IRBPP_ENV_WAVES, IRBPP_ENV_WAVES)))
-IRBPP_ENV_KERNEL(irbpp_env_kernel, PATH_BLOCK, IRBPP_CAPPED)
-IRBPP_ENV_KERNEL(irbpp_env_kernel_box8, PATH_BOX, IRBPP_CAPPED)
-IRBPP_ENV_KERNEL(irbpp_env_kernel_box, PATH_BOX, )
-IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel, PATH_BLOCK, 0, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_box8, PATH_BOX, 0, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_box, PATH_BOX, 0, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, 0, IRBPP_CAPPED)
 // (pinning the generic build to seven waves per SIMD with amdgpu_waves_per_eu(7, 7) -- it asks for 71 VGPRs of its own
 // accord -- changes the compiler's scheduling for the worse: general 12.8 -> 11.7, abc_fine 5.2 -> 3.8 M steps/s)
-IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, )
-IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, 0, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, 0, )
+// specialised builds (irbpp_device.h: SPEC_KEYS): the geometries of BASELINE.json's configs as compile-time constants
+#ifndef IRBPP_NO_SPEC
+IRBPP_ENV_KERNEL(irbpp_env_kernel_s1, PATH_BLOCK, 1, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_s2, PATH_BOX, 2, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_s3, PATH_GENERIC, 3, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
+#endif
 
-template <int PATH>
-__device__ __forceinline__ void env_transition(const Params& P, const Tables& T, const State& S, const StepIO& io,
+template <int PATH, int SPEC>
+__device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem) {
+    // SPEC > 0: sizes, LDS offsets and division constants become literals (the run-time build keeps reading the kernarg
+    // segment where it needs a field: a copy costs it its register allocation)
+    Params P_spec;
+    const Params& P = SPEC == 0 ? P_run : (P_spec = specialise<SPEC>(P_run), P_spec);
     const Lds L = carve_lds(smem, P);
     // Launch slot -> bin: identity, the caller's list (reset_specific), or -- online steps on large generic data sets --
     // S.order, which irbpp_item_order_kernel groups by observed item per die.
@@ -2116,7 +2135,7 @@ __device__ __forceinline__ void env_transition(const Params& P, const Tables& T,
         const bool pref_ok = st_next >= 0 && st_next < T.n_shapes;
         if (pref_ok && tid < P.R * SRW_) sr_pref = ((const int*)(T.sr + (size_t)st_next * P.R))[tid];
         if (ok) {
-            const double tx = P.txs[lx & 15], ty = P.txs[ly & 15];       // np.round(lx*resA, 6), precomputed
+            const double tx = P_run.txs[lx & 15], ty = P_run.txs[ly & 15];   // np.round(lx*resA, 6), precomputed (indexed in the kernarg segment: the local copy must stay in registers)
             if (round6_scaled(tx + sr.ext_x - P.bin_x) > 0.0 || round6_scaled(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
         }
         double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)

@@ -518,7 +518,7 @@ class GpuVecEnv(object):
         self.num_groups = int(num_groups)
         if self.num_groups == 0:            # the library's own choice (groups_for): which overlap path does this data set take?
             probe = GpuPackingEnv(shapes, sequences[:1], 1, device=device, **{k: v for k, v in env_kw.items() if k != "item_stream"})
-            generic = "generic" in probe.kernel_info()[1]
+            generic = probe.lib.irbpp_overlap_path(probe._h) == 3
             fine = probe.Hx * probe.Hy > 32 * 32
             probe.close()
             self.num_groups = groups_for(("abc_fine" if fine else "general") if generic else "lattice", num_envs)

@@ -64,6 +64,21 @@ def test_loader_fails_loudly_without_the_library(tmp_path, monkeypatch):
         _lib.load(str(tmp_path / "libirbpp_hip.so"))
 
 
+def test_loader_refuses_a_binary_built_from_other_sources(lib, tmp_path, monkeypatch):
+    """The library carries the hash of the sources it was compiled from (irbpp_source_hash); the loader compares it with
+    the hash of the sources lying next to it, so a stale .so cannot be tested or measured by mistake."""
+    assert lib.irbpp_source_hash().decode() == build.source_hash() == build.built_hash()
+    assert not build.needs_build()
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(build, "source_hash", lambda: "0123456789abcdef")
+    with pytest.raises(RuntimeError, match="was built from sources"):
+        _lib.load()
+    assert build.needs_build()
+    monkeypatch.setenv("IRBPP_ALLOW_STALE_LIBRARY", "1")
+    assert _lib.load() is not None
+    monkeypatch.setattr(_lib, "_lib", lib)
+
+
 def test_env_construction_without_a_gpu_raises(lib):
     import torch
     if torch.cuda.is_available():

@@ -71,6 +71,26 @@ def test_bad_item_id_reaches_the_error_word_of_the_step(k):
     genv.close()
 
 
+def test_error_raised_by_a_listed_reset_reaches_the_next_buffered_step():
+    """irbpp_reset_bins with an index outside the environment raises IRBPP_DEVERR_BAD_BIN in the device error word only
+    (a reset has no step outputs).  The buffered step that follows -- whose transition kernel is its last and which
+    hands the library the SAME err_dev pointer as the step before -- must still report it: the library seeds the
+    step's word again after every reset."""
+    from irbpp_amd.vec_env import GpuPackingEnv
+    sh = synthetic.blockout_shapes(n_shapes=8, n_rot=4, cube=0.06, seed=1)
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 40, seed=2)
+    env = GpuPackingEnv(sh, seqs, 4, device=DEV, bufferSize=3)
+    env.reset()
+    slot = torch.zeros(4, dtype=torch.int32, device=DEV)
+    env.step(env.policy_minz(env.get_action_candidates(slot)))
+    env.step_info_host()                                                    # clean so far, err_dev handed over twice
+    env.reset_bins(torch.tensor([1, 9], dtype=torch.int32, device=DEV))     # bin 9 does not exist
+    env.step(slot)                                                          # no get_action_candidates in between: nobody else copies the word
+    with pytest.raises(_lib.IrbppError, match="flags=8"):
+        env.step_info_host()
+    env.close()
+
+
 def test_item_ring_that_runs_dry_is_caught_at_the_fetch():
     """item_stream = 1 with a feeder that never refills: the bin that wraps around its 16-item ring reads a slot it has
     consumed already -> IRBPP_DEVERR_STREAM_DRY in that step's error word (not an episode that silently replays items)."""

@@ -223,3 +223,41 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
     for e in envs:
         e.check_device_error()
         e.close()
+
+
+@pytest.mark.parametrize("workload,n,steps,spec", [("blockout", 160, 130, "_s1"), ("cube", 128, 60, "_s2"), ("general", 96, 45, "_s3"),
+                                                   ("abc_fine", 64, 40, "_s4"), ("blockout_k10", 96, 120, "_s1"),
+                                                   ("blockout_r8", 96, 100, "_s3")])
+def test_specialised_builds_change_nothing(workload, n, steps, spec):
+    """BASELINE.json's geometries run builds of the transition and emit kernels that have the grid sizes, LDS offsets and
+    division constants as compile-time literals (irbpp_device.h: SPEC_KEYS); IRBPP_TUNE_NO_SPECIALISED forces the build that
+    reads them from Params.  Same observations, rewards, done flags and heightmaps through whole episodes; and the
+    default really is the specialised build."""
+    from bench import make_workload
+    shapes, seqs, kw = make_workload(workload)
+    k = int(kw.get("bufferSize", 1))
+    a = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)
+    b = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=_lib.TUNE_NO_SPECIALISED, **kw)
+    assert a.kernel_info()[1].split(" + ")[0].endswith(spec), a.kernel_info()
+    assert "_s" not in b.kernel_info()[1].split(" + ")[0].replace("irbpp_env_kernel", ""), b.kernel_info()
+    oa, ob = a.reset(), b.reset()
+    assert torch.equal(oa, ob)
+    done_total = 0
+    for t in range(steps):
+        if k > 1:
+            slot = torch.full((n,), t % k, dtype=torch.int32, device=DEV)
+            la, lb = a.get_action_candidates(slot), b.get_action_candidates(slot)
+            assert torch.equal(la, lb), f"location observation, step {t}"
+            act = a.policy_minz(la)
+        else:
+            act = a.policy_minz(oa)
+        ra, rb = a.step(act), b.step(act)
+        for x, y in zip(ra, rb):
+            assert torch.equal(x, y), f"step {t}"
+        oa, ob = ra[0].clone(), rb[0].clone()
+        done_total += int(ra[2].sum())
+    assert torch.equal(a.get_heightmaps(), b.get_heightmaps())
+    assert done_total > 0
+    for e in (a, b):
+        e.check_device_error()
+        e.close()
