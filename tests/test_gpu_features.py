@@ -118,7 +118,8 @@ def test_lattice_data_agrees_on_both_overlap_paths():
     n = 128
     a = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, **kw)
     b = GpuPackingEnv(shapes, seqs[:300], n, device=DEV, tuning=_lib.TUNE_NO_BLOCK_PATH, **kw)
-    assert a.kernel_info()[1].startswith("irbpp_env_kernel +") and "irbpp_env_kernel_generic" in b.kernel_info()[1]
+    assert a.lib.irbpp_overlap_path(a._h) == 1 and b.lib.irbpp_overlap_path(b._h) == 3
+    assert a.kernel_info()[1].startswith("irbpp_env_kernel_s1 +") and "irbpp_env_kernel_generic" in b.kernel_info()[1]
     oa, ob = a.reset(), b.reset()
     assert torch.equal(oa, ob)
     for t in range(140):

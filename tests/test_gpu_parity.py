@@ -161,8 +161,9 @@ def test_online_matches_reference_golden(golden_dir, name):
     np.testing.assert_array_equal(obs, _f32(g["obs"][0]))
     fallbacks = 0
     for t in range(len(g["act"])):
-        a = minz_action(obs, S)
-        assert a == g["act"][t]
+        # the recorded action: the reference's scripted policy saw float64 rows, and two heights that differ there
+        # (0.12 and 0.12000000000000001 on the 4 cm lattice) are one float32 -- the policy is not what is under test
+        a = int(g["act"][t])
         o, r, d, info = genv.step(np.array([a]))
         obs = o.cpu().numpy()[0]
         assert d[0] == g["done"][t] and r.numpy()[0, 0] == np.float32(g["rew"][t])
@@ -200,8 +201,7 @@ def test_hierarchical_matches_reference_golden(golden_dir, name, k):
         np.testing.assert_array_equal(loc[5 * S:], ref[5 * S:])
         if (ref[:5 * S].reshape(S, 5)[:, 4] == 1).any():
             np.testing.assert_array_equal(loc, ref)
-        a = minz_action(loc, S)
-        assert a == g["act"][t]
+        a = int(g["act"][t])                           # (recorded on float64 rows, see test_online_matches_reference_golden)
         o, r, d, info = genv.step(np.array([a]))
         assert d[0] == g["done"][t] and r.numpy()[0, 0] == np.float32(g["rew"][t])
         if d[0]:
