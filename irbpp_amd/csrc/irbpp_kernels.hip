@@ -941,7 +941,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             }
             int code = 255;
             if (valid) {
-                zdst[r * AC + tid] = z;
+                if (!debug_out) zdst[r * AC + tid] = z;                // (irbpp_possible_position leaves the last observation's hand-over alone: the next step reads its drop height there)
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
                 if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                     const int idx = li + 32;
@@ -1031,7 +1031,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         }
         uint32_t bits_lo = 0u, bits_hi = 0u;                 // my level code as a bit
         if (valid) {
-            zdst[r * AC + cell] = z;
+            if (!debug_out) zdst[r * AC + cell] = z;
             const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
             if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                 const int idx = li + 32;
@@ -2070,13 +2070,16 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
     }
     uint32_t st_key = 0u;
     int st_next = -2;                                 // -2: not prefetched
-    if (mode == MODE_STEP) {                          // round 2: candidate key, the next item of the trajectory
-        st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);
+    constexpr int SRW_ = sizeof(ShapeRot) / 4;
+    int* const sr0 = (int*)(smem + P.o_img);          // the R ShapeRots of the item being placed: the level images' bytes, idle until
+    if (mode == MODE_STEP) {                          //   the overlap test.  round 2: candidate key, the next item of the trajectory,
+        st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);            //   and those ShapeRots (one dword per thread, coalesced)
         st_key = st_a < st_nrows ? S.cand[(size_t)b * P.S + st_a] : 0u;     // rows beyond the last are zeros
         if (P.K == 1) {
             const int at = T.stream ? (int)((uint32_t)st_cursor % (uint32_t)T.seq_len) : st_cursor;
             st_next = at < T.seq_len ? T.seq[(long long)st_trow * T.seq_len + at] : -1;
         }
+        if (tid < P.R * SRW_) sr0[tid] = st_item0 >= 0 ? ((const int*)(T.sr + (size_t)st_item0 * P.R))[tid] : 0;
     }
     __syncthreads();
 
@@ -2124,13 +2127,14 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         const int item0 = st_item0;
         const int oa = st_oa;
         bool ok = item0 >= 0 && st_nvalid > 0 && rot < P.R;          // prejudge (:238-245)
-        // round 3: the placed item's ShapeRot and volume, and -- speculatively, for the observation that follows a
-        // successful placement -- the R ShapeRots of the next item (one dword per thread, stored to LDS further down)
-        ShapeRot sr = {};
-        if (item0 >= 0 && rot < P.R) sr = T.sr[item0 * P.R + rot];
+        // the placed item's ShapeRot: staged in LDS with round 2 (until round 5: a 112-byte copy per thread from global memory,
+        // one more dependent round trip behind the candidate key)
+        const bool have_sr = item0 >= 0 && rot < P.R;
+        const ShapeRot& sr = ((const ShapeRot*)sr0)[have_sr ? rot : 0];
+        // round 3: the volume, and -- speculatively, for the observation that follows a successful placement -- the R
+        // ShapeRots of the next item (one dword per thread, stored to LDS further down)
         double vol0 = 0.0;
         if (tid == 0 && item0 >= 0) vol0 = T.volume[item0];
-        constexpr int SRW_ = sizeof(ShapeRot) / 4;
         int sr_pref = 0;
         const bool pref_ok = st_next >= 0 && st_next < T.n_shapes;
         if (pref_ok && tid < P.R * SRW_) sr_pref = ((const int*)(T.sr + (size_t)st_next * P.R))[tid];
@@ -2142,17 +2146,39 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         // The reference reads the drop height before it looks at `success`, and appends the placement to
         // self.packed either way (binPhy.py:266,296): with a placement log attached, a refused placement needs
         // its height too.
-        const bool in_grid = item0 >= 0 && rot < P.R && lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay;
-        // round 4: the thread's first top cell (heightmap update) is requested together with its bottom cells
+        const bool in_grid = have_sr && lx <= P.Ax - sr.ax && ly <= P.Ay - sr.ay;
+        const bool want_z = in_grid && (ok || cold_args()->S.log_meta != nullptr);
+        // ... which is an entry of the posZmap the last observation of this bin computed (self.space.posZmap, binPhy.py:266):
+        // where naiveMask was set -- every candidate row with V = 1 -- the overlap test left it in w_posz, and the bit row
+        // of w_valid says so.  Also round 3, together with the thread's first top cell (heightmap update).
+        uint32_t vword = 0u;
+        double zc = 1e3;
+        if (want_z) {
+            vword = S.w_valid[((size_t)b * P.R + rot) * 16 + lx];
+            zc = S.w_posz[((size_t)b * P.R + rot) * P.AC + lx * P.Ay + ly];
+        }
         Cell tc0 = {};
-        if (ok && tid < sr.nt) tc0 = T.tcell[sr.ot + tid];
-        if (in_grid && (ok || cold_args()->S.log_meta != nullptr)) {
-            const Cell* cells = T.bcell + sr.ob;
-            for (int rep = 0; rep < IRBPP_REPS(11); ++rep) {
-            double m = sr.has_out ? 0.0 : -1e300;
+        const int s_nt = ok ? sr.nt : 0, s_ot = sr.ot;
+        if (tid < s_nt) tc0 = T.tcell[s_ot + tid];
+        if (want_z) {
+            if ((vword >> ly) & 1u) {
+                z = zc;
+            } else {
+                // A cell the observation did not list as valid (a zero-padded row, an action beyond the rows -- nothing a policy
+                // that honours the mask column ever picks): its posZmap entry is recomputed from the footprint's bottom cells
+                // (space.py:118-119), by ONE thread -- the workgroup-parallel form of this loop cost the kernel registers on a
+                // path that practically never runs.
+                if (tid == 0) {
+                    const Cell* cells = T.bcell + sr.ob;
+                    const int s_nb = sr.nb;
+                    double m = sr.has_out ? 0.0 : -1e300;
 #pragma unroll 1
-            for (int e = tid; e < sr.nb; e += BLOCK) m = fmax(m, L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v);
-            z = block_max_f64(m, L.redd);
+                    for (int e = 0; e < s_nb; ++e) m = fmax(m, L.hm[tile_of_cell(P, lx, ly, cells[e].ij)] - cells[e].v);
+                    L.redd[0] = m;
+                }
+                __syncthreads();
+                z = L.redd[0];
+                __syncthreads();
             }
         }
         if (ok) {
@@ -2193,10 +2219,10 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         }
         if (ok) {
             // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
-            const Cell* cells = T.tcell + sr.ot;
+            const Cell* cells = T.tcell + s_ot;
             for (int rep = 0; rep < IRBPP_REPS(12); ++rep)
 #pragma unroll 1
-            for (int e = tid; e < sr.nt; e += BLOCK) {
+            for (int e = tid; e < s_nt; e += BLOCK) {
                 const Cell tc = e == tid ? tc0 : cells[e];
                 const int ij = tc.ij;
                 const int row = lx * P.step + (ij & 0xFFFF), col = ly * P.step + (ij >> 16);
