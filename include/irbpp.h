@@ -87,6 +87,11 @@ typedef struct {
 #define IRBPP_TUNE_INLINE_POLYGON 256 /* every trace wave approximates the borders it followed itself; no polygon kernel (the
                                          path a full record list takes, forced for the parity tests; measured slower at every size) */
 #define IRBPP_TUNE_NO_HEAVY_FIRST 512 /* emit kernel: the bins in launch order, speckled ones not first                        */
+#define IRBPP_TUNE_FUSED_APPLY 2048 /* step(): the actions applied inside the transition kernel (one 256-thread workgroup per bin, as until
+                                      round 4) whatever the size of the launch ...                                              */
+#define IRBPP_TUNE_SPLIT_APPLY 4096 /* ... or by irbpp_apply_kernel (one wave per bin) in front of it whatever the size (default: split
+                                      from the size on at which it pays, see split_apply in irbpp_capi.hip); identical results, for
+                                      A/B runs and the parity tests                                                              */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

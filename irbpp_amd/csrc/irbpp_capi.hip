@@ -456,6 +456,27 @@ static int pick_spec(const irbpp_env* env) {
 #endif
 }
 
+// step(): the actions are applied by irbpp_apply_kernel (a wave per bin) and the transition kernel only observes
+// (MODE_OBSERVE), unless the stability proxy is on (it rates the placement on the LDS tile) or the caller asks for the fused form
+// -- from the launch size on at which that pays.  The apply kernel costs a launch and one pass of its dependent reads
+// (~9 us at any size, 15 us with free-form footprints); inside the transition kernel the same chain is paid once per ROUND
+// of workgroups (eight per CU), hidden in part behind the other workgroups' arithmetic.  Measured on the specialised builds
+// (profiles/r05/s6, placement-steps/s split vs fused): BlockOut 2048 / 4096 / 6144 / 8192 / 16384 bins -4 % / 0 / +1.7 /
+// +3.0 / +6.1 %; cube 4096 / 8192: 0 / +2.7 %; free-form solids at R = 8: 4096 -1.1 %, 8192 +0.3 % (BlockOut at R = 8: 0 /
+// +1.6 %); the 64 x 64 heightmap (four workgroups per CU, footprints of up to 1600 cells): -2 % at two and at four rounds;
+// a buffered step (K > 1: the apply phase and a float32 copy of the tile, nothing to take out): -22 % / -52 %.  Hence: online
+// steps only; lattice and box data from three rounds of workgroups on, cell lists from four rounds on where eight
+// workgroups share a CU.
+static bool split_apply(const irbpp_env* env, int n) {
+    if (env->P.stability != 0 || (env->cfg.tuning & IRBPP_TUNE_FUSED_APPLY)) return false;
+    if (env->cfg.tuning & IRBPP_TUNE_SPLIT_APPLY) return true;
+    if (env->P.K > 1) return false;
+    const int per_cu = (160 * 1024) / (env->P.lds_bytes > 0 ? env->P.lds_bytes : 1);
+    if (per_cu < 8) return false;
+    const bool lists = env->P.block_b == 0 && !env->P.box;
+    return n >= (lists ? 4 : 3) * 256 * 8;
+}
+
 static EnvKernel pick_env_kernel(const irbpp_env* env) {
     const Params& P = env->P;
     const int t = env->cfg.tuning;
@@ -526,7 +547,14 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
                              !(env->cfg.tuning & IRBPP_TUNE_NO_HEAVY_FIRST);
     io.heavy_turn = heavy_first ? env->heavy_turn : -1;
     if (heavy_first) env->heavy_turn ^= 1;
-    hipLaunchKernelGGL(pick_env_kernel(env).fn, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, mode);
+    int env_mode = mode;
+    if (mode == MODE_STEP && split_apply(env, n)) {
+        io.n_slots = n;
+        hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+        env_mode = MODE_OBSERVE;         // (a buffered step ends with the apply kernel: it wrote the order observation)
+    }
+    if (!(env_mode == MODE_OBSERVE && env->P.K > 1))
+        hipLaunchKernelGGL(pick_env_kernel(env).fn, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, env_mode);
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything

@@ -314,7 +314,8 @@ enum Mode : int32_t {
     MODE_RESET = 0,       // reset(): new episodes everywhere, first observation
     MODE_STEP = 1,        // step(): apply action, auto-reset, next observation
     MODE_CANDS = 2,       // get_action_candidates(): location observation of the chosen slot
-    MODE_POSSIBLE = 3     // get_possible_position() only, results to global memory
+    MODE_POSSIBLE = 3,    // get_possible_position() only, results to global memory
+    MODE_OBSERVE = 4      // second half of a split step(): irbpp_apply_kernel has applied the actions; observe the queue's first item (K == 1)
 };
 
 struct StepIO {
@@ -344,6 +345,7 @@ struct StepIO {
     int32_t use_order;          // 1: launch slot -> bin through State::order (bins grouped by observed item per die); 0: identity
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
     int32_t heavy_turn;         // which of State::w_heavy's two lists this launch fills and serves (-1: none: listed resets, block / box data)
+    int32_t n_slots;            // launch slots of this launch (irbpp_apply_kernel: one wave per slot, four per workgroup)
 };
 
 }  // namespace irbpp

@@ -1986,18 +1986,21 @@ irbpp_polygon_kernel(const Params P, const State S
 // are exactly two rounds of the chip (measured on the block path: 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups
 // per CU).  irbpp_env_kernel_wide decides the path at run time and lets the register allocator have what it wants: the
 // fallback that irbpp_config::tuning can force for A/B measurements (see pick_env_kernel in irbpp_capi.hip).
-template <int PATH, int SPEC>
+template <int PATH, int SPEC, bool FUSED>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
 #ifndef IRBPP_ENV_WAVES
 #define IRBPP_ENV_WAVES 8
 #endif
+// FUSED: the build can apply a step's actions itself (MODE_STEP) as well as observe behind irbpp_apply_kernel (MODE_OBSERVE):
+// which of the two a step takes is decided per launch (irbpp_capi.hip: split_apply).  (An observe-only build of the block
+// path allocates five SGPR spills instead of sixteen and is not measurably faster.)
 #define IRBPP_ENV_KERNEL(NAME, PATH, SPEC, ATTR)                                                                        \
     extern "C" __global__ void __launch_bounds__(BLOCK) ATTR                                                           \
     NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                             \
         extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                           \
-        env_transition<PATH, SPEC>(P, T, S, io, mode, smem);                                                           \
+        env_transition<PATH, SPEC, true>(P, T, S, io, mode, smem);                                                     \
     }
 // (eight waves per SIMD need <= 64 VGPRs AND <= 96 SGPRs of the SIMD's 800: the cap is on both)
 #define IRBPP_CAPPED __attribute__((amdgpu_waves_per_eu(IRBPP_ENV_WAVES, IRBPP_ENV_WAVES)))
@@ -2017,9 +2020,10 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_s3, PATH_GENERIC, 3, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
 #endif
 
-template <int PATH, int SPEC>
+template <int PATH, int SPEC, bool FUSED>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem) {
+    if constexpr (!FUSED) { if (mode == MODE_STEP) return; }         // (never launched that way: irbpp_capi.hip)
     // SPEC > 0: sizes, LDS offsets and division constants become literals (the run-time build keeps reading the kernarg
     // segment where it needs a field: a copy costs it its register allocation)
     Params P_spec;
@@ -2029,7 +2033,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
     // S.order, which irbpp_item_order_kernel groups by observed item per die.
     const bool some = mode == MODE_RESET && io.bin_list != nullptr;          // reset_specific
     const int slot = (int)blockIdx.x + io.block_off;
-    const int b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+    const int b = ((mode == MODE_STEP || mode == MODE_CANDS || mode == MODE_OBSERVE) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
     const int tid = threadIdx.x;
     if (b < 0 || b >= P.N) {                                                 // whole workgroup leaves
         if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_BIN);
@@ -2046,7 +2050,9 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
     // under load -- more than the arithmetic of the whole apply phase.  The reads are therefore issued as early as
     // their addresses are known, in four rounds, and carried in registers to where they are used.
     int st_a = 0, st_item0 = -1, st_oa = 0, st_nvalid = 0, st_nrows = 0, st_cursor = 0, st_trow = 0;
-    if (mode == MODE_STEP) {                          // round 1: needs only b; in flight together with the tile
+    int ob_item = -1;                                 // MODE_OBSERVE: the item irbpp_apply_kernel left at the head of the queue
+    if (mode == MODE_OBSERVE) ob_item = q[0];
+    if (FUSED && mode == MODE_STEP) {                 // round 1: needs only b; in flight together with the tile
         st_a = io.actions[b];
         const BinState* ps0 = S.bs + b;
         st_item0 = ps0->cur_item;
@@ -2072,7 +2078,12 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
     int st_next = -2;                                 // -2: not prefetched
     constexpr int SRW_ = sizeof(ShapeRot) / 4;
     int* const sr0 = (int*)(smem + P.o_img);          // the R ShapeRots of the item being placed: the level images' bytes, idle until
-    if (mode == MODE_STEP) {                          //   the overlap test.  round 2: candidate key, the next item of the trajectory,
+    bool ob_staged = false;
+    if (mode == MODE_OBSERVE) {                       // round 2 of an observation: the item's ShapeRots, in place before the barrier
+        ob_staged = ob_item >= 0 && ob_item < T.n_shapes;
+        if (ob_staged && tid < P.R * SRW_) L.sr[tid] = ((const int*)(T.sr + (size_t)ob_item * P.R))[tid];
+    }
+    if (FUSED && mode == MODE_STEP) {                 //   the overlap test.  round 2: candidate key, the next item of the trajectory,
         st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);            //   and those ShapeRots (one dword per thread, coalesced)
         st_key = st_a < st_nrows ? S.cand[(size_t)b * P.S + st_a] : 0u;     // rows beyond the last are zeros
         if (P.K == 1) {
@@ -2096,6 +2107,9 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         oa = oa < 0 ? 0 : (oa >= P.K ? P.K - 1 : oa);
         obs_item = q[oa];
         if (tid == 0) S.bs[b].order_action = oa;
+    } else if (mode == MODE_OBSERVE) {   // cur_observation of the item the split step left at the head of the queue
+        obs_item = ob_item;
+        sr_staged = ob_staged;
     } else
     if (mode == MODE_RESET) {            // PackingGame.reset (binPhy.py:128-147)
         if (tid == 0) {
@@ -2121,7 +2135,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
             for (int i = 0; i < P.K; ++i) L.redi[16 + i] = q[i];
         }
         __syncthreads();
-    } else {                             // PackingGame.step (binPhy.py:248-337)
+    } else if constexpr (FUSED) {        // PackingGame.step (binPhy.py:248-337)
         const uint32_t key = st_key;                                 // action_to_position (:234-236)
         const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
         const int item0 = st_item0;
@@ -2316,6 +2330,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         __syncthreads();
     }
 
+    if (mode == MODE_OBSERVE) stamp(io, b, 1);
     if (mode == MODE_RESET || mode == MODE_STEP) {
         stamp(io, b, 1);
         if (P.K == 1) {                  // online: cur_observation with a fresh item (binPhy.py:188-227)
@@ -2328,6 +2343,215 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         }
     }
     if (do_observe) observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
+}
+
+// ---------------------------------------------------------------------------------------
+// PackingGame.step without its observation (binPhy.py:248-337 up to the cur_observation call): ONE WAVE per bin.
+// Applying an action is a chain of dependent global reads -- action and bin state; candidate key, the placed item's
+// ShapeRots; drop height and top cells; the heightmap cells under them -- with a few dozen instructions of arithmetic in
+// between: latency, no work.  Inside the transition kernel that chain held a 256-thread workgroup with its 15 KB of LDS
+// for 21 k of its 47 k cycles, eight workgroups per CU at a time (profiles/r05/s3, s4).  As a kernel of its own with a wave
+// per bin every bin of the launch is resident at once (32 waves per CU: 8192 bins fill the chip exactly), the chain is
+// paid once per launch instead of once per round of workgroups, and the heightmap is updated where it lives: the
+// footprint's cells of the float64 map in HBM (a few hundred bytes), not a tile.  The observation of the next item is the
+// transition kernel's MODE_OBSERVE, launched behind this one.  A buffered environment's step ends here: the order
+// observation [k ids | heightmap] is written by the bin's wave.
+// Same arithmetic, same order of operations, same outputs as the fused apply phase of env_transition (which the
+// stability proxy and IRBPP_TUNE_FUSED_APPLY still run: tests/test_gpu_features.py plays both side by side).
+// ---------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_apply_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    const int lane = threadIdx.x & 63;
+    const int slot = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
+    if (slot >= io.n_slots) return;                                  // (wave-uniform)
+    const int b = __builtin_amdgcn_readfirstlane(slot + io.block_off);
+    double* const ghm = S.hm + (size_t)b * P.Hc;
+    int32_t* const q = S.queue + (size_t)b * P.K;
+    // round 1: the action and the bin's scalars
+    int a = io.actions[b];
+    const BinState* ps0 = S.bs + b;
+    const int item0 = ps0->cur_item, oa = ps0->order_action, nvalid0 = ps0->nvalid, nrows = ps0->nrows;
+    const int cursor = ps0->cursor, trow = ps0->traj_row;
+    // round 2: candidate key; ALL rotations' ShapeRots of the placed item, sixteen bytes per lane (R x 112 bytes are
+    // contiguous), so that the one the key names needs no round trip of its own; its volume; the next item of the trajectory
+    a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
+    const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane(a < nrows ? (int)S.cand[(size_t)b * P.S + a] : 0);   // action_to_position (:234-236)
+    int nxt = -2;
+    if (P.K == 1) {
+        const int at = T.stream ? (int)((uint32_t)cursor % (uint32_t)T.seq_len) : cursor;
+        nxt = at < T.seq_len ? T.seq[(long long)trow * T.seq_len + at] : -1;
+    }
+    static_assert(sizeof(ShapeRot) == 112, "seven 16-byte chunks per ShapeRot");
+    int4 srq = make_int4(0, 0, 0, 0);
+    if (item0 >= 0 && lane < P.R * 7) srq = ((const int4*)(T.sr + (size_t)item0 * P.R))[lane];
+    const double vol0 = item0 >= 0 ? T.volume[item0] : 0.0;
+    const int rot = key >> 16, lx = (key >> 8) & 255, ly = key & 255;
+    const bool have_sr = item0 >= 0 && rot < P.R;
+    const int rot7 = have_sr ? rot * 7 : 0;
+    // dword W (a compile-time offset) of the chosen rotation's ShapeRot: component W % 4 of lane rot * 7 + W / 4
+#define IRBPP_SRW(W) __builtin_amdgcn_readlane(((W) & 3) == 0 ? srq.x : ((W) & 3) == 1 ? srq.y : ((W) & 3) == 2 ? srq.z : srq.w, rot7 + ((W) >> 2))
+#define IRBPP_SRI(FIELD) IRBPP_SRW(offsetof(ShapeRot, FIELD) / 4)
+#define IRBPP_SRD(FIELD) __hiloint2double(IRBPP_SRW(offsetof(ShapeRot, FIELD) / 4 + 1), IRBPP_SRW(offsetof(ShapeRot, FIELD) / 4))
+    const int s_ax = IRBPP_SRI(ax), s_ay = IRBPP_SRI(ay), s_nb = IRBPP_SRI(nb), s_ob = IRBPP_SRI(ob), s_has_out = IRBPP_SRI(has_out);
+    const int s_ot = IRBPP_SRI(ot);
+    const double ext_x = IRBPP_SRD(ext_x), ext_y = IRBPP_SRD(ext_y), ext_z = IRBPP_SRD(ext_z);
+    bool ok = item0 >= 0 && nvalid0 > 0 && rot < P.R;                // prejudge (:238-245)
+    if (ok) {
+        const double tx = P.txs[lx & 15], ty = P.txs[ly & 15];       // np.round(lx*resA, 6), precomputed
+        if (round6_scaled(tx + ext_x - P.bin_x) > 0.0 || round6_scaled(ty + ext_y - P.bin_y) > 0.0) ok = false;
+    }
+    const int s_nt = ok ? IRBPP_SRI(nt) : 0;
+#undef IRBPP_SRD
+#undef IRBPP_SRI
+#undef IRBPP_SRW
+    // round 3: the drop height -- posZmap[rot, lx, ly] of the last observation (binPhy.py:266), which the overlap test left in
+    // w_posz wherever naiveMask was set (w_valid's bit row says so) -- and the lane's first top cell
+    const KernArgsPtr ka = cold_args();
+    const bool in_grid = have_sr && lx <= P.Ax - s_ax && ly <= P.Ay - s_ay;
+    const bool want_z = in_grid && (ok || ka->S.log_meta != nullptr);
+    uint32_t vword = 0u;
+    double zc = 1e3;
+    if (want_z) {
+        vword = S.w_valid[((size_t)b * P.R + rot) * 16 + lx];
+        zc = S.w_posz[((size_t)b * P.R + rot) * P.AC + lx * P.Ay + ly];
+    }
+    const Cell* const tcells = T.tcell + s_ot;
+    Cell tc0 = {};
+    if (lane < s_nt) tc0 = tcells[lane];
+    const int row0 = lx * P.step, col0 = ly * P.step;
+    // round 4: the heightmap cell under it
+    double h0 = 0.0;
+    const int i0 = (row0 + (tc0.ij & 0xFFFF)) * P.Hy + col0 + (tc0.ij >> 16);
+    if (lane < s_nt) h0 = ghm[i0];
+    double z = 1e3;
+    if (want_z) {
+        if ((vword >> ly) & 1u) {
+            z = zc;
+        } else {
+            // a cell the observation did not list as valid (a zero-padded row, an action beyond the rows): its posZmap entry
+            // from the footprint's bottom cells (space.py:118-119)
+            const Cell* cells = T.bcell + s_ob;
+            double m = s_has_out ? 0.0 : -1e300;
+            for (int e = lane; e < s_nb; e += 64) {
+                const Cell c = cells[e];
+                m = fmax(m, ghm[(row0 + (c.ij & 0xFFFF)) * P.Hy + col0 + (c.ij >> 16)] - c.v);
+            }
+            z = wave_max_f64(m);
+        }
+    }
+    if (ok) {
+        // Interface.simulateHeight (Interface.py:365-369) on the kinematic AABB, x scale
+        const double top = z * P.scale_z + ext_z * P.scale_z;
+        if (round6_scaled(top - P.ibin_z) > 0.0) ok = false;
+    }
+    if (ok) {
+        // heightmap update, closed form of space.py:213 (np.maximum with (T + z) * maskH)
+        if (lane < s_nt) ghm[i0] = fmax(h0, tc0.v + z);
+        for (int e0 = 64; e0 < s_nt; e0 += 4 * 64) {                 // (free-form footprints: four cells per lane in flight)
+            Cell tc[4];
+            int ix[4];
+            double hv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = e0 + u * 64 + lane;
+                tc[u] = tcells[e < s_nt ? e : s_nt - 1];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                ix[u] = (row0 + (tc[u].ij & 0xFFFF)) * P.Hy + col0 + (tc[u].ij >> 16);
+                hv[u] = ghm[ix[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (e0 + u * 64 + lane < s_nt) ghm[ix[u]] = fmax(hv[u], tc[u].v + z);
+        }
+    } else {
+        for (int i = lane; i < P.Hc; i += 64) ghm[i] = 0.0;            // Space.reset (space.py:49-52)
+    }
+    if (lane == 0) {
+        BinState* ps = S.bs + b;
+        if (ok) {
+            const double vol = vol0;
+            const double reward = (vol / P.bin_vol) * 10.0;          // binPhy.py:321-322
+            const double epr = ps->ep_reward + reward;
+            const int epl = ps->ep_len + 1;
+            const int slot_i = ps->item_idx;                         // self.packed.append(...) (binPhy.py:296)
+            if (ka->S.log_meta && slot_i < ka->S.log_cap) {
+                ka->S.log_meta[(size_t)b * ka->S.log_cap + slot_i] = (uint32_t)item0 | ((uint32_t)rot << 16) |
+                                                              ((uint32_t)lx << 20) | ((uint32_t)ly << 24);
+                ka->S.log_z[(size_t)b * ka->S.log_cap + slot_i] = z;
+            }
+            ps->ep_reward = epr;
+            ps->ep_len = epl;
+            ps->item_idx += 1;
+            ps->ratio_acc += vol;
+            for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];      // update_item_queue (IRcreator.py:22-24)
+            if (nxt == -2) nxt = fetch_item(T, S, trow, cursor);     // generate_item (:325): prefetched for K == 1
+            else {
+                if (T.stream) {                                       // the prefetched slot is consumed here (see fetch_item)
+                    if (nxt == STREAM_CONSUMED) raise_error(S, IRBPP_DEVERR_STREAM_DRY);
+                    else const_cast<int32_t*>(T.seq)[(long long)trow * T.seq_len + (int)((uint32_t)cursor % (uint32_t)T.seq_len)] = STREAM_CONSUMED;
+                }
+                if (nxt >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
+                else if (nxt < 0) nxt = -1;
+            }
+            q[P.K - 1] = nxt;
+            ps->cursor = cursor + 1;
+            if (ka->io.reward) ka->io.reward[b] = reward;
+            if (ka->io.done) ka->io.done[b] = 0;
+            if (ka->io.counter) ka->io.counter[b] = -1;
+            if (ka->io.ratio) ka->io.ratio[b] = -1.0;
+            if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
+            if (ka->io.ep_len) ka->io.ep_len[b] = epl;
+            if (ka->io.stable) ka->io.stable[b] = 0;
+        } else {
+            const int counter = ps->item_idx;                        // info (binPhy.py:306-309)
+            const double ratio = ps->ratio_acc / P.bin_vol;          // get_ratio (:149-153)
+            const double epr = ps->ep_reward + 0.0;
+            const int epl = ps->ep_len + 1;
+            if (ka->io.stable) ka->io.stable[b] = 0;
+            if (ka->io.reward) ka->io.reward[b] = 0.0;
+            if (ka->io.done) ka->io.done[b] = 1;
+            if (ka->io.counter) ka->io.counter[b] = counter;
+            if (ka->io.ratio) ka->io.ratio[b] = ratio;
+            if (ka->io.ep_reward) ka->io.ep_reward[b] = epr;
+            if (ka->io.ep_len) ka->io.ep_len[b] = epl;
+            if (ka->S.log_meta && counter < ka->S.log_cap) {           // the refused placement is in self.packed too (binPhy.py:296)
+                ka->S.log_meta[(size_t)b * ka->S.log_cap + counter] = (uint32_t)(item0 & 0xFFFF) | ((uint32_t)(rot & 15) << 16) |
+                                                               ((uint32_t)(lx & 15) << 20) | ((uint32_t)(ly & 15) << 24);
+                ka->S.log_z[(size_t)b * ka->S.log_cap + counter] = z;
+            }
+            double* tot = ka->S.totals + (size_t)b * 4;
+            tot[0] += 1.0; tot[1] += ratio; tot[2] += (double)counter; tot[3] += epr;
+            // auto-reset (shmem_vec_env.py:142-144) -> PackingGame.reset
+            const int ep = ps->episode + 1;
+            const int trow2 = trajectory_row(P, T, b, ep);
+            ps->episode = ep;
+            ps->traj_row = trow2;
+            const int c0 = T.stream ? cursor : 0;
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow2, c0 + i);
+            ps->cursor = c0 + P.K;
+            ps->item_idx = 0;
+            ps->ratio_acc = 0.0;
+            ps->ep_reward = 0.0;
+            ps->ep_len = 0;
+        }
+    }
+    if (P.K > 1 && io.obs != nullptr) {  // buffer branch of cur_observation (binPhy.py:228-230): [k ids | heightmap]
+        // (the queue was written by lane 0, heightmap cells by whichever lane held their top cell: made visible to the
+        // whole wave first)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        float* const obs = io.obs + (size_t)b * io.obs_stride;
+        for (int i = lane; i < P.K; i += 64) obs[i] = (float)q[i];
+        for (int i0 = 0; i0 < P.Hc; i0 += 8 * 64) {                  // eight loads in flight per lane
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; v[u] = ghm[i < P.Hc ? i : P.Hc - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; if (i < P.Hc) obs[P.K + i] = (float)v[u]; }
+        }
+    }
 }
 
 // Launch order of an online step on the generic path: bins that are about to observe the SAME item run on the same

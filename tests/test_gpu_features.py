@@ -229,36 +229,50 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
 @pytest.mark.parametrize("workload,n,steps,spec", [("blockout", 160, 130, "_s1"), ("cube", 128, 60, "_s2"), ("general", 96, 45, "_s3"),
                                                    ("abc_fine", 64, 40, "_s4"), ("blockout_k10", 96, 120, "_s1"),
                                                    ("blockout_r8", 96, 100, "_s3")])
-def test_specialised_builds_change_nothing(workload, n, steps, spec):
+def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, spec):
     """BASELINE.json's geometries run builds of the transition and emit kernels that have the grid sizes, LDS offsets and
-    division constants as compile-time literals (irbpp_device.h: SPEC_KEYS); IRBPP_TUNE_NO_SPECIALISED forces the build that
-    reads them from Params.  Same observations, rewards, done flags and heightmaps through whole episodes; and the
-    default really is the specialised build."""
+    division constants as compile-time literals (irbpp_device.h: SPEC_KEYS), and a step applies its actions in
+    irbpp_apply_kernel (a wave per bin) in front of the transition kernel.  IRBPP_TUNE_NO_SPECIALISED forces the builds that
+    read Params, IRBPP_TUNE_FUSED_APPLY the round-4 form (actions applied inside the transition kernel).  Same observations,
+    rewards, done flags, step outputs and heightmaps through whole episodes -- with the scripted policy, and with actions
+    drawn at random over all S rows for some bins (zero-padded rows: the drop height is then recomputed, not looked up)."""
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
     k = int(kw.get("bufferSize", 1))
-    a = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)
-    b = GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=_lib.TUNE_NO_SPECIALISED, **kw)
-    assert a.kernel_info()[1].split(" + ")[0].endswith(spec), a.kernel_info()
-    assert "_s" not in b.kernel_info()[1].split(" + ")[0].replace("irbpp_env_kernel", ""), b.kernel_info()
-    oa, ob = a.reset(), b.reset()
-    assert torch.equal(oa, ob)
+    flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY, _lib.TUNE_FUSED_APPLY, _lib.TUNE_SPLIT_APPLY,
+             _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY]
+    envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
+    names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
+    assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
+    assert names[1] == names[4] and "_s" not in names[1].replace("irbpp_env_kernel", ""), names
+    obs = [e.reset() for e in envs]
+    assert all(torch.equal(obs[0], o) for o in obs[1:])
+    gen = torch.Generator(device="cpu").manual_seed(5)
     done_total = 0
     for t in range(steps):
         if k > 1:
             slot = torch.full((n,), t % k, dtype=torch.int32, device=DEV)
-            la, lb = a.get_action_candidates(slot), b.get_action_candidates(slot)
-            assert torch.equal(la, lb), f"location observation, step {t}"
-            act = a.policy_minz(la)
+            loc = [e.get_action_candidates(slot) for e in envs]
+            assert all(torch.equal(loc[0], x) for x in loc[1:]), f"location observation, step {t}"
+            act = envs[0].policy_minz(loc[0])
         else:
-            act = a.policy_minz(oa)
-        ra, rb = a.step(act), b.step(act)
-        for x, y in zip(ra, rb):
-            assert torch.equal(x, y), f"step {t}"
-        oa, ob = ra[0].clone(), rb[0].clone()
-        done_total += int(ra[2].sum())
-    assert torch.equal(a.get_heightmaps(), b.get_heightmaps())
+            act = envs[0].policy_minz(obs[0])
+        if t % 7 == 3:                                       # some bins act at random over all S rows, padding included
+            rnd = torch.randint(0, S, (n,), generator=gen, dtype=torch.int32).to(DEV)
+            pick = (torch.arange(n, device=DEV) % 4) == (t % 4)
+            act = torch.where(pick, rnd, act)
+        res = [e.step(act) for e in envs]
+        info = [e.step_info_host() for e in envs]
+        for j in range(1, len(envs)):
+            for x, y in zip(res[0], res[j]):
+                assert torch.equal(x, y), f"step {t}, env {j}"
+            for key in info[0]:
+                np.testing.assert_array_equal(info[0][key], info[j][key], err_msg=f"{key}, step {t}, env {j}")
+        obs = [r[0].clone() for r in res]
+        done_total += int(res[0][2].sum())
+    hm = [e.get_heightmaps() for e in envs]
+    assert all(torch.equal(hm[0], h) for h in hm[1:])
     assert done_total > 0
-    for e in (a, b):
+    for e in envs:
         e.check_device_error()
         e.close()

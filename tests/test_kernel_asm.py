@@ -54,11 +54,9 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
     1.1 us): a build that spills more than the state the profiles were taken on fails here instead of shipping."""
     sizes = asmcheck.scratch_sizes(build.build(force=False))
     limits = {"irbpp_emit_kernel": 0, "irbpp_trace_kernel": 0, "irbpp_trace_kernel_c32": 0, "irbpp_trace_kernel_c16": 0,
-              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 36, "irbpp_env_kernel_box8": 0, "irbpp_env_kernel_generic8": 16,
+              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 0, "irbpp_env_kernel_box8": 0, "irbpp_env_kernel_generic8": 48, "irbpp_apply_kernel": 0,
               "irbpp_env_kernel_generic": 0, "irbpp_env_kernel_box": 0,
               # round 5: the builds BASELINE.json's geometries run (sizes as compile-time constants, irbpp_device.h SPEC_KEYS);
-              # the run-time block build (lattice data on other geometries) keeps nine dwords since the apply phase reads the
-              # placed item's ShapeRot from LDS
               "irbpp_env_kernel_s1": 0, "irbpp_env_kernel_s2": 0, "irbpp_env_kernel_s3": 16, "irbpp_env_kernel_s4": 0,
               "irbpp_emit_kernel_s1": 0, "irbpp_emit_kernel_s2": 0, "irbpp_emit_kernel_s3": 0, "irbpp_emit_kernel_s4": 0,
               "irbpp_env_kernel_wide": 36}           # (_wide: the A/B build that decides the overlap path at run time; not a default)
