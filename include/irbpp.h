@@ -92,6 +92,9 @@ typedef struct {
 #define IRBPP_TUNE_SPLIT_APPLY 4096 /* ... or by irbpp_apply_kernel (one wave per bin) in front of it whatever the size (default: split
                                       from the size on at which it pays, see split_apply in irbpp_capi.hip); identical results, for
                                       A/B runs and the parity tests                                                              */
+#define IRBPP_TUNE_BLOCK_EMIT 8192 /* emit kernel: one 256-thread workgroup per bin also for lattice / box data (default there, from 2048
+                                     bins per launch on: one wave per bin, four bins per workgroup); identical results          */
+#define IRBPP_TUNE_WAVE_EMIT 16384 /* ... or the wave-per-bin form for lattice / box data whatever the size of the launch      */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

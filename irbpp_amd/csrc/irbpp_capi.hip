@@ -90,7 +90,9 @@ int raise_lds_limits() {
                              (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
+                             (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2,
 #endif
+                             (const void*)irbpp_emit_wave_kernel,
                              (const void*)irbpp_emit_kernel, (const void*)irbpp_heuristic_kernel};
     for (const void* k : kernels)
         if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return IRBPP_ERR_HIP;
@@ -523,6 +525,7 @@ static int pick_trace_cpw(const irbpp_env* env, int n) {
 // transition kernel and, in the split pipeline, trace and emit -- on one stream.
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
     io.block_off = first;
+    io.n_slots = n;
     io.auto_action = env->auto_actions;
     io.use_order = 0;
     if (mode == MODE_STEP && env->item_order && first == 0 && n == env->P.N) {
@@ -549,7 +552,6 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     if (heavy_first) env->heavy_turn ^= 1;
     int env_mode = mode;
     if (mode == MODE_STEP && split_apply(env, n)) {
-        io.n_slots = n;
         hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
         env_mode = MODE_OBSERVE;         // (a buffered step ends with the apply kernel: it wrote the order observation)
     }
@@ -576,18 +578,22 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
 #else
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S);
 #endif
-        env_kernel_fn emit_fn = irbpp_emit_kernel;
+        // lattice and box data (practically never more than S candidates per bin): a wave per bin, four bins per workgroup
+        // -- from 2048 bins on: a launch over 1024 bins is one such workgroup per CU, 2.6 % slower than a workgroup per bin (profiles/r05/s7)
+        const bool wave_emit = (env->P.block_b > 0 || env->P.box) && !heavy_first && !(env->cfg.tuning & IRBPP_TUNE_BLOCK_EMIT) &&
+                               (n >= 2048 || (env->cfg.tuning & IRBPP_TUNE_WAVE_EMIT));
+        env_kernel_fn emit_fn = wave_emit ? irbpp_emit_wave_kernel : irbpp_emit_kernel;
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
         switch (pick_spec(env)) {
-            case 1: emit_fn = irbpp_emit_kernel_s1; break;
-            case 2: emit_fn = irbpp_emit_kernel_s2; break;
+            case 1: emit_fn = wave_emit ? irbpp_emit_wave_kernel_s1 : irbpp_emit_kernel_s1; break;
+            case 2: emit_fn = wave_emit ? irbpp_emit_wave_kernel_s2 : irbpp_emit_kernel_s2; break;
             case 3: emit_fn = irbpp_emit_kernel_s3; break;
             case 4: emit_fn = irbpp_emit_kernel_s4; break;
             default: break;
         }
 #endif
-        hipLaunchKernelGGL(emit_fn, dim3(n + (heavy_first ? env->P.heavy_cap : 0)), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T,
-                           env->S, io, mode);
+        const int egrid = wave_emit ? (n + 3) / 4 : n + (heavy_first ? env->P.heavy_cap : 0);
+        hipLaunchKernelGGL(emit_fn, dim3(egrid), dim3(256), env->P.emit_lds_bytes, st, env->P, env->T, env->S, io, mode);
     }
 }
 

@@ -143,6 +143,7 @@ struct Params {
     int32_t nslot, slot_cap, slot_bytes, scratch_bytes, lds_bytes;   // lds_bytes: transition kernel (no posZValid region)
     int32_t lds_bytes_full;   // + posZValid at o_posz: heuristic kernel
     int32_t e_vmask, e_red, e_hist, e_keys, emit_lds_bytes;   // the emit kernel's own carve-up
+    int32_t ew_bytes, e_need; // wave-per-bin emit kernel: bytes of LDS per wave (vertex bits + candidate keys), offset of its flag words
     int32_t big_slot_bytes;   // bytes of the scratch region the serial redo of an oversized border may use
     // Block path of the overlap test: when every footprint of the dataset is a union of b x b tiles
     // (b a multiple of step) that are either masked out or have one bottom height, the per-bin grid
@@ -242,6 +243,10 @@ constexpr void layout_lds(Params& P, int32_t pad = 0) {
         P.e_hist = e;   e += align16(10 * npad > 1024 ? 10 * npad : 1024);       // >= 4 * S bytes for the rows' values too
     }
     P.e_keys = e;   e += align16(keys);
+    // wave-per-bin form of the emit kernel (lattice / box data): per wave the bin's vertex bits and up to S candidate keys
+    P.ew_bytes = align16((P.R * 16 + P.S + 64) * 4);
+    if (e < 4 * P.ew_bytes) e = 4 * P.ew_bytes;
+    P.e_need = e;   e += 16;                           // its four "this bin needs the workgroup" words, behind everything else
     P.emit_lds_bytes = e;
 }
 
@@ -278,7 +283,7 @@ constexpr Params spec_params(const SpecKey& k) {
     X(Hx) X(Hy) X(Hc) X(Ax) X(Ay) X(AC) X(step) X(R) X(S) X(pp) X(LX) X(LY) X(PL) X(tile_words) X(mg_pp) X(mg_ly)      \
     X(g_ysh) X(box) X(o_m1) X(o_vbits) X(o_sr) X(o_hm) X(o_posz) X(o_lev) X(o_present) X(o_taskidx) X(o_tasklist)      \
     X(o_img) X(o_clist) X(o_vmask) X(o_scratch) X(o_red) X(o_dps) X(nslot) X(slot_cap) X(slot_bytes) X(scratch_bytes)  \
-    X(lds_bytes) X(lds_bytes_full) X(e_vmask) X(e_red) X(e_hist) X(e_keys) X(emit_lds_bytes) X(big_slot_bytes)         \
+    X(lds_bytes) X(lds_bytes_full) X(e_vmask) X(e_red) X(e_hist) X(e_keys) X(emit_lds_bytes) X(ew_bytes) X(e_need) X(big_slot_bytes)         \
     X(block_b) X(mb_w) X(mb_h) X(o_mb) X(o_c2) X(mg_hy) X(mg_step) X(mg_ay) X(mg_ax) X(mg_ac) X(mg_mbw) X(dbg_repeat)  \
     X(split) X(wimg) X(heavy_thr) X(stability) X(obs_len1)
 constexpr bool spec_matches(const Params& P, const Params& C) {

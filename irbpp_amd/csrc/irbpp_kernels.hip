@@ -260,8 +260,8 @@ __device__ __forceinline__ ConstCellPtr as_const(const Cell* p) { return (ConstC
 // [0..4] phase boundaries, [5..7] contour-stage detail, [8]/[9] 100 MHz wall clock at entry/exit,
 // [10] HW_ID | XCC_ID << 32 (which CU the bin ran on)
 constexpr int PHASE_ROW = 16;
-__device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
-    if (io.phase_cycles && threadIdx.x == 0) {
+__device__ __forceinline__ void stamp(const StepIO& io, int b, int k, bool leader) {
+    if (io.phase_cycles && leader) {
         long long* row = io.phase_cycles + (size_t)b * PHASE_ROW;
         row[k] = (long long)clock64();
         if (k == 0) {
@@ -273,6 +273,8 @@ __device__ __forceinline__ void stamp(const StepIO& io, int b, int k) {
         if (k == 4) row[9] = (long long)wall_clock64();
     }
 }
+
+__device__ __forceinline__ void stamp(const StepIO& io, int b, int k) { stamp(io, b, k, threadIdx.x == 0); }
 
 __device__ inline SlotMem carve_slot(unsigned char* base, int cap, int cap_stk) {
     SlotMem m;
@@ -1661,6 +1663,170 @@ IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s1, true, 1)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s2, true, 2)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s3, true, 3)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s4, true, 4)
+#endif
+
+// ---------------------------------------------------------------------------------------
+// The emit kernel with ONE WAVE per bin (four bins per workgroup), for data whose bins practically never have more than S
+// candidates (lattice and box data).  An ordinary bin has ~100 candidate rows: as a 256-thread workgroup two waves did the
+// rows, two idled through the barriers, and 8192 bins were four rounds of workgroups, each a chain of dependent reads (vertex
+// bits -> keys -> posZ of the rows -> stores).  With a wave per bin there is no barrier on the ordinary path, 32 bins share
+// a CU and 8192 bins are ONE round.  A bin that needs the workgroup -- more than S candidates, or no candidate but valid
+// cells (both: radix select + sort over LDS) -- is flagged and served by all four waves with emit_observation behind one
+// barrier, after the waves' own bins are out.  Same rows, same order, same stores as emit_observation.
+// ---------------------------------------------------------------------------------------
+template <int SPEC>
+__device__ __forceinline__ void emit_wave_body(const Params& P_run, const Tables& T, const State& S, const StepIO& io, const int mode,
+                                               unsigned char* smem) {
+    Params P_spec;
+    const Params& P = SPEC == 0 ? P_run : (P_spec = specialise<SPEC>(P_run), P_spec);
+    int* const need = (int*)(smem + P.e_need);       // (dynamic LDS only: the kernel's limit is raised to the CU's whole 160 KB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
+    const bool some = mode == MODE_RESET && io.bin_list != nullptr;
+    // workgroup 0 retires the launch's flat lists and hands on the error word (see emit_body)
+    if (blockIdx.x == 0 && tid < NXCD) { S.w_total[tid * XCD_STRIDE] = 0; S.w_nround[tid * XCD_STRIDE] = 0; }
+    if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) *io.err_out = *S.err;
+    const int local = (int)blockIdx.x * WAVES + wave;
+    const int slot = local + io.block_off;
+    int b = -1;
+    if (local < io.n_slots) b = ((mode == MODE_STEP || mode == MODE_CANDS) && io.use_order) ? S.order[slot] : some ? io.bin_list[slot] : slot;
+    if (b >= P.N) b = -1;                            // (the transition kernel has flagged it already)
+    b = __builtin_amdgcn_readfirstlane(b);
+    if (lane == 0) need[wave] = -1;
+    if (b >= 0) {
+        uint32_t* const vm = (uint32_t*)(smem + wave * P.ew_bytes);    // [R * 16] vertex bits
+        uint32_t* const keys = vm + R * 16;                            // [S] candidate keys
+        const uint32_t* gv = S.w_vmask + (size_t)b * R * 16;
+        for (int i = lane; i < R * 16; i += 64) vm[i] = gv[i];
+        const int nvalid = S.w_meta[(size_t)b * WMETA + 2], item = S.w_meta[(size_t)b * WMETA + 3];
+        const int prev_rows = io.obs_rows != nullptr ? io.obs_rows[b] : -1;
+        float* const obs = io.obs + (size_t)(some ? slot : b) * io.obs_stride;
+        const double* const zsrc = S.w_posz + (size_t)b * R * AC;
+        const uint32_t* const gvalid = S.w_valid + (size_t)b * R * 16;
+        stamp(io, b, 3, lane == 0);
+        IRBPP_WAVE_SYNC();
+        // candidate rows per rotation, ordered by (col, row) (np.unique, cvTools.py:101): a lane per (rotation, column), four
+        // rotations at a time; counted first -- only S keys fit, and more than S is the workgroup's business
+        const int cx = lane & 15;
+        auto column = [&](int r) {                                     // my column of rotation r: bit cy = vertex at (row cy, col cx)
+            uint32_t col = 0u;
+            if (r < R && cx < Ay) {
+#pragma unroll
+                for (int cy = 0; cy < 16; ++cy) col |= ((vm[r * 16 + cy] >> cx) & 1u) << cy;
+                col &= (1u << Ax) - 1u;
+            }
+            return col;
+        };
+        int n = 0;
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += 4) n += __builtin_amdgcn_readlane(wave_inclusive_sum(__popc(column(r0 + (lane >> 4)))), 63);
+        if (n > P.S || (n == 0 && nvalid > 0)) {
+            if (lane == 0) need[wave] = b;
+        } else {
+            int at0 = 0;
+#pragma unroll 1
+            for (int r0 = 0; r0 < R; r0 += 4) {
+                const int r = r0 + (lane >> 4);
+                uint32_t col = column(r);
+                const int cnt = __popc(col), incl = wave_inclusive_sum(cnt);
+                int at = at0 + incl - cnt;
+                while (col != 0u) {
+                    const int cy = __ffs((int)col) - 1;
+                    col &= col - 1u;
+                    keys[at++] = ((uint32_t)r << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+                }
+                at0 += __builtin_amdgcn_readlane(incl, 63);
+            }
+            IRBPP_WAVE_SYNC();
+            const bool fallback = n == 0;            // nothing fits (nvalid == 0): the first S cells in position order, H = bin height, V = 0
+            const int total_cells = R * AC;
+            const int nrows = fallback ? (total_cells < P.S ? total_cells : P.S) : n;
+            int write_rows = P.S;
+            if (io.obs_rows != nullptr) {
+                if (prev_rows >= 0) write_rows = prev_rows > nrows ? prev_rows : nrows;
+                if (lane == 0) io.obs_rows[b] = nrows;
+            }
+            float best = INFINITY;                   // MINZ: the lowest float32 H among V == 1, first on ties
+            int bi = 0x7fffffff;
+            for (int row = lane; row < write_rows; row += 64) {
+                float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
+                if (row < nrows) {
+                    uint32_t k;
+                    if (fallback) {
+                        const int r = fdiv(row, AC, P.mg_ac), c = row - r * AC, x = fdiv(c, Ay, P.mg_ay);
+                        k = ((uint32_t)r << 16) | ((uint32_t)x << 8) | (uint32_t)(c - x * Ay);
+                    } else {
+                        k = keys[row];
+                    }
+                    float rv;
+                    if (fallback) rv = (float)((gvalid[(k >> 16) * 16 + ((k >> 8) & 255u)] >> (k & 255u)) & 1u);
+                    else rv = (float)zsrc[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];       // a candidate is a valid cell
+                    v0 = (float)(k >> 16);
+                    v1 = (float)((k >> 8) & 255u);
+                    v2 = (float)(k & 255u);
+                    v3 = fallback ? (float)P.bin_z : rv;
+                    v4 = fallback ? rv : 1.0f;
+                    S.cand[(size_t)b * P.S + row] = k;
+                    if (!fallback && rv < best) { best = rv; bi = row; }
+                }
+                float* const o = obs + 5 * row;
+                o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
+            }
+            if (lane == 0) {
+                S.bs[b].cur_item = item;
+                S.bs[b].nvalid = nvalid;
+                S.bs[b].nrows = nrows;
+            }
+            if (io.auto_action != nullptr) {
+#define IRBPP_ARGMIN_STEP(CTRL, ROWS)                                                                                          \
+                {                                                                                                              \
+                    const float ob = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(best), __float_as_int(best), CTRL, ROWS, 0xF, false)); \
+                    const int oi = __builtin_amdgcn_update_dpp(bi, bi, CTRL, ROWS, 0xF, false);                                 \
+                    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }                                           \
+                }
+                IRBPP_ARGMIN_STEP(0x111, 0xF) IRBPP_ARGMIN_STEP(0x112, 0xF) IRBPP_ARGMIN_STEP(0x114, 0xF) IRBPP_ARGMIN_STEP(0x118, 0xF)
+                IRBPP_ARGMIN_STEP(0x142, 0xA) IRBPP_ARGMIN_STEP(0x143, 0xC)
+#undef IRBPP_ARGMIN_STEP
+                if (lane == 63) io.auto_action[b] = bi == 0x7fffffff ? 0 : bi;
+            }
+            stamp(io, b, 4, lane == 0);
+        }
+    }
+    __syncthreads();
+    // the bins that need the workgroup (rare): one after the other, all four waves, the 256-thread routine
+    if ((need[0] & need[1] & need[2] & need[3]) == -1) return;          // (-1 = all bits set: nobody)
+    Lds L = {};
+    L.vmask = (uint32_t*)(smem + P.e_vmask);
+    L.redd = (double*)(smem + P.e_red);
+    L.redi = (int*)(L.redd + 8);
+    L.img = (uint16_t*)(smem + P.e_hist);
+    L.scratch = smem + P.e_keys;
+#pragma unroll 1
+    for (int w = 0; w < WAVES; ++w) {
+        const int bw = __builtin_amdgcn_readfirstlane(need[w]);       // (uniform: addresses stay scalar)
+        if (bw < 0) continue;
+        const int slot_w = (int)blockIdx.x * WAVES + w + io.block_off;
+        float* const obs = io.obs + (size_t)(some ? slot_w : bw) * io.obs_stride;
+        const uint32_t* gv = S.w_vmask + (size_t)bw * R * 16;
+        __syncthreads();
+#pragma unroll 1
+        for (int i = tid; i < R * 16; i += BLOCK) L.vmask[i] = gv[i];
+        const int nvalid = S.w_meta[(size_t)bw * WMETA + 2], item = S.w_meta[(size_t)bw * WMETA + 3];
+        __syncthreads();
+        stamp(io, bw, 3);
+        emit_observation(P, S, io, L, bw, item, nvalid, obs, S.w_posz + (size_t)bw * R * AC, S.w_valid + (size_t)bw * R * 16);
+    }
+}
+#define IRBPP_EMIT_WAVE_KERNEL(NAME, SPEC)                                                                                  \
+    extern "C" __global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(8, 8)))                      \
+    NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                              \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                            \
+        emit_wave_body<SPEC>(P, T, S, io, mode, smem);                                                                  \
+    }
+IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel, 0)
+#ifndef IRBPP_NO_SPEC
+IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel_s1, 1)
+IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel_s2, 2)
 #endif
 
 // ---------------------------------------------------------------------------------------

@@ -233,14 +233,15 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     """BASELINE.json's geometries run builds of the transition and emit kernels that have the grid sizes, LDS offsets and
     division constants as compile-time literals (irbpp_device.h: SPEC_KEYS), and a step applies its actions in
     irbpp_apply_kernel (a wave per bin) in front of the transition kernel.  IRBPP_TUNE_NO_SPECIALISED forces the builds that
-    read Params, IRBPP_TUNE_FUSED_APPLY the round-4 form (actions applied inside the transition kernel).  Same observations,
+    read Params, IRBPP_TUNE_FUSED_APPLY the round-4 form (actions applied inside the transition kernel), IRBPP_TUNE_BLOCK_EMIT
+    the emit kernel with a workgroup per bin where lattice / box data take the one with a wave per bin.  Same observations,
     rewards, done flags, step outputs and heightmaps through whole episodes -- with the scripted policy, and with actions
     drawn at random over all S rows for some bins (zero-padded rows: the drop height is then recomputed, not looked up)."""
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
     k = int(kw.get("bufferSize", 1))
-    flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY, _lib.TUNE_FUSED_APPLY, _lib.TUNE_SPLIT_APPLY,
-             _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY]
+    flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
+             _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT]
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
@@ -274,5 +275,34 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     assert all(torch.equal(hm[0], h) for h in hm[1:])
     assert done_total > 0
     for e in envs:
+        e.check_device_error()
+        e.close()
+
+
+def test_wave_emit_serves_bins_that_need_the_workgroup():
+    """The wave-per-bin emit kernel (lattice / box data) hands a bin with more than S candidates -- or with valid cells but
+    no candidate -- to its workgroup (radix select + sort over LDS).  With S = 40 on the Cube set that happens at most
+    steps: every observation against the C oracle and against the workgroup-per-bin emit kernel."""
+    from oracle.c_oracle import COracleVecEnv
+    sh = synthetic.cube_shapes()
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 60, seed=77)
+    n, s_sel = 10, 40
+    wave = GpuPackingEnv(sh, seqs, n, device=DEV, selectedAction=s_sel, tuning=_lib.TUNE_WAVE_EMIT)
+    block = GpuPackingEnv(sh, seqs, n, device=DEV, selectedAction=s_sel, tuning=_lib.TUNE_BLOCK_EMIT)
+    cenv = COracleVecEnv(n, sh, seqs, selectedAction=s_sel)
+    ow, ob, oc = wave.reset(), block.reset(), _f32(cenv.reset())
+    full = 0
+    for t in range(60):
+        assert torch.equal(ow, ob), f"step {t}"
+        np.testing.assert_array_equal(ow.cpu().numpy(), oc, err_msg=f"step {t}")
+        full += int((ow[:, :5 * s_sel].reshape(n, s_sel, 5)[:, :, 4] == 1).all(dim=1).sum())
+        act = torch.from_numpy(np.array([minz_action(o, s_sel) for o in oc], dtype=np.int32)).to(DEV)
+        rw, rb = wave.step(act), block.step(act)
+        for x, y in zip(rw, rb):
+            assert torch.equal(x, y)
+        oc = _f32(cenv.step(act.cpu().numpy())[0])
+        ow, ob = rw[0].clone(), rb[0].clone()
+    assert full > 20, full                       # observations whose S rows are all candidates: the selection ran
+    for e in (wave, block):
         e.check_device_error()
         e.close()

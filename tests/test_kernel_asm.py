@@ -59,6 +59,9 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
               # round 5: the builds BASELINE.json's geometries run (sizes as compile-time constants, irbpp_device.h SPEC_KEYS);
               "irbpp_env_kernel_s1": 0, "irbpp_env_kernel_s2": 0, "irbpp_env_kernel_s3": 16, "irbpp_env_kernel_s4": 0,
               "irbpp_emit_kernel_s1": 0, "irbpp_emit_kernel_s2": 0, "irbpp_emit_kernel_s3": 0, "irbpp_emit_kernel_s4": 0,
+              # wave-per-bin emit kernel: its ordinary path (a wave's own bin) touches no scratch; the spills sit in the path behind
+              # its early return (bins that need the workgroup: more than S candidates), around the loop over those bins
+              "irbpp_emit_wave_kernel": 216, "irbpp_emit_wave_kernel_s1": 152, "irbpp_emit_wave_kernel_s2": 108,
               "irbpp_env_kernel_wide": 36}           # (_wide: the A/B build that decides the overlap path at run time; not a default)
     for kernel, limit in limits.items():
         assert kernel in sizes, kernel
