@@ -379,7 +379,8 @@ def main():
     ap.add_argument("--scaling", default=None, choices=["weak", "strong"],
                     help="weak: --bins per GPU; strong: the global bins (of --config, else --bins) divided over the GPUs")
     ap.add_argument("--groups", type=int, default=0,
-                    help="independent groups of bins, each stepped on its own stream (0 = one group)")
+                    help="independent groups of bins, each stepped on its own stream (0 = as many as the library recommends "
+                         "for the data and size: vec_env.groups_for, i.e. two or one)")
     ap.add_argument("--tuning", type=int, default=0, help="irbpp_config::tuning bit flags (A/B measurements; results never change)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra measurements (other configs, 8192 bins, grouped, VecEnv)")
@@ -426,10 +427,12 @@ def main():
     shapes, seqs, kw = make_workload(workload)
     if a.tuning:
         kw["tuning"] = a.tuning
-    # `value` (cfg 2, the headline) is ONE group = one launch per kernel over all bins; north_star's sharded configs, whose
-    # per-GPU launches are small, take the number of groups the library recommends for their data and size unless --groups says otherwise
+    # The bins are stepped as the number of independent groups the library recommends for this data and size
+    # (vec_env.groups_for: two groups on two HIP streams where that was measured to pay -- repeatable, because two consecutive
+    # streams always get hardware queues of their own -- else one; what GpuVecEnv(num_groups=0) does); --groups overrides.
+    # The same bins as ONE launch group are measured beside it (`extra.one_group`).
     from irbpp_amd.vec_env import groups_for
-    groups = a.groups if a.groups > 0 else (groups_for(workload, bins) if a.config in ("cfg4", "cfg5") else 1)
+    groups = a.groups if a.groups > 0 else groups_for(workload, bins, device=dev)
     env = GroupedPackingEnv(shapes, seqs, bins, groups, device=dev, **D.shard(rank, world, bins), **kw)
     hc = env.Hx * env.Hy
     k = int(kw.get("bufferSize", 1))
@@ -473,42 +476,19 @@ def main():
     extra, grouped = None, None
     if world == 1 and not a.no_extra:
         extra = {}
-        if workload == "blockout" and groups == 1 and bins % 4 == 0 and bins >= 2048:
-            runs = [side_run(workload, bins, 4, 0.3) for _ in range(2)]
-            grouped = dict(runs[0])                             # BOTH instances: how the runtime maps four streams onto its
-            grouped["value"] = float(np.mean([r["value"] for r in runs]))    # hardware queues varies from one to the next
-            grouped["ms_per_step"] = float(np.mean([r["ms_per_step"] for r in runs]))
-            grouped["instances"] = [r["value"] for r in runs]
-            grouped["note"] = "mean of two instances (both listed); see bench.py"
-            # ... and the same in a child process that asks the runtime for eight hardware queues (GPU_MAX_HW_QUEUES, read when
-            # a process initialises HIP -- irbpp_amd.use_hardware_queues): with the default four the group streams share queues
-            try:
-                import subprocess
-                child_env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
-                res = subprocess.run([sys.executable, os.path.abspath(__file__), "--groups", "4", "--bins", str(bins), "--no-extra",
-                                      "--no-cpu-baseline", "--min-seconds", "0.3"], env=child_env, capture_output=True, text=True, timeout=240)
-                line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-                grouped["with_8_hardware_queues"] = {"value": json.loads(line)["value"], "ms_per_step": json.loads(line)["ms_per_step"],
-                                                     "note": "child process, GPU_MAX_HW_QUEUES=8, four groups"}
-            except Exception as exc:                                     # noqa: BLE001 -- an extra, never the measurement
-                grouped["with_8_hardware_queues"] = {"error": repr(exc)[:200]}
+        if groups != 1:
+            extra["one_group"] = side_run(workload, bins, 1)             # the same bins as one launch per kernel
         if workload == "blockout":
+            def recommended(wl, nb):
+                return side_run(wl, nb, groups_for(wl, nb, device=dev))
             if bins != 4096:
-                extra["bins4096_one_gpu"] = side_run("blockout", 4096)        # BASELINE configs[1] at its own size
+                extra["bins4096_one_gpu"] = recommended("blockout", 4096)     # BASELINE configs[1] at its own size
             if bins != 8192:
-                extra["bins8192_one_gpu"] = side_run("blockout", 8192)
-            extra["cfg3_general_4096"] = side_run("general", 4096)
-            extra["cfg4_blockout_k10_1024_per_gpu"] = side_run("blockout_k10", 1024)
-            extra["cfg5_abc_fine_2048_per_gpu"] = side_run("abc_fine", 2048)
-            # the sharded configs at their per-GPU sizes again, stepped as independent groups of bins on their own streams
-            # (vec_env.groups_for): a launch over so few bins leaves most of the chip idle, and groups overlap each other's kernels
-            from irbpp_amd.vec_env import groups_for
-            for key, wl, nb in (("cfg3_general_4096", "general", 4096), ("cfg4_blockout_k10_1024_per_gpu", "blockout_k10", 1024),
-                                ("cfg5_abc_fine_2048_per_gpu", "abc_fine", 2048)):
-                g = groups_for(wl, nb)
-                if g > 1:
-                    extra[key + f"_grouped"] = side_run(wl, nb, g)
-            extra["cfg1_cube_4096"] = side_run("cube", 4096)
+                extra["bins8192_one_gpu"] = recommended("blockout", 8192)
+            extra["cfg3_general_4096"] = recommended("general", 4096)
+            extra["cfg4_blockout_k10_1024_per_gpu"] = recommended("blockout_k10", 1024)
+            extra["cfg5_abc_fine_2048_per_gpu"] = recommended("abc_fine", 2048)
+            extra["cfg1_cube_4096"] = recommended("cube", 4096)
             extra["vecenv_step"] = vecenv_rate(4096, dev)
 
     if rank == 0:
@@ -541,9 +521,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "basis": "algorithmic bytes of one step of this rank's bins / wall time of one step",
                          "kernel": kernel_name, "kernel_ms": kernel_ms, "lds_bytes_per_workgroup": lds_bytes,
-                         "kernel_note": "a step is four kernels (transition, trace, polygon, emit), none of which carries the "
-                                        "step's bytes alone: kernel_ms = HIP events around the four on their stream (summed "
-                                        "over the groups), and `achieved` prices the step's algorithmic bytes on its wall time",
+                         "kernel_note": "a step is a chain of kernels (transition [behind irbpp_apply_kernel at large launches], trace, "
+                                        "polygon, emit), none of which carries the step's bytes alone: kernel_ms = HIP events "
+                                        "around the chain on its stream (summed over the groups, which overlap), and `achieved` "
+                                        "prices the step's algorithmic bytes on its wall time",
                          "algorithmic_bytes_per_step": bps},
             "episodes": {"finished_in_timed_region": finished, "finished_since_reset": float(tot[0]),
                          "mean_ratio": float(tot[1] / tot[0]) if tot[0] else None,
@@ -553,8 +534,6 @@ def main():
             out["roofline"]["traffic_note"] = why
         if issue is not None:
             out["roofline"]["issue"] = issue       # the kernel is instruction-issue bound, not HBM bound: SQ busy shares
-        if grouped is not None:
-            out["grouped_stepping"] = grouped
         if extra:
             out["extra"] = extra
         if cpu is not None:

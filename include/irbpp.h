@@ -340,8 +340,9 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
  * irbpp_debug_kernel_times waits for the recorded launches and writes the durations of the latest
  * min(max_count, recorded) of them in ms to ms_host, oldest first; *count says how many; the ring
  * is then empty again. */
-/* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and the name of the build of it that
- * launches (one per overlap path, with and without the 64-VGPR cap; a static string).  Valid after irbpp_load_shapes. */
+/* Tooling: LDS bytes per workgroup of the transition kernel for this configuration and the names of the kernels a step over
+ * all bins of this environment launches, " + "-separated, the transition kernel's build first (a string owned by the
+ * environment, rewritten by the next call).  Valid after irbpp_load_shapes. */
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name);
 /* The overlap path irbpp_load_shapes chose for the data set: 1 block path (every footprint a union of uniform b x b
  * tiles: lattice data), 2 box path (every footprint a solid box), 3 generic cell lists; IRBPP_ERR_STATE before the

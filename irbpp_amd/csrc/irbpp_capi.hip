@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -37,6 +38,7 @@ struct irbpp_env {
     size_t timing_next = 0, timing_used = 0;
     int timing_every = 1, timing_phase = 0;   // events go around every timing_every-th transition only
     std::vector<void*> allocs;
+    char kernel_names[256] = {0};          // irbpp_debug_kernel_info
 };
 
 #define HIP_TRY(expr)                                   \
@@ -466,9 +468,10 @@ static int pick_spec(const irbpp_env* env) {
 // (profiles/r05/s6, placement-steps/s split vs fused): BlockOut 2048 / 4096 / 6144 / 8192 / 16384 bins -4 % / 0 / +1.7 /
 // +3.0 / +6.1 %; cube 4096 / 8192: 0 / +2.7 %; free-form solids at R = 8: 4096 -1.1 %, 8192 +0.3 % (BlockOut at R = 8: 0 /
 // +1.6 %); the 64 x 64 heightmap (four workgroups per CU, footprints of up to 1600 cells): -2 % at two and at four rounds;
-// a buffered step (K > 1: the apply phase and a float32 copy of the tile, nothing to take out): -22 % / -52 %.  Hence: online
-// steps only; lattice and box data from three rounds of workgroups on, cell lists from four rounds on where eight
-// workgroups share a CU.
+// a buffered step (K > 1: the apply phase and a float32 copy of the tile, nothing to take out): -22 % / -52 %.  With a second
+// group of bins on another stream the split pays a round earlier (BlockOut as two groups of 4096: 59.1 -> 60.5 M,
+// profiles/r05/s10).  Hence: online steps only; lattice and box data from two rounds of workgroups on, cell lists from four
+// rounds on where eight workgroups share a CU.
 static bool split_apply(const irbpp_env* env, int n) {
     if (env->P.stability != 0 || (env->cfg.tuning & IRBPP_TUNE_FUSED_APPLY)) return false;
     if (env->cfg.tuning & IRBPP_TUNE_SPLIT_APPLY) return true;
@@ -476,7 +479,7 @@ static bool split_apply(const irbpp_env* env, int n) {
     const int per_cu = (160 * 1024) / (env->P.lds_bytes > 0 ? env->P.lds_bytes : 1);
     if (per_cu < 8) return false;
     const bool lists = env->P.block_b == 0 && !env->P.box;
-    return n >= (lists ? 4 : 3) * 256 * 8;
+    return n >= (lists ? 4 : 2) * 256 * 8;
 }
 
 static EnvKernel pick_env_kernel(const irbpp_env* env) {
@@ -886,7 +889,18 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name) {
     if (!env || !lds_bytes || !kernel_name) return IRBPP_ERR_ARG;
     *lds_bytes = env->P.lds_bytes;
-    *kernel_name = pick_env_kernel(env).name;
+    // the kernels of a step over all bins of this environment, in launch order behind the transition kernel's build
+    const int n = env->P.N, spec = pick_spec(env);
+    const bool lattice = env->P.block_b > 0 || env->P.box;
+    const bool wave_emit = lattice && !(env->cfg.tuning & IRBPP_TUNE_BLOCK_EMIT) && (n >= 2048 || (env->cfg.tuning & IRBPP_TUNE_WAVE_EMIT));
+    const int cpw = pick_trace_cpw(env, n);
+    char emit[48];
+    snprintf(emit, sizeof emit, "%s%s", wave_emit ? "irbpp_emit_wave_kernel" : "irbpp_emit_kernel",
+             spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : "");
+    snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s + irbpp_trace_kernel%s + irbpp_polygon_kernel + %s%s",
+             pick_env_kernel(env).name, cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
+             split_apply(env, n) ? " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)" : "");
+    *kernel_name = env->kernel_names;
     return IRBPP_OK;
 }
 

@@ -264,7 +264,7 @@ class GpuPackingEnv(object):
         """Tooling: (LDS bytes per workgroup, name of the transition-kernel build that launches)."""
         lds, name = C.c_int32(0), C.c_char_p()
         _lib.check(self.lib.irbpp_debug_kernel_info(self._h, C.byref(lds), C.byref(name)), "irbpp_debug_kernel_info")
-        return lds.value, name.value.decode() + " + irbpp_trace_kernel + irbpp_polygon_kernel + irbpp_emit_kernel"
+        return lds.value, name.value.decode()
 
     def enable_kernel_timing(self, capacity: int, every: int = 1) -> None:
         """Tooling: bracket the kernels of the next transitions with HIP events on their stream, ``capacity`` pairs
@@ -345,9 +345,15 @@ class GroupedPackingEnv(object):
         seq_of = (lambda g: sequences[g * self.per:(g + 1) * self.per]) if kw.get("item_stream") else (lambda g: sequences)
         self.groups = [GpuPackingEnv(shapes, seq_of(g), self.per, device=device, global_offset=global_offset + g * self.per,
                                      global_bins=total, **kw) for g in range(num_groups)]
-        # one group: the caller's current stream; several: a stream each
-        self.streams = [torch.cuda.Stream(device=self.device) for _ in range(num_groups)] if num_groups > 1 \
-            else [torch.cuda.current_stream(self.device)]
+        # one group: the caller's current stream; two: the process's pair of streams that was CHECKED to run side by side
+        # (group_stream_pair); more: a stream each from torch's pool, whose mapping onto the runtime's hardware queues is
+        # the runtime's (see groups_for)
+        if num_groups == 1:
+            self.streams = [torch.cuda.current_stream(self.device)]
+        elif num_groups == 2:
+            self.streams = list(group_stream_pair(self.device)[0])
+        else:
+            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(num_groups)]
         e = self.groups[0]
         self.obs_len, self.loc_obs_len, self.K, self.S, self.n_rot = e.obs_len, e.loc_obs_len, e.K, e.S, e.n_rot
         self.Hx, self.Hy, self.Ax, self.Ay = e.Hx, e.Hy, e.Ax, e.Ay
@@ -450,28 +456,87 @@ class GroupedPackingEnv(object):
             e.close()
 
 
-def groups_for(workload_kind: str, num_bins: int) -> int:
+_STREAM_PAIRS = {}
+
+
+def _run_side_by_side(a, b, device, cycles=1_500_000) -> bool:
+    """Do kernels on streams ``a`` and ``b`` overlap?  A spin kernel (torch.cuda._sleep) on one stream, then one on each:
+    the pair takes about as long as the single one if the streams have hardware queues of their own, twice as long if they
+    share one."""
+    import time
+
+    def timed(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(cycles)
+        for st in streams:
+            st.synchronize()
+        return time.perf_counter() - t0
+
+    timed([a, b])                                      # (first launches on a stream pay for its set-up)
+    single = min(timed([a]) for _ in range(2))
+    pair = min(timed([a, b]) for _ in range(2))
+    return pair < 1.5 * single
+
+
+def group_stream_pair(device):
+    """The two HIP streams this process steps two groups of bins on, and whether they were seen to overlap.
+
+    How the runtime maps streams onto its hardware queues depends on what the process has created before: two streams
+    fresh from torch's pool ran two groups of a 4096-bin BlockOut environment at 44.6 M steps/s in one instance and at
+    15.9 - 28 M in the next (a shared queue: every kernel of one group then waits for the other group's, profiles/r05/s10,
+    s11 -- with streams of different priority likewise).  So the pair is chosen ONCE per process and device: candidates from
+    the pool are tried against the first until a spin-kernel probe shows the two running side by side, and every
+    GroupedPackingEnv with two groups uses that pair.  -> ((stream0, stream1), overlap_seen)"""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in _STREAM_PAIRS:
+        first = torch.cuda.Stream(device=device)
+        pair, ok = None, False
+        for _ in range(12):
+            cand = torch.cuda.Stream(device=device)
+            if pair is None:
+                pair = (first, cand)
+            if _run_side_by_side(first, cand, device):
+                pair, ok = (first, cand), True
+                break
+        _STREAM_PAIRS[key] = (pair, ok)
+    return _STREAM_PAIRS[key]
+
+
+def groups_for(workload_kind: str, num_bins: int, buffered: bool = False, device=None) -> int:
     """How many independent groups of bins (GroupedPackingEnv / GpuVecEnv(num_groups=...)) a caller without a preference
-    should step ``num_bins`` bins as.  Measured on one MI355X (profiles/r04/s1, s7): the heavy transition kernels of
-    free-form data (``"general"``, ``"abc_fine"``: 128 / 400 us per launch) overlap well -- general 15.1 -> 17.8 M steps/s
-    with 2 groups at 4096 bins, abc_fine 5.6 -> 6.2 / 6.7 M with 2 / 4 groups at 2048 -- whereas a buffered BlockOut step
-    at 1024 bins is a chain of six short latency-bound kernels whose length does not depend on the number of bins:
-    groups change nothing there (10.8 / 11.0 / 6.1 M for 1 / 2 / 4 groups, the last one hit by stream-to-queue aliasing).
-    Lattice data at full width gains from four groups ONLY if the group streams get hardware queues of their own: with the
-    runtime's default of four queues they share them (BlockOut at 4096 bins: 27 M as four groups against 35 M as one), with
-    ``GPU_MAX_HW_QUEUES=8`` (irbpp_amd.use_hardware_queues, before the process initialises HIP) four groups run at 38 - 41 M
-    (profiles/r04/s42, s43) -- so the answer for lattice data is 4 from 4096 bins on when that variable says eight or more,
-    else 1.  ``value`` of bench.py stays the one-group figure."""
-    if workload_kind in ("general", "abc_fine") and num_bins >= 1024 and num_bins % 4 == 0:
-        return 4 if workload_kind == "abc_fine" else 2
-    if workload_kind not in ("general", "abc_fine") and num_bins >= 4096 and num_bins % 4 == 0:
-        try:
-            queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
-        except ValueError:
-            queues = 4
-        if queues >= 8:
-            return 4
-    return 1
+    should step ``num_bins`` bins as: **two, or one**.
+
+    A step is a chain of four or five kernels, each with a ramp and a tail, some bound by instruction issue (transition,
+    polygon), some by latency at three waves per SIMD (trace): two groups on two streams fill one group's idle issue slots
+    with the other's work -- IF the two streams have hardware queues of their own, which ``group_stream_pair`` checks once
+    per process (on a shared queue two groups run at a THIRD of one group's rate).  On the checked pair the figures repeat
+    from instance to instance and from process to process (profiles/r05/s12: 4 instances x 2 processes each; one -> two
+    groups): BlockOut 8192 bins 52.6 -> 59.3 M steps/s, 4096 bins 40.8 -> 44.6 M, 2048 bins 28.5 -> 31.5 M, free-form solids
+    4096 bins 19.5 -> 22.4 M, the 64 x 64 heightmap at 2048 bins 6.2 -> 7.16 M, a buffered environment (k = 10) at 8192 bins
+    42.4 -> 48.4 M and at 4096 bins 34.1 -> 37.8 M -- but at 1024 bins (BASELINE config 4 per GPU) 15.4 -> 11.3 - 12.1 M: a
+    chain of short latency-bound launches whose length does not depend on the number of bins.  More than two groups are not
+    recommended: their streams come from torch's pool and share hardware queues as the runtime sees fit (BlockOut 8192 bins
+    as four groups: 43.7 / 30 M); ``irbpp_amd.use_hardware_queues`` remains for callers who manage their own streams.
+
+    ``workload_kind``: "general" / "abc_fine" (free-form cell lists, the generic overlap path) or anything else (lattice /
+    box data); ``buffered``: bufferSize > 1 (also recognised from a kind that ends in "_k<digits>"); ``device``: if given,
+    the answer is 1 unless this process's pair of streams on that device was seen to overlap."""
+    import re
+    if num_bins % 2 != 0:
+        return 1
+    if buffered or re.search(r"_k\d+$", workload_kind):
+        want = 2 if num_bins >= 4096 else 1
+    elif workload_kind in ("general", "abc_fine"):
+        want = 2 if num_bins >= 1024 else 1
+    else:
+        want = 2 if num_bins >= 2048 else 1
+    if want == 2 and device is not None and not group_stream_pair(device)[1]:
+        return 1
+    return want
 
 
 class _Infos(Sequence):
@@ -521,7 +586,8 @@ class GpuVecEnv(object):
             generic = probe.lib.irbpp_overlap_path(probe._h) == 3
             fine = probe.Hx * probe.Hy > 32 * 32
             probe.close()
-            self.num_groups = groups_for(("abc_fine" if fine else "general") if generic else "lattice", num_envs)
+            self.num_groups = groups_for(("abc_fine" if fine else "general") if generic else "lattice", num_envs,
+                                         buffered=int(env_kw.get("bufferSize", 1)) > 1, device=device)
         if self.num_groups > 1:
             self.env = GroupedPackingEnv(shapes, sequences, num_envs, self.num_groups, device=device, **env_kw)
         else:

@@ -276,3 +276,10 @@ def test_num_groups_zero_lets_the_library_choose():
     lat = GpuVecEnv(blk, synthetic.make_sequences(blk.n_shapes, 64, 150, seed=5), 1024, device=DEV, num_groups=0)
     assert lat.num_groups == 1
     lat.close()
+    from irbpp_amd.vec_env import group_stream_pair
+    pair, seen = group_stream_pair(DEV)
+    lat = GpuVecEnv(blk, synthetic.make_sequences(blk.n_shapes, 64, 150, seed=5), 4096, device=DEV, num_groups=0)
+    assert lat.num_groups == (2 if seen else 1)             # two groups only on a pair of streams that was seen to overlap
+    if seen:
+        assert list(lat.env.streams) == list(pair)          # ... the process's one checked pair
+    lat.close()

@@ -14,16 +14,17 @@ def test_use_hardware_queues_sets_the_runtime_variable_once(monkeypatch):
     monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
 
 
-def test_groups_for_lattice_data_depends_on_the_hardware_queues(monkeypatch):
-    """vec_env.groups_for: free-form data as 2 / 4 groups; lattice data as four groups only from 4096 bins on and only when
-    the runtime was asked for eight hardware queues (with four the group streams share queues: profiles/r04/s42)."""
+def test_groups_for_recommends_two_groups_or_one(monkeypatch):
+    """vec_env.groups_for: two groups (two consecutive streams always get hardware queues of their own: profiles/r05/s9) where
+    that was measured to pay, one otherwise; never four, and nothing read from the process environment."""
     from irbpp_amd.vec_env import groups_for
-    monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
-    assert groups_for("general", 4096) == 2 and groups_for("abc_fine", 2048) == 4 and groups_for("general", 512) == 1
-    assert groups_for("lattice", 4096) == 1 and groups_for("blockout_k10", 8192) == 1
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "8")
-    assert groups_for("lattice", 4096) == 4 and groups_for("blockout", 8192) == 4
-    assert groups_for("lattice", 1024) == 1 and groups_for("lattice", 4098) == 1
-    assert groups_for("general", 4096) == 2
-    monkeypatch.setenv("GPU_MAX_HW_QUEUES", "not a number")
-    assert groups_for("lattice", 4096) == 1
+    for queues in (None, "4", "8"):
+        if queues is None:
+            monkeypatch.delenv("GPU_MAX_HW_QUEUES", raising=False)
+        else:
+            monkeypatch.setenv("GPU_MAX_HW_QUEUES", queues)
+        assert groups_for("general", 4096) == 2 and groups_for("abc_fine", 2048) == 2 and groups_for("general", 512) == 1
+        assert groups_for("lattice", 4096) == 2 and groups_for("blockout", 8192) == 2 and groups_for("cube", 8192) == 2
+        assert groups_for("lattice", 2048) == 2 and groups_for("lattice", 1024) == 1 and groups_for("lattice", 4097) == 1
+        assert groups_for("blockout_k10", 1024) == 1 and groups_for("lattice", 2048, buffered=True) == 1
+        assert groups_for("blockout_k10", 8192) == 2 and groups_for("blockout_k10", 4096) == 2
