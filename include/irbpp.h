@@ -217,7 +217,8 @@ int irbpp_invalidate_obs_buffer(irbpp_env* env, float* obs_dev, void* stream);
  * lets a bin run more than `length` items ahead of what it has written. */
 int irbpp_stream_cursors(irbpp_env* env, int32_t* cursors_dev, int32_t set, void* stream);
 /* Row r of the stream table gets ids_dev[r][0 .. count_dev[r]) (int32[n_traj][width], device memory) at ring positions
- * (first_dev[r] + c) mod length. */
+ * (first_dev[r] + c) mod length.  Ids below -1 are stored as -1 (no item): the value -3 is the bins' own mark of a slot
+ * they have consumed. */
 int irbpp_stream_write(irbpp_env* env, const int32_t* ids_dev, const int32_t* first_dev, const int32_t* count_dev,
                        int32_t width, void* stream);
 

@@ -103,7 +103,13 @@ int raise_lds_limits() {
 
 }  // namespace
 
-static int trace_grid_cap(int N) { return N > TRACE_SMALL_GRID ? N : TRACE_SMALL_GRID; }
+// waves of the largest trace grid a launch over this environment's bins can ask for (16 candidates per wave: four waves per
+// bin), at most TRACE_SMALL_GRID of them beyond one per bin: State::w_big holds one scratch per wave of the grid (9 KB each:
+// a 1-bin probe environment allocates 37 KB, not 76 MB)
+static int trace_grid_cap(int N) {
+    const int small = 4 * N < TRACE_SMALL_GRID ? 4 * N : TRACE_SMALL_GRID;
+    return N > small ? N : small;
+}
 
 extern "C" {
 

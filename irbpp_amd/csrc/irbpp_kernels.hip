@@ -168,18 +168,24 @@ __device__ inline int trajectory_row(const Params& P, const Tables& T, int b, in
 // pointer is read from the kernarg segment where it is needed.
 struct KernArgs;
 __device__ __forceinline__ void raise_error(const State& S, int bit);
-constexpr int STREAM_CONSUMED = -3;     // stream mode: a ring slot the bin has read and the host has not rewritten yet
-__device__ inline int fetch_item(const Tables& T, const State& S, int row, int cursor) {
-    if (T.stream) cursor = (int)((uint32_t)cursor % (uint32_t)T.seq_len);
-    else if (cursor >= T.seq_len) return -1;
-    int32_t* slot = const_cast<int32_t*>(T.seq) + (long long)row * T.seq_len + cursor;
-    const int id = *slot;
-    if (T.stream) {                                   // the ring ran dry: caught at the fetch, not a refill later
+constexpr int STREAM_CONSUMED = -3;     // stream mode: a ring slot the bin has read and the host has not rewritten yet (irbpp_stream_write
+                                        // turns any id below -1 it is handed into -1, so the host cannot write this value)
+// Stream mode: the id that was read from ring slot (row, cursor) is consumed -- the slot is marked, in the item table
+// itself (Tables::seq is the bins' own rings then: every slot has one reader, the bin that owns the row, and is read once
+// per lap) -- and validated.  A slot that still carries the mark means the ring ran dry: caught at the fetch, not a refill
+// later.  One routine for the fetch and for the ids a step requested ahead of time.
+__device__ inline int consume_item(const Tables& T, const State& S, int row, int cursor, int id) {
+    if (T.stream) {
         if (id == STREAM_CONSUMED) { raise_error(S, IRBPP_DEVERR_STREAM_DRY); return -1; }
-        *slot = STREAM_CONSUMED;
+        const_cast<int32_t*>(T.seq)[(long long)row * T.seq_len + (int)((uint32_t)cursor % (uint32_t)T.seq_len)] = STREAM_CONSUMED;
     }
     if (id >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); return -1; }
     return id < 0 ? -1 : id;
+}
+__device__ inline int fetch_item(const Tables& T, const State& S, int row, int cursor) {
+    if (!T.stream && cursor >= T.seq_len) return -1;
+    const int at = T.stream ? (int)((uint32_t)cursor % (uint32_t)T.seq_len) : cursor;
+    return consume_item(T, S, row, cursor, T.seq[(long long)row * T.seq_len + at]);
 }
 
 // n / d for 0 <= n < 2^16 and the runtime grid sizes 1 <= d < 2^16, without the ~25-instruction integer
@@ -2437,14 +2443,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
                 for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];  // update_item_queue (IRcreator.py:22-24)
                 int nxt = st_next;                                    // generate_item (:325): prefetched for K == 1
                 if (nxt == -2) nxt = fetch_item(T, S, st_trow, cursor);
-                else {
-                    if (T.stream) {                                   // the prefetched slot is consumed here (see fetch_item)
-                        if (nxt == STREAM_CONSUMED) raise_error(S, IRBPP_DEVERR_STREAM_DRY);
-                        else const_cast<int32_t*>(T.seq)[(long long)st_trow * T.seq_len + (int)((uint32_t)cursor % (uint32_t)T.seq_len)] = STREAM_CONSUMED;
-                    }
-                    if (nxt >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
-                    else if (nxt < 0) nxt = -1;
-                }
+                else nxt = consume_item(T, S, st_trow, cursor, nxt);   // requested with round 2, consumed here
                 q[P.K - 1] = nxt;
                 ps->cursor = cursor + 1;
                 if (ka->io.reward) ka->io.reward[b] = reward;
@@ -2652,15 +2651,8 @@ irbpp_apply_kernel(const Params P, const Tables T, const State S, const StepIO i
             ps->item_idx += 1;
             ps->ratio_acc += vol;
             for (int i = oa; i < P.K - 1; ++i) q[i] = q[i + 1];      // update_item_queue (IRcreator.py:22-24)
-            if (nxt == -2) nxt = fetch_item(T, S, trow, cursor);     // generate_item (:325): prefetched for K == 1
-            else {
-                if (T.stream) {                                       // the prefetched slot is consumed here (see fetch_item)
-                    if (nxt == STREAM_CONSUMED) raise_error(S, IRBPP_DEVERR_STREAM_DRY);
-                    else const_cast<int32_t*>(T.seq)[(long long)trow * T.seq_len + (int)((uint32_t)cursor % (uint32_t)T.seq_len)] = STREAM_CONSUMED;
-                }
-                if (nxt >= T.n_shapes) { raise_error(S, IRBPP_DEVERR_BAD_ITEM); nxt = -1; }
-                else if (nxt < 0) nxt = -1;
-            }
+            if (nxt == -2) nxt = fetch_item(T, S, trow, cursor);     // generate_item (:325): requested with round 2 for K == 1
+            else nxt = consume_item(T, S, trow, cursor, nxt);
             q[P.K - 1] = nxt;
             ps->cursor = cursor + 1;
             if (ka->io.reward) ka->io.reward[b] = reward;
@@ -2948,7 +2940,7 @@ irbpp_stream_write_kernel(int32_t* seq, int n_traj, int seq_len, const int32_t* 
     const long long t = (long long)blockIdx.x * BLOCK + threadIdx.x;
     if (t >= (long long)n_traj * width) return;
     const int row = (int)(t / width), c = (int)(t - (long long)row * width);
-    if (c < count[row]) seq[(long long)row * seq_len + (int)((uint32_t)(first[row] + c) % (uint32_t)seq_len)] = ids[t];
+    if (c < count[row]) seq[(long long)row * seq_len + (int)((uint32_t)(first[row] + c) % (uint32_t)seq_len)] = ids[t] < -1 ? -1 : ids[t];   // (-3 is the bins' own mark)
 }
 
 extern "C" __global__ void __launch_bounds__(BLOCK)
