@@ -95,6 +95,9 @@ typedef struct {
 #define IRBPP_TUNE_BLOCK_EMIT 8192 /* emit kernel: one 256-thread workgroup per bin also for lattice / box data (default there, from 2048
                                      bins per launch on: one wave per bin, four bins per workgroup); identical results          */
 #define IRBPP_TUNE_WAVE_EMIT 16384 /* ... or the wave-per-bin form for lattice / box data whatever the size of the launch      */
+#define IRBPP_TUNE_GRAPH 32768 /* step() / get_action_candidates() replayed as HIP graphs owned by the library (one per distinct argument
+                                  set, captured at its second use) instead of launched kernel by kernel.  Off by default: slower on
+                                  ROCm 7.2 at every size measured (launch_env in irbpp_capi.hip); identical results                 */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

@@ -39,6 +39,13 @@ struct irbpp_env {
     int timing_every = 1, timing_phase = 0;   // events go around every timing_every-th transition only
     std::vector<void*> allocs;
     char kernel_names[256] = {0};          // irbpp_debug_kernel_info
+    // small launches replayed as HIP graphs (launch_env): the launches of a transition, captured once per distinct
+    // argument set on a stream of the library's own and replayed on the caller's
+    struct GraphEntry { std::vector<uint8_t> key; hipGraphExec_t exec; hipGraph_t graph; uint64_t used; };
+    std::vector<GraphEntry> graphs;
+    hipStream_t cap_stream = nullptr;
+    uint64_t graph_clock = 0, graph_replays = 0;
+    int obs_epoch = 0;                     // bumped by every (un)registration of an observation buffer: part of a graph's key
 };
 
 #define HIP_TRY(expr)                                   \
@@ -234,6 +241,8 @@ int irbpp_destroy(irbpp_env* env) {
     hipSetDevice(env->cfg.device);
     for (void* p : env->allocs) hipFree(p);
     for (hipEvent_t e : env->timing) hipEventDestroy(e);
+    for (auto& g : env->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+    if (env->cap_stream) hipStreamDestroy(env->cap_stream);
     delete env;
     return IRBPP_OK;
 }
@@ -611,6 +620,19 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
 // dropped: the eight cross-queue dependencies per step cost more than the overlapped launch tails give back,
 // 18.5 -> 11.8 M steps/s.  Overlap across sub-batches is offered one level up instead, where no join is needed:
 // vec_env.GroupedPackingEnv steps independent groups of bins on their own streams.)
+// Transitions as HIP graphs -- OPT-IN (IRBPP_TUNE_GRAPH), because on this runtime (ROCm 7.2) it LOSES at every size measured:
+// a buffered placement at 1024 bins 15.3 -> 13.1 M steps/s, BlockOut online 1024 / 2048 bins 17.8 -> 16.4 / 28.4 -> 26.2 M,
+// the 64 x 64 heightmap at 2048 bins 6.34 -> 6.22 M, 8192 BlockOut bins as two groups 60.8 -> 58.8 M (profiles/r05/s14): what
+// hipGraphLaunch puts between the kernel nodes of a linear chain costs more than the host's launch calls and the dispatch
+// gaps it removes (~7 us of a 66 us placement).  The mechanism stays for runtimes where that changes: the chain of a
+// transition is captured ONCE per distinct argument set (mode, every pointer and flag of StepIO, the host-side state the
+// launch code branches on) on a stream of the library's own and replayed on the caller's stream with one hipGraphLaunch.
+// An argument set is captured when it is seen the SECOND time: a caller that hands over a fresh observation tensor every
+// step never repeats one and is launched directly.  Everything issued while the caller's stream is itself being captured
+// is launched directly too (into the caller's capture).
+constexpr int GRAPH_CACHE = 24;
+static bool graph_wanted(const irbpp_env* env, int) { return (env->cfg.tuning & IRBPP_TUNE_GRAPH) != 0; }
+
 static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int grid = 0) {
     if (grid <= 0) grid = env->P.N;
     io.phase_cycles = env->phase_cycles;
@@ -619,7 +641,62 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int gri
     const size_t slot = env->timing_next;
     if (pairs && (env->timing_phase++ % env->timing_every) != 0) pairs = 0;       // not a sampled launch
     if (pairs) hipEventRecord(env->timing[2 * slot], st);
-    launch_group(env, io, mode, st, 0, grid);
+    bool launched = false;
+    if (graph_wanted(env, grid) && (mode == MODE_STEP || mode == MODE_CANDS)) {
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) cs = hipStreamCaptureStatusActive;
+        if (cs == hipStreamCaptureStatusNone) {
+            // everything launch_group reads: the arguments and the host-side state it branches on
+            struct Key { StepIO io; int mode, grid, heavy_turn, obs_epoch; int32_t* auto_actions; } k;
+            memset(&k, 0, sizeof k);
+            k.io = io; k.mode = mode; k.grid = grid; k.heavy_turn = env->heavy_turn; k.obs_epoch = env->obs_epoch;
+            k.auto_actions = env->auto_actions;
+            const uint8_t* kb = (const uint8_t*)&k;
+            irbpp_env::GraphEntry* hit = nullptr;
+            for (auto& g : env->graphs)
+                if (g.key.size() == sizeof k && memcmp(g.key.data(), kb, sizeof k) == 0) { hit = &g; break; }
+            if (hit == nullptr) {                        // first sight: remember it, launch directly
+                if (env->graphs.size() >= (size_t)GRAPH_CACHE) {       // (the least recently used entry makes room)
+                    size_t lru = 0;
+                    for (size_t i = 1; i < env->graphs.size(); ++i) if (env->graphs[i].used < env->graphs[lru].used) lru = i;
+                    if (env->graphs[lru].exec) hipGraphExecDestroy(env->graphs[lru].exec);
+                    if (env->graphs[lru].graph) hipGraphDestroy(env->graphs[lru].graph);
+                    env->graphs.erase(env->graphs.begin() + lru);
+                }
+                env->graphs.push_back({std::vector<uint8_t>(kb, kb + sizeof k), nullptr, nullptr, ++env->graph_clock});
+            } else {
+                hit->used = ++env->graph_clock;
+                const int turn_before = env->heavy_turn;
+                if (hit->exec == nullptr) {              // second sight: capture the chain on the library's own stream
+                    if (env->cap_stream == nullptr && hipStreamCreateWithFlags(&env->cap_stream, hipStreamNonBlocking) != hipSuccess)
+                        env->cap_stream = nullptr;
+                    if (env->cap_stream != nullptr && hipStreamBeginCapture(env->cap_stream, hipStreamCaptureModeRelaxed) == hipSuccess) {
+                        launch_group(env, io, mode, env->cap_stream, 0, grid);
+                        hipGraph_t graph = nullptr;
+                        if (hipStreamEndCapture(env->cap_stream, &graph) == hipSuccess && graph != nullptr &&
+                            hipGraphInstantiate(&hit->exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                            hit->graph = graph;
+                        } else {
+                            if (graph) hipGraphDestroy(graph);
+                            hit->exec = nullptr;
+                        }
+                        env->heavy_turn = turn_before;   // (the capture ran the host code of a launch; the launch itself follows)
+                        (void)hipGetLastError();
+                    }
+                }
+                if (hit->exec != nullptr && hipGraphLaunch(hit->exec, st) == hipSuccess) {
+                    launched = true;
+                    ++env->graph_replays;
+                    // the host-side state a direct launch would have advanced
+                    const bool observes = mode == MODE_CANDS || (mode == MODE_STEP && env->P.K == 1);
+                    const bool heavy_first = env->P.split && observes && env->P.heavy_cap > 0 && env->P.block_b == 0 && !env->P.box &&
+                                             io.bin_list == nullptr && !(env->cfg.tuning & IRBPP_TUNE_NO_HEAVY_FIRST);
+                    if (heavy_first) env->heavy_turn ^= 1;
+                }
+            }
+        }
+    }
+    if (!launched) launch_group(env, io, mode, st, 0, grid);
     if (pairs) {
         hipEventRecord(env->timing[2 * slot + 1], st);
         env->timing_next = (slot + 1) % pairs;
@@ -719,6 +796,7 @@ int irbpp_set_auto_policy(irbpp_env* env, int32_t* actions_dev) {
 int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev) {
     if (!env || !obs_dev) return IRBPP_ERR_ARG;
     HIP_TRY(hipSetDevice(env->cfg.device));
+    env->obs_epoch++;
     for (auto& rb : env->obs_buffers)
         if (rb.first == obs_dev) {           // registered again (e.g. a new allocation at an old address): contents unknown
             HIP_TRY(hipMemset(rb.second, 0xFF, (size_t)env->P.N * sizeof(int32_t)));
@@ -739,6 +817,7 @@ int irbpp_register_obs_buffer(irbpp_env* env, float* obs_dev) {
 
 int irbpp_unregister_obs_buffer(irbpp_env* env, float* obs_dev) {
     if (!env || !obs_dev) return IRBPP_ERR_ARG;
+    env->obs_epoch++;
     for (auto& rb : env->obs_buffers)
         if (rb.first == obs_dev) { rb.first = nullptr; return IRBPP_OK; }
     return IRBPP_ERR_ARG;

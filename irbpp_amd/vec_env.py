@@ -130,8 +130,9 @@ class GpuPackingEnv(object):
             self._h, n, f64(ext), f64(vol), dims.ctypes.data_as(_lib.c_i32_p),
             offs.ctypes.data_as(C.POINTER(C.c_int64)), pos, f64(T), f64(B), f64(mH), f64(mB)), "irbpp_load_shapes")
 
-    def _stream(self):
-        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+    def _stream(self, stream=None):
+        """The HIP stream a call is issued on: ``stream`` (a torch.cuda.Stream) or the current one."""
+        return C.c_void_p((stream if stream is not None else torch.cuda.current_stream(self.device)).cuda_stream)
 
     # -- transitions -------------------------------------------------------------------------
     def reset(self) -> torch.Tensor:
@@ -148,21 +149,22 @@ class GpuPackingEnv(object):
                    "irbpp_reset_bins")
         return obs
 
-    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None):
+    def step(self, actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, stream=None):
         """actions: int32[N] on the device.  Returns (obs, reward f64[N], done u8[N]) device tensors;
-        the reward/done tensors are views of buffers overwritten by the next step."""
+        the reward/done tensors are views of buffers overwritten by the next step.  ``stream``: issue on this
+        torch.cuda.Stream instead of the current one (only together with ``obs_out``: nothing is allocated then)."""
         assert actions.dtype == torch.int32 and actions.is_cuda and actions.numel() == self.num_bins
         obs = obs_out if obs_out is not None else \
             torch.empty((self.num_bins, self.obs_len), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.irbpp_step(self._h, _ptr(actions), _ptr(obs), C.byref(self._step_out), self._stream()),
+        _lib.check(self.lib.irbpp_step(self._h, _ptr(actions), _ptr(obs), C.byref(self._step_out), self._stream(stream)),
                    "irbpp_step")
         return obs, self._out_f64[0], self._out_done
 
-    def get_action_candidates(self, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def get_action_candidates(self, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
         assert order_actions.dtype == torch.int32 and order_actions.is_cuda
         obs = obs_out if obs_out is not None else \
             torch.empty((self.num_bins, self.loc_obs_len), dtype=torch.float32, device=self.device)
-        _lib.check(self.lib.irbpp_get_action_candidates(self._h, _ptr(order_actions), _ptr(obs), self._stream()),
+        _lib.check(self.lib.irbpp_get_action_candidates(self._h, _ptr(order_actions), _ptr(obs), self._stream(stream)),
                    "irbpp_get_action_candidates")
         return obs
 
@@ -387,6 +389,8 @@ class GroupedPackingEnv(object):
         that the tensors are long-lived and were produced on group g's own stream (the fused policy,
         ``policy_minz_group``): no cross-stream dependency is inserted."""
         self._enter(g, actions, obs_out, wait=wait)
+        if obs_out is not None:              # nothing to allocate: straight onto the group's stream (the context manager
+            return self.groups[g].step(actions, obs_out=obs_out, stream=self.streams[g])     # costs the host ~10 us per call)
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].step(actions, obs_out=obs_out)
 
@@ -398,6 +402,8 @@ class GroupedPackingEnv(object):
     def get_action_candidates_group(self, g: int, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None,
                                     wait: bool = True):
         self._enter(g, order_actions, obs_out, wait=wait)
+        if obs_out is not None:
+            return self.groups[g].get_action_candidates(order_actions, obs_out=obs_out, stream=self.streams[g])
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].get_action_candidates(order_actions, obs_out=obs_out)
 

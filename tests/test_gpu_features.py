@@ -241,7 +241,7 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     shapes, seqs, kw = make_workload(workload)
     k = int(kw.get("bufferSize", 1))
     flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
-             _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT]
+             _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT]
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
@@ -249,11 +249,15 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)
+    bufs = [[torch.empty_like(obs[0]), torch.empty_like(obs[0])] for _ in envs]
+    lbufs = [torch.empty((n, e.loc_obs_len), dtype=torch.float32, device=DEV) for e in envs]
+    abufs = [torch.empty((n,), dtype=torch.int32, device=DEV) for _ in envs]
+    slots = [torch.full((n,), j, dtype=torch.int32, device=DEV) for j in range(max(k, 1))]
     done_total = 0
     for t in range(steps):
         if k > 1:
-            slot = torch.full((n,), t % k, dtype=torch.int32, device=DEV)
-            loc = [e.get_action_candidates(slot) for e in envs]
+            slot = slots[t % k]
+            loc = [e.get_action_candidates(slot, obs_out=lbufs[j]) for j, e in enumerate(envs)]
             assert all(torch.equal(loc[0], x) for x in loc[1:]), f"location observation, step {t}"
             act = envs[0].policy_minz(loc[0])
         else:
@@ -262,7 +266,11 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
             rnd = torch.randint(0, S, (n,), generator=gen, dtype=torch.int32).to(DEV)
             pick = (torch.arange(n, device=DEV) % 4) == (t % 4)
             act = torch.where(pick, rnd, act)
-        res = [e.step(act) for e in envs]
+        # (ping-pong observation buffers: the environment with IRBPP_TUNE_GRAPH sees every argument set again and replays
+        # its steps as HIP graphs from the third step on)
+        for ab in abufs:
+            ab.copy_(act)
+        res = [e.step(abufs[j], obs_out=bufs[j][t & 1]) for j, e in enumerate(envs)]
         info = [e.step_info_host() for e in envs]
         for j in range(1, len(envs)):
             for x, y in zip(res[0], res[j]):
