@@ -851,6 +851,8 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
         feeder = itemgen.StreamFeeder(itemgen.streams_for_args(args, args.num_processes),
                                       ring_len=int(getattr(args, "item_ring", 4096)), buffer_size=args.bufferSize)
         sequences, kw["item_stream"] = feeder.initial, 1
+    if getattr(args, "tuning", 0):           # (not a reference argument: irbpp_config::tuning, A/B runs and tests)
+        kw["tuning"] = int(args.tuning)
     # (args.num_groups is not a reference argument: > 1 steps the envs as that many independent groups on their own HIP
     # streams, item streams included -- GroupedPackingEnv)
     # args.obs_ring (not a reference argument either): 0 (default here) = every call returns a fresh observation tensor, the

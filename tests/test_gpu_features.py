@@ -50,9 +50,10 @@ def test_hierarchical_evaluation_matches_the_reference_golden(golden_dir, tmp_pa
     assert abs(out["avg_reward"] - float(g["avg_reward"])) < 1e-9 and out["avg_length"] == float(g["avg_length"])
 
 
-@pytest.mark.parametrize("k,sample,groups", [(1, "instance", 1), (3, "instance", 1), (1, "category", 1), (2, "pose", 1),
-                                             (1, "instance", 3), (3, "category", 2)])
-def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample, groups):
+@pytest.mark.parametrize("k,sample,groups,tuning", [(1, "instance", 1, 0), (3, "instance", 1, 0), (1, "category", 1, 0), (2, "pose", 1, 0),
+                                                    (1, "instance", 3, 0), (3, "category", 2, 0),
+                                                    (1, "instance", 1, _lib.TUNE_SPLIT_APPLY), (2, "pose", 2, _lib.TUNE_SPLIT_APPLY)])
+def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample, groups, tuning):
     """make_vec_envs(args) with nothing but the reference's namespace (no args.sequences): every environment draws its
     items like the reference's worker of that rank (RandomInstanceCreator / RandomCateCreator / RandomItemCreator on
     np.random seeded seed + rank; IRcreator.py:26-72, envs.py:41).  The oracle side restates the creators on numpy's
@@ -69,7 +70,8 @@ def test_make_vec_envs_trains_on_the_reference_item_streams(k, sample, groups):
     args = types.SimpleNamespace(
         num_processes=n, device=0, seed=seed, shapes=sh, dicPath=dic, dataSample=sample, resolutionA=0.02,
         resolutionH=0.01, resolutionZ=0.01, bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S,
-        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=64, num_groups=groups)
+        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=64, num_groups=groups, tuning=tuning)   # (tuning: the ring's
+                                                               # consume-and-mark in irbpp_apply_kernel as well as in the transition kernel)
     envs, spaces, obs_len = make_vec_envs(args, "./logs/runinfo", True)
     assert envs.num_groups == groups              # grouped stepping: group g is fed rows [g*per, (g+1)*per) on its own stream
     envs.candidates_on_device = True

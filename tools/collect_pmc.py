@@ -5,8 +5,8 @@ the kernel sources they were taken on (bench.py quotes them only while that hash
     python tools/collect_pmc.py <dir with fetch/ write/ sq/ [sq2/] sub-directories> <workload> <bins> [<git rev>]
 
 Each sub-directory holds the counter_collection.csv of ONE pass (MI355X_MICROARCH.md: FETCH_SIZE and
-WRITE_SIZE do not fit one pass; SQ has eight slots).  A step is four kernels (transition, trace, polygon,
-emit), each launched once per step: per-step figures are sums of the kernels' per-launch averages over the
+WRITE_SIZE do not fit one pass; SQ has eight slots).  A step is a chain of kernels ([apply,] transition, trace,
+polygon, emit), each launched once per step of ONE group of bins (the passes run bench.py --groups 1): per-step figures are sums of the kernels' per-launch averages over the
 second half of the run (prefill and warm-up dropped).  HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (KB -> bytes):
 gfx950's FETCH_SIZE reports half the bytes of wide coalesced reads (same guide, HBM section); the emit kernel,
 whose reads and writes per bin are known exactly, is kept as the calibration of both factors."""
@@ -23,7 +23,8 @@ from irbpp_amd.build import source_hash  # noqa: E402
 
 src, workload, bins = sys.argv[1], sys.argv[2], int(sys.argv[3])
 rev = sys.argv[4] if len(sys.argv) > 4 else ""
-STEP_KERNELS = ("irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel")
+STEP_KERNELS = ("irbpp_apply_kernel", "irbpp_env_kernel", "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel",
+                "irbpp_emit_wave_kernel")
 
 
 def agg(sub):
@@ -67,11 +68,12 @@ entry = {"bins": bins, "kernels": per_kernel, "hbm_bytes_per_launch": total, "hb
          "note": "hbm_bytes_per_launch = one step = one launch of each of the listed kernels",
          "command": "rocprofv3 --pmc <counters> --output-format csv -- python bench.py --bins %d --workload %s "
                     "--no-cpu-baseline --no-extra (each counter group in its own pass)" % (bins, workload)}
-if "irbpp_emit_kernel" in per_kernel and len(sys.argv) > 5:
+emit_name = next((k for k in per_kernel if k.startswith("irbpp_emit")), None)
+if emit_name is not None and len(sys.argv) > 5:
     r_ac, sel = int(sys.argv[5]), 500
     true_r, true_w = bins * (r_ac * 8 + r_ac // 16 * 4 + 32), bins * (5 * sel * 4 + sel * 4 + 4)
-    e = per_kernel["irbpp_emit_kernel"]
-    entry["calibration"] = {"kernel": "irbpp_emit_kernel", "true_read_bytes": true_r, "true_write_bytes": true_w,
+    e = per_kernel[emit_name]
+    entry["calibration"] = {"kernel": emit_name, "true_read_bytes": true_r, "true_write_bytes": true_w,
                             "two_x_FETCH_SIZE_over_true_reads": 2 * e["FETCH_SIZE_KB_avg"] * 1024 / true_r,
                             "WRITE_SIZE_over_true_writes": e["WRITE_SIZE_KB_avg"] * 1024 / true_w}
 sq = collections.defaultdict(dict)
