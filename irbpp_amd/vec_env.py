@@ -352,10 +352,8 @@ class GroupedPackingEnv(object):
         # the runtime's (see groups_for)
         if num_groups == 1:
             self.streams = [torch.cuda.current_stream(self.device)]
-        elif num_groups == 2:
-            self.streams = list(group_stream_pair(self.device)[0])
         else:
-            self.streams = [torch.cuda.Stream(device=self.device) for _ in range(num_groups)]
+            self.streams = group_streams(self.device, num_groups)[0]
         e = self.groups[0]
         self.obs_len, self.loc_obs_len, self.K, self.S, self.n_rot = e.obs_len, e.loc_obs_len, e.K, e.S, e.n_rot
         self.Hx, self.Hy, self.Ax, self.Ay = e.Hx, e.Hy, e.Ax, e.Ay
@@ -487,29 +485,37 @@ def _run_side_by_side(a, b, device, cycles=1_500_000) -> bool:
     return pair < 1.5 * single
 
 
-def group_stream_pair(device):
-    """The two HIP streams this process steps two groups of bins on, and whether they were seen to overlap.
+def group_streams(device, count: int = 2):
+    """``count`` HIP streams this process steps that many groups of bins on, and whether they were all seen to overlap with
+    each other.
 
     How the runtime maps streams onto its hardware queues depends on what the process has created before: two streams
     fresh from torch's pool ran two groups of a 4096-bin BlockOut environment at 44.6 M steps/s in one instance and at
     15.9 - 28 M in the next (a shared queue: every kernel of one group then waits for the other group's, profiles/r05/s10,
-    s11 -- with streams of different priority likewise).  So the pair is chosen ONCE per process and device: candidates from
-    the pool are tried against the first until a spin-kernel probe shows the two running side by side, and every
-    GroupedPackingEnv with two groups uses that pair.  -> ((stream0, stream1), overlap_seen)"""
+    s11 -- with streams of different priority likewise).  So the streams are chosen ONCE per process and device: candidates
+    from the pool are tried against the ones already chosen until a spin-kernel probe shows them running side by side with
+    every one of those, and every GroupedPackingEnv uses the first ``count`` of that list.  The runtime's default of four
+    hardware queues bounds the list at four.  -> (streams, overlap_seen)"""
     device = torch.device(device)
     key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-    if key not in _STREAM_PAIRS:
-        first = torch.cuda.Stream(device=device)
-        pair, ok = None, False
-        for _ in range(12):
-            cand = torch.cuda.Stream(device=device)
-            if pair is None:
-                pair = (first, cand)
-            if _run_side_by_side(first, cand, device):
-                pair, ok = (first, cand), True
-                break
-        _STREAM_PAIRS[key] = (pair, ok)
-    return _STREAM_PAIRS[key]
+    chosen, tried = _STREAM_PAIRS.setdefault(key, ([], [0]))
+    if not chosen:
+        chosen.append(torch.cuda.Stream(device=device))
+    while len(chosen) < count and tried[0] < 24:
+        cand = torch.cuda.Stream(device=device)
+        tried[0] += 1
+        if all(_run_side_by_side(st, cand, device) for st in chosen):
+            chosen.append(cand)
+    if len(chosen) >= count:
+        return list(chosen[:count]), True
+    extra = [torch.cuda.Stream(device=device) for _ in range(count - len(chosen))]      # (no guarantee for these)
+    return list(chosen) + extra, False
+
+
+def group_stream_pair(device):
+    """group_streams(device, 2) as ((stream0, stream1), overlap_seen)."""
+    streams, ok = group_streams(device, 2)
+    return (streams[0], streams[1]), ok
 
 
 def groups_for(workload_kind: str, num_bins: int, buffered: bool = False, device=None) -> int:
