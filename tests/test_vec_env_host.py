@@ -26,5 +26,5 @@ def test_groups_for_recommends_two_groups_or_one(monkeypatch):
         assert groups_for("general", 4096) == 2 and groups_for("abc_fine", 2048) == 2 and groups_for("general", 512) == 1
         assert groups_for("lattice", 4096) == 2 and groups_for("blockout", 8192) == 2 and groups_for("cube", 8192) == 2
         assert groups_for("lattice", 2048) == 2 and groups_for("lattice", 1024) == 1 and groups_for("lattice", 4097) == 1
-        assert groups_for("blockout_k10", 1024) == 1 and groups_for("lattice", 2048, buffered=True) == 1
-        assert groups_for("blockout_k10", 8192) == 2 and groups_for("blockout_k10", 4096) == 2
+        assert groups_for("blockout_k10", 1024) == 1 and groups_for("lattice", 1024, buffered=True) == 1
+        assert groups_for("blockout_k10", 8192) == 2 and groups_for("blockout_k10", 2048) == 2
