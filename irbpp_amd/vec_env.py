@@ -468,6 +468,8 @@ def _run_side_by_side(a, b, device, cycles=1_500_000) -> bool:
     the pair takes about as long as the single one if the streams have hardware queues of their own, twice as long if they
     share one."""
     import time
+    if not hasattr(torch.cuda, "_sleep"):              # (no spin kernel in this torch: nothing can be checked)
+        return False
 
     def timed(streams):
         torch.cuda.synchronize(device)
