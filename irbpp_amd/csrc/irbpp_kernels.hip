@@ -62,12 +62,18 @@ __device__ __forceinline__ double round6_scaled(double x) { return rint(x * 1e6)
 // (fmod's result is always representable, so fma(-q, b, |a|) is exact for the right q).
 __device__ __forceinline__ int np_floor_divide_int(double a, double b, double inv_b) {
     const double x = fabs(a);
-    double q = trunc(x * inv_b);
-    double r = fma(-q, b, x);
-    if (r < 0.0) { q -= 1.0; r = fma(-q, b, x); }
-    else if (r >= b) { q += 1.0; r = fma(-q, b, x); }
-    if (!(a < 0.0)) return (int)q;
-    return r == 0.0 ? -(int)q : -(int)q - 1;
+    const double q0 = trunc(x * inv_b);
+    const double r0 = fma(-q0, b, x);
+    // the guess is off by at most one either way: a remainder below 0 -> one less, at or above b -> one more
+    int q = (int)q0 + (r0 >= b ? 1 : 0) - (r0 < 0.0 ? 1 : 0);
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__ballot(a < 0.0) == 0ull) return q;                 // (wave-uniform: placement heights are practically never negative,
+#endif                                                       //  and the sign's share -- a second exact remainder -- was two thirds of this routine)
+    if (a < 0.0) {
+        const double r = fma(-(double)q, b, x);              // the exact remainder of the corrected quotient
+        q = r == 0.0 ? -q : -q - 1;
+    }
+    return q;
 }
 
 // wave64 inclusive scans on the DPP network (no LDS round trips): prefix inside each row of 16 lanes by four
@@ -782,6 +788,8 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int i = tid; i < (R * AC + 3) / 4; i += BLOCK) ((uint32_t*)L.lev)[i] = 0xFFFFFFFFu;     // 255: no level
     }
     if (dense) for (int i = tid; i < R * AC; i += BLOCK) zdst[i] = 1e3;
+    int bl_first = 0, bl_total = 0;
+    Cell bl_entry = {};
     if (use_block)
     for (int rep = 0; rep < IRBPP_REPS(6); ++rep) {
         if (rep) __syncthreads();
@@ -797,6 +805,15 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             L.c2[t] = m;
         }
         __syncthreads();
+        // The item's block lists -- all rotations, contiguous in the table, a few dozen 16-byte entries -- are requested now, a
+        // thread per entry: they arrive during the grid's second step and go to LDS behind it (the bytes of c2, dead by then),
+        // where the rotation loops read them with ONE broadcast ds_read_b128 per entry instead of three v_readlane.
+        if (rep == 0 && item >= 0) {
+            const ShapeRot* sa = (const ShapeRot*)srw;
+            bl_first = __builtin_amdgcn_readfirstlane(sa->oblk);
+            bl_total = __builtin_amdgcn_readfirstlane(sa[R - 1].oblk) + __builtin_amdgcn_readfirstlane(sa[R - 1].nblk) - bl_first;
+            if (bl_total <= AC / 2 && tid < bl_total) bl_entry = T.blkcell[bl_first + tid];
+        }
 #pragma unroll 1
         for (int t = tid; t < P.mb_h * P.mb_w; t += BLOCK) {
             const int pi = fdiv(t, P.mb_w, P.mg_mbw), pj = t - pi * P.mb_w;
@@ -808,6 +825,17 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         }
     }
     __syncthreads();
+    const bool bl_lds = use_block && item >= 0 && bl_total <= AC / 2;        // (block-uniform)
+    typedef int32_t bl_words __attribute__((ext_vector_type(4)));
+    bl_words* const bl = (bl_words*)L.c2;                                    // [bl_total] (bottom height, byte offset in the block-max grid)
+    if (bl_lds) {
+        if (tid < bl_total) {
+            bl_words w;
+            w.x = __double2loint(bl_entry.v); w.y = __double2hiint(bl_entry.v); w.z = bl_entry.ij * 8; w.w = 0;
+            bl[tid] = w;
+        }
+        __syncthreads();
+    }
 
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int my_valid = 0;
@@ -858,6 +886,44 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // the block-max grid, instead of this chain of prefetches, was measured: 28.25 vs 28.42 M steps/s, not taken.)
     int ncell_next = 0, off_next = 0;
     Cell pre = {};                                           // first cell chunk of the next rotation, in flight
+    if (bl_lds) {
+    for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        zs[r] = 1e3;
+        vs[r] = false;
+        if (r >= R) continue;
+        const ShapeRot* sp = (const ShapeRot*)srw + r;
+        const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
+        const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
+        const int ne = __builtin_amdgcn_readfirstlane(sp->nblk), e0 = __builtin_amdgcn_readfirstlane(sp->oblk) - bl_first;
+        const double ext_z_r = sp->ext_z_r;
+        const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+        if (in_range) {
+            const char* const hb = (const char*)(L.mb + X * P.mb_w + Y);
+            const bl_words* const be = bl + e0;                       // (one address for the whole wave: a broadcast read)
+            double m = has_out ? 0.0 : -1e300;
+            int u = 0;
+            for (; u + 4 <= ne; u += 4) {
+                bl_words q[4];
+                double hv[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) q[k] = be[u + k];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) hv[k] = *(const double*)(hb + q[k].z);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) m = fmax(m, hv[k] - __hiloint2double(q[k].y, q[k].x));
+            }
+            for (; u < ne; ++u) {
+                const bl_words q = be[u];
+                m = fmax(m, *(const double*)(hb + q.z) - __hiloint2double(q.y, q.x));
+            }
+            zs[r] = m;
+            vs[r] = round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
+        }
+    }
+    }
+    } else
     for (int rep = 0; rep < IRBPP_REPS(2); ++rep) {
     if (item >= 0) {
         const ShapeRot* s0 = (const ShapeRot*)srw;

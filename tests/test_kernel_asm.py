@@ -54,7 +54,7 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
     1.1 us): a build that spills more than the state the profiles were taken on fails here instead of shipping."""
     sizes = asmcheck.scratch_sizes(build.build(force=False))
     limits = {"irbpp_emit_kernel": 0, "irbpp_trace_kernel": 0, "irbpp_trace_kernel_c32": 0, "irbpp_trace_kernel_c16": 0,
-              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 0, "irbpp_env_kernel_box8": 0, "irbpp_env_kernel_generic8": 48, "irbpp_apply_kernel": 0,
+              "irbpp_polygon_kernel": 0, "irbpp_env_kernel": 12, "irbpp_env_kernel_box8": 0, "irbpp_env_kernel_generic8": 48, "irbpp_apply_kernel": 0,
               "irbpp_env_kernel_generic": 0, "irbpp_env_kernel_box": 0,
               # round 5: the builds BASELINE.json's geometries run (sizes as compile-time constants, irbpp_device.h SPEC_KEYS);
               "irbpp_env_kernel_s1": 0, "irbpp_env_kernel_s2": 0, "irbpp_env_kernel_s3": 16, "irbpp_env_kernel_s4": 0,
