@@ -512,7 +512,8 @@ def main():
             "ms_per_step": elapsed / timed_steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{workload} {'online' if k == 1 else 'buffered'} (bufferSize={k}), {bins} bins/GPU, resolutionA=0.02 "
-                                   f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy",
+                                   f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy"
+                                   + (f", stepped as {groups} groups of bins on {groups} HIP streams (vec_env.groups_for)" if groups > 1 else ""),
                        "baseline_config": a.config, "bins_per_gpu": bins, "global_bins": bins * world,
                        "parallelism": f"bins sharded x{world}", "groups_per_gpu": groups},
             "ranks": {"world_size": world, "backend": a.backend if world > 1 else None, "devices": devices,
