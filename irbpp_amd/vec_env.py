@@ -862,12 +862,13 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
     if getattr(args, "tuning", 0):           # (not a reference argument: irbpp_config::tuning, A/B runs and tests)
         kw["tuning"] = int(args.tuning)
     # (args.num_groups is not a reference argument: > 1 steps the envs as that many independent groups on their own HIP
-    # streams, item streams included -- GroupedPackingEnv)
+    # streams, item streams included -- GroupedPackingEnv; default 0 = the library's own choice, groups_for: two groups on the
+    # process's checked pair of streams from 2048 lattice / 1024 free-form environments on, one below)
     # args.obs_ring (not a reference argument either): 0 (default here) = every call returns a fresh observation tensor, the
     # reference's behaviour; 3 = the ring of library-registered buffers GpuVecEnv uses by default (+10 % step rate; an
     # observation is overwritten three calls later, which the reference's trainer never notices)
     envs = GpuVecEnv(shapes, sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
-                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 1)), obs_ring=int(getattr(args, "obs_ring", 0)), **kw)
+                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 0)), obs_ring=int(getattr(args, "obs_ring", 0)), **kw)
     return envs, [envs.observation_space, envs.action_space], envs.obs_len
 
 
