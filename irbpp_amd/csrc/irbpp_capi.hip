@@ -483,14 +483,16 @@ static int pick_spec(const irbpp_env* env) {
 // (profiles/r05/s6, placement-steps/s split vs fused): BlockOut 2048 / 4096 / 6144 / 8192 / 16384 bins -4 % / 0 / +1.7 /
 // +3.0 / +6.1 %; cube 4096 / 8192: 0 / +2.7 %; free-form solids at R = 8: 4096 -1.1 %, 8192 +0.3 % (BlockOut at R = 8: 0 /
 // +1.6 %); the 64 x 64 heightmap (four workgroups per CU, footprints of up to 1600 cells): -2 % at two and at four rounds;
-// a buffered step (K > 1: the apply phase and a float32 copy of the tile, nothing to take out): -22 % / -52 %.  With a second
+// a buffered step (K > 1: the apply phase and a float32 copy of the tile) with a WAVE per bin: -22 % / -52 % (one wave takes
+// 16 dependent round trips to copy the tile) -- with a WORKGROUP per bin (irbpp_apply_wg_kernel: wave 0 applies, all four
+// waves copy; no LDS tile, no overlap-test code in the kernel) it wins at every size, see profiles/r05/s25.  With a second
 // group of bins on another stream the split pays a round earlier (BlockOut as two groups of 4096: 59.1 -> 60.5 M,
-// profiles/r05/s10).  Hence: online steps only; lattice and box data from two rounds of workgroups on, cell lists from four
+// profiles/r05/s10).  Hence, for online steps: lattice and box data from two rounds of workgroups on, cell lists from four
 // rounds on where eight workgroups share a CU.
 static bool split_apply(const irbpp_env* env, int n) {
     if (env->P.stability != 0 || (env->cfg.tuning & IRBPP_TUNE_FUSED_APPLY)) return false;
     if (env->cfg.tuning & IRBPP_TUNE_SPLIT_APPLY) return true;
-    if (env->P.K > 1) return false;
+    if (env->P.K > 1) return true;                 // buffered: the workgroup-per-bin form (apply + order observation), at every size
     const int per_cu = (160 * 1024) / (env->P.lds_bytes > 0 ? env->P.lds_bytes : 1);
     if (per_cu < 8) return false;
     const bool lists = env->P.block_b == 0 && !env->P.box;
@@ -570,7 +572,8 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     if (heavy_first) env->heavy_turn ^= 1;
     int env_mode = mode;
     if (mode == MODE_STEP && split_apply(env, n)) {
-        hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+        if (env->P.K > 1) hipLaunchKernelGGL(irbpp_apply_wg_kernel, dim3(n), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+        else hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
         env_mode = MODE_OBSERVE;         // (a buffered step ends with the apply kernel: it wrote the order observation)
     }
     if (!(env_mode == MODE_OBSERVE && env->P.K > 1))
@@ -984,7 +987,8 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
              spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : "");
     snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s + irbpp_trace_kernel%s + irbpp_polygon_kernel + %s%s",
              pick_env_kernel(env).name, cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
-             split_apply(env, n) ? " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)" : "");
+             !split_apply(env, n) ? "" : (env->P.K > 1 ? " (step: irbpp_apply_wg_kernel alone)"
+                                                       : " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)"));
     *kernel_name = env->kernel_names;
     return IRBPP_OK;
 }

@@ -2010,8 +2010,11 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         }
         const bool spilled = __ballot(my_n > LCAP) != 0ull;           // (uniform) somebody's points lie partly in global scratch:
         if (spilled) {                                                //   written by one lane, read by others below
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            // (workgroup scope = this wave: writer and readers share the CU's L1, the release is a wait for the stores.  Until
+            // session 26 this was an AGENT-scope pair, whose release writes back the L2: paid by every wave with a border of
+            // more than 56 points, one wave in sixteen)
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         const long long t_traced = prof ? (long long)clock64() : 0;
         // ---- the closed borders go to the polygon kernel in rounds of 64 * PP contour points, borders packed back
@@ -2590,14 +2593,18 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
 // Same arithmetic, same order of operations, same outputs as the fused apply phase of env_transition (which the
 // stability proxy and IRBPP_TUNE_FUSED_APPLY still run: tests/test_gpu_features.py plays both side by side).
 // ---------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(BLOCK)
-irbpp_apply_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+// PER_WORKGROUP (buffered environments): a WORKGROUP per bin -- wave 0 applies the action exactly as below, then all four waves
+// write the order observation (the tile's 1024 ... 4096 cells as float32: one wave alone took 16 ... 64 dependent round trips
+// for it, which is what made the wave-per-bin form lose for K > 1).
+template <bool PER_WORKGROUP>
+__device__ __forceinline__ void apply_body(const Params& P, const Tables& T, const State& S, const StepIO& io) {
     const int lane = threadIdx.x & 63;
-    const int slot = (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
-    if (slot >= io.n_slots) return;                                  // (wave-uniform)
+    const int slot = PER_WORKGROUP ? (int)blockIdx.x : (int)blockIdx.x * WAVES + (int)(threadIdx.x >> 6);
+    if (slot >= io.n_slots) return;                                  // (wave-uniform; workgroup-uniform when PER_WORKGROUP)
     const int b = __builtin_amdgcn_readfirstlane(slot + io.block_off);
     double* const ghm = S.hm + (size_t)b * P.Hc;
     int32_t* const q = S.queue + (size_t)b * P.K;
+    if (!PER_WORKGROUP || threadIdx.x < 64) {
     // round 1: the action and the bin's scalars
     int a = io.actions[b];
     const BinState* ps0 = S.bs + b;
@@ -2761,22 +2768,31 @@ irbpp_apply_kernel(const Params P, const Tables T, const State S, const StepIO i
             ps->ep_len = 0;
         }
     }
+    }
     if (P.K > 1 && io.obs != nullptr) {  // buffer branch of cur_observation (binPhy.py:228-230): [k ids | heightmap]
         // (the queue was written by lane 0, heightmap cells by whichever lane held their top cell: made visible to the
-        // whole wave first)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        // whole wave / workgroup first.  WORKGROUP scope: the waves of a workgroup share their CU's L1, so the release is a
+        // wait for the stores and the acquire nothing -- an AGENT-scope release writes back the whole L2 on this chip,
+        // which made this step take a millisecond whatever the number of bins, profiles/r05/s25)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (PER_WORKGROUP) __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float* const obs = io.obs + (size_t)b * io.obs_stride;
-        for (int i = lane; i < P.K; i += 64) obs[i] = (float)q[i];
-        for (int i0 = 0; i0 < P.Hc; i0 += 8 * 64) {                  // eight loads in flight per lane
+        const int t0 = PER_WORKGROUP ? (int)threadIdx.x : lane, stride = PER_WORKGROUP ? BLOCK : 64;
+        for (int i = t0; i < P.K; i += stride) obs[i] = (float)q[i];
+        for (int i0 = 0; i0 < P.Hc; i0 += 8 * stride) {              // eight loads in flight per thread
             double v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; v[u] = ghm[i < P.Hc ? i : P.Hc - 1]; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * stride + t0; v[u] = ghm[i < P.Hc ? i : P.Hc - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) { const int i = i0 + u * 64 + lane; if (i < P.Hc) obs[P.K + i] = (float)v[u]; }
+            for (int u = 0; u < 8; ++u) { const int i = i0 + u * stride + t0; if (i < P.Hc) obs[P.K + i] = (float)v[u]; }
         }
     }
 }
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_apply_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) { apply_body<false>(P, T, S, io); }
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_apply_wg_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) { apply_body<true>(P, T, S, io); }
 
 // Launch order of an online step on the generic path: bins that are about to observe the SAME item run on the same
 // die, one after the other.  The item a bin observes next is known before the step (the next entry of its trajectory;
