@@ -572,7 +572,10 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     if (heavy_first) env->heavy_turn ^= 1;
     int env_mode = mode;
     if (mode == MODE_STEP && split_apply(env, n)) {
-        if (env->P.K > 1) hipLaunchKernelGGL(irbpp_apply_wg_kernel, dim3(n), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+        // a buffered step: a workgroup per bin at launches of fewer than 2048 bins (a wave per bin leaves most of the chip
+        // to one dependent chain per CU there: 15.7 vs 15.3 M at 1024 bins), a wave per bin from there on (every bin resident
+        // at once: 8192 bins as two groups 50.6 -> 55.2 M, 4096 bins 40.0 -> 41.6 M; profiles/r05/s27)
+        if (env->P.K > 1 && n < 2048) hipLaunchKernelGGL(irbpp_apply_wg_kernel, dim3(n), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
         else hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
         env_mode = MODE_OBSERVE;         // (a buffered step ends with the apply kernel: it wrote the order observation)
     }
@@ -987,7 +990,7 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
              spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : "");
     snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s + irbpp_trace_kernel%s + irbpp_polygon_kernel + %s%s",
              pick_env_kernel(env).name, cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
-             !split_apply(env, n) ? "" : (env->P.K > 1 ? " (step: irbpp_apply_wg_kernel alone)"
+             !split_apply(env, n) ? "" : (env->P.K > 1 ? (n < 2048 ? " (step: irbpp_apply_wg_kernel alone)" : " (step: irbpp_apply_kernel alone)")
                                                        : " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)"));
     *kernel_name = env->kernel_names;
     return IRBPP_OK;
