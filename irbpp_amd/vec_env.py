@@ -531,7 +531,7 @@ def groups_for(workload_kind: str, num_bins: int, buffered: bool = False, device
     from instance to instance and from process to process (profiles/r05/s12: 4 instances x 2 processes each; one -> two
     groups): BlockOut 8192 bins 52.6 -> 59.3 M steps/s, 4096 bins 40.8 -> 44.6 M, 2048 bins 28.5 -> 31.5 M, free-form solids
     4096 bins 19.5 -> 22.4 M, the 64 x 64 heightmap at 2048 bins 6.2 -> 7.16 M, a buffered environment (k = 10) at 8192 bins
-    42.4 -> 48.4 M, at 4096 bins 34.1 -> 37.8 M and at 2048 bins 24.5 -> 26.6 M -- but at 1024 bins (BASELINE config 4 per GPU) level at best (15.3 M): a
+    42.4 -> 48.4 M, at 4096 bins 34.1 -> 37.8 M and at 2048 bins 24.5 -> 26.6 M -- but at 1024 bins (BASELINE config 4 per GPU) level at best (15.3 M; figures of session 12, before the buffered step became an apply kernel): a
     chain of short latency-bound launches whose length does not depend on the number of bins.  More than two groups are not
     recommended: their streams come from torch's pool and share hardware queues as the runtime sees fit (BlockOut 8192 bins
     as four groups: 43.7 / 30 M); ``irbpp_amd.use_hardware_queues`` remains for callers who manage their own streams.
