@@ -2809,19 +2809,40 @@ irbpp_item_order_kernel(const Tables T, const State S, int N) {
     const int tid = threadIdx.x;
     hist[tid] = 0;
     __syncthreads();
-    auto bucket_of = [&](int b) {
-        const BinState* ps = S.bs + b;
-        int c = ps->cursor;
-        if (T.stream) c = (int)((uint32_t)c % (uint32_t)T.seq_len);
-        int item = c < T.seq_len ? T.seq[(long long)ps->traj_row * T.seq_len + c] : 0;
-        item = item < 0 ? 0 : (item >= T.n_shapes ? T.n_shapes - 1 : item);
-        return (int)(((long long)item * 1024) / T.n_shapes);
+    // A thread's bins are b = tid + k * 1024.  Each needs two DEPENDENT global reads (cursor and trajectory row, then the item):
+    // taken one bin at a time that was 16 + 8 round trips per thread at 8192 bins (40 us, 5 % of a fine-heightmap step); taken
+    // EIGHT bins at a time the loads of a chunk are in flight together: two round trips per chunk.
+    constexpr int PER = 8;
+    auto buckets_of = [&](int k0, int (&out)[PER]) {
+        int cur[PER], row[PER], item[PER];
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int bb = tid + (k0 + u) * 1024;
+            const BinState* ps = S.bs + (bb < N ? bb : 0);
+            cur[u] = ps->cursor;
+            row[u] = ps->traj_row;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            int c = cur[u];
+            if (T.stream) c = (int)((uint32_t)c % (uint32_t)T.seq_len);
+            item[u] = c < T.seq_len ? T.seq[(long long)row[u] * T.seq_len + c] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int it = item[u] < 0 ? 0 : (item[u] >= T.n_shapes ? T.n_shapes - 1 : item[u]);
+            out[u] = (int)(((long long)it * 1024) / T.n_shapes);
+        }
     };
-    int mine[4];                                     // N <= 4096 bins per launch group use registers; beyond, recompute
-    for (int k = 0, b = tid; b < N; b += 1024, ++k) {
-        const int bk = bucket_of(b);
-        if (k < 4) mine[k] = bk;
-        atomicAdd(&hist[bk], 1);
+    int mine[PER];                                   // the first chunk's buckets stay in registers (N <= 8192: all of them)
+    for (int k0 = 0; k0 * 1024 < N; k0 += PER) {
+        int bk[PER];
+        buckets_of(k0, bk);
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            if (k0 == 0) mine[u] = bk[u];
+            if (tid + (k0 + u) * 1024 < N) atomicAdd(&hist[bk[u]], 1);
+        }
     }
     __syncthreads();
     if (tid < 64) {                                  // exclusive scan of the 1024 counts by one wave
@@ -2833,10 +2854,22 @@ irbpp_item_order_kernel(const Tables T, const State S, int N) {
     }
     __syncthreads();
     const int chunk = N / NXCD;                      // N is a multiple of 8 (irbpp_capi.hip)
-    for (int k = 0, b = tid; b < N; b += 1024, ++k) {
-        const int bk = k < 4 ? mine[k] : bucket_of(b);
-        const int s_pos = atomicAdd(&start[bk], 1);
-        S.order[NXCD * (s_pos % chunk) + s_pos / chunk] = b;
+    for (int k0 = 0; k0 * 1024 < N; k0 += PER) {
+        int bk[PER];
+        if (k0 == 0) {
+#pragma unroll
+            for (int u = 0; u < PER; ++u) bk[u] = mine[u];
+        } else {
+            buckets_of(k0, bk);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int bb = tid + (k0 + u) * 1024;
+            if (bb < N) {
+                const int s_pos = atomicAdd(&start[bk[u]], 1);
+                S.order[NXCD * (s_pos % chunk) + s_pos / chunk] = bb;
+            }
+        }
     }
 }
 
