@@ -98,6 +98,9 @@ typedef struct {
 #define IRBPP_TUNE_GRAPH 32768 /* step() / get_action_candidates() replayed as HIP graphs owned by the library (one per distinct argument
                                   set, captured at its second use) instead of launched kernel by kernel.  Off by default: slower on
                                   ROCm 7.2 at every size measured (launch_env in irbpp_capi.hip); identical results                 */
+#define IRBPP_TUNE_WG512 65536 /* generic overlap path: the transition kernel with 512-thread workgroups (eight waves share a bin's tile)
+                                  whatever the LDS per bin; default: where at most four 256-thread workgroups fit a CU's LDS      */
+#define IRBPP_TUNE_NO_WG512 131072 /* ... never                                                                                 */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

@@ -100,7 +100,9 @@ int raise_lds_limits() {
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
                              (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2,
+                             (const void*)wg512::irbpp_env_kernel_s4_w512,
 #endif
+                             (const void*)wg512::irbpp_env_kernel_generic_w512,
                              (const void*)irbpp_emit_wave_kernel,
                              (const void*)irbpp_emit_kernel, (const void*)irbpp_heuristic_kernel};
     for (const void* k : kernels)
@@ -459,7 +461,7 @@ int irbpp_obs_len(const irbpp_env* env, int32_t which) {
 // The transition kernel is compiled once per overlap path (lattice blocks, solid boxes, generic cell lists), with and
 // without the 64-VGPR cap that makes eight workgroups per CU resident, plus one build that decides at run time.
 typedef void (*env_kernel_fn)(const Params, const Tables, const State, const StepIO, const int);
-struct EnvKernel { env_kernel_fn fn; const char* name; };
+struct EnvKernel { env_kernel_fn fn; const char* name; int threads = 256; };
 // Specialised builds (irbpp_device.h): SPEC index whose compile-time constants equal this environment's Params, or 0.
 static int pick_spec(const irbpp_env* env) {
 #if defined(IRBPP_NO_SPEC) || defined(IRBPP_ABLATE)
@@ -503,6 +505,16 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
     const Params& P = env->P;
     const int t = env->cfg.tuning;
     const bool lds_allows_8 = 8 * P.lds_bytes <= 160 * 1024;
+    // Generic path where the tile is so large that at most four 256-thread workgroups fit a CU's LDS (the 64 x 64 heightmap:
+    // 40 KB per bin): 512-thread workgroups, eight waves on one tile (irbpp::wg512, the second pass of irbpp_kernels.hip)
+    const bool generic = P.block_b == 0 && !P.box;
+    const bool wg512 = generic && !(t & (IRBPP_TUNE_NO_WG512 | IRBPP_TUNE_WIDE_KERNEL | IRBPP_TUNE_NARROW_KERNEL)) &&
+                       ((t & IRBPP_TUNE_WG512) || 5 * P.lds_bytes > 160 * 1024);
+#if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
+    if (wg512 && pick_spec(env) == 4) return {wg512::irbpp_env_kernel_s4_w512, "irbpp_env_kernel_s4_w512", 512};
+#endif
+    if (wg512 && (pick_spec(env) == 0 || (t & IRBPP_TUNE_WG512)))
+        return {wg512::irbpp_env_kernel_generic_w512, "irbpp_env_kernel_generic_w512", 512};
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
     switch (pick_spec(env)) {            // (a key fixes the overlap path: block_b and box are pinned fields)
         case 1: return {irbpp_env_kernel_s1, "irbpp_env_kernel_s1"};
@@ -579,8 +591,10 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         else hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
         env_mode = MODE_OBSERVE;         // (a buffered step ends with the apply kernel: it wrote the order observation)
     }
-    if (!(env_mode == MODE_OBSERVE && env->P.K > 1))
-        hipLaunchKernelGGL(pick_env_kernel(env).fn, dim3(n), dim3(256), env->P.lds_bytes, st, env->P, env->T, env->S, io, env_mode);
+    if (!(env_mode == MODE_OBSERVE && env->P.K > 1)) {
+        const EnvKernel ek = pick_env_kernel(env);
+        hipLaunchKernelGGL(ek.fn, dim3(n), dim3(ek.threads), env->P.lds_bytes, st, env->P, env->T, env->S, io, env_mode);
+    }
     if (split) {
         // the grid covers an average of up to 64 candidates per bin and strides over the chunks beyond that
         // one trace wave per 64 candidates a bin may average, two polygon waves per bin; the kernels stride over anything

@@ -29,9 +29,34 @@
 #include "irbpp_device.h"
 #include "../../include/irbpp.h"
 
-namespace irbpp {
+// This file is compiled in TWO PASSES (it includes itself at its end): pass 1 is everything, for 256-thread workgroups; pass 2
+// compiles the transition kernel's code once more inside namespace irbpp::wg512 with BLOCK = 512 -- eight waves share one
+// bin's heightmap tile -- for the data whose tile is so large (64 x 64 float64 = 32 KB) that only four 256-thread workgroups
+// fit a CU's LDS, i.e. four waves per SIMD.  Everything that does not depend on BLOCK is compiled in pass 1 only and found by
+// pass 2 in the enclosing namespace.
+#ifndef IRBPP_PASS
+#define IRBPP_PASS 1
+#endif
 
+// (a call from twice-compiled code to a twice-compiled function names its namespace: argument-dependent lookup would
+// otherwise find the pass-1 function beside the pass-2 one)
+#undef IRBPP_HERE
+#if IRBPP_PASS == 1
+#define IRBPP_HERE ::irbpp::
+#else
+#define IRBPP_HERE ::irbpp::wg512::
+#endif
+
+namespace irbpp {
+#if IRBPP_PASS == 2
+namespace wg512 {
+#endif
+
+#if IRBPP_PASS == 1
 constexpr int BLOCK = 256;
+#else
+constexpr int BLOCK = 512;                       // second pass: the transition kernel's code again for 512-thread workgroups (see the end of the file)
+#endif
 constexpr int WAVES = BLOCK / 64;
 
 // Tooling build only (tools/build_variant.sh NAME -DIRBPP_ABLATE): phase `bit` runs twice when Params.dbg_repeat has the
@@ -41,12 +66,15 @@ constexpr int WAVES = BLOCK / 64;
 // 3 emit stores, 5 tile staging, 6 block-max grid, 7 level codes + masks, 8 float32 heightmap copy, 9 level images +
 // candidate bits, 10 candidate list, 11 drop height of the placement, 12 heightmap update, 13 overlap-test set-up,
 // 14 hand-over stores.
+#ifndef IRBPP_REPS
 #ifdef IRBPP_ABLATE
 #define IRBPP_REPS(bit) (1 + ((P.dbg_repeat >> (bit)) & 1))
 #else
 #define IRBPP_REPS(bit) 1
 #endif
+#endif
 
+#if IRBPP_PASS == 1
 // np.round(x, 6): multiply, round-half-even, true-divide (numpy around for decimals > 0)
 __device__ __forceinline__ double round6(double x) { return rint(x * 1e6) / 1e6; }
 
@@ -117,6 +145,7 @@ __device__ __forceinline__ double wave_max_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+#endif  // IRBPP_PASS == 1
 __device__ inline double block_max_f64(double v, double* red) {
     v = wave_max_f64(v);
     __syncthreads();
@@ -155,6 +184,7 @@ __device__ inline int block_scan_flag(bool flag, int* red, int& total) {
     return base + pre;
 }
 
+#if IRBPP_PASS == 1
 // LoadItemCreator.generate_item (IRcreator.py:97-103) on the pre-drawn trajectories; the
 // trajectory of global bin g in its e-th episode is (traj_start + g + e*global_bins) % n_traj.
 // The 64-bit modulo runs once per episode (trajectory_row, kept in BinState::traj_row), not per item.
@@ -238,6 +268,7 @@ __device__ __forceinline__ int tile_of_linear(const Params& P, int g) {
     const int row = fdiv(g, P.Hy, P.mg_hy);
     return tile_rc(P, row, g - row * P.Hy);
 }
+#endif  // IRBPP_PASS == 1
 // Walk of the whole heightmap by the workgroup, element i = tid + k*BLOCK of the row-major map: when BLOCK is a
 // multiple of Hy the column of a thread's elements never changes and its row advances by BLOCK/Hy per trip.
 struct TileWalk {
@@ -258,6 +289,7 @@ __device__ __forceinline__ int tile_walk_index(const Params& P, const TileWalk& 
     return w.regular ? tile_row_part(P, w.row) + w.col_part : tile_of_linear(P, w.lin);
 }
 __device__ __forceinline__ void tile_walk_next(TileWalk& w) { w.lin += BLOCK; w.row += w.row_step; }
+#if IRBPP_PASS == 1
 // footprint cell `ij` (i | j << 16) of an item whose corner sits on action cell (lx, ly)
 __device__ __forceinline__ int tile_of_cell(const Params& P, int lx, int ly, int ij) {
     return tile_rc(P, lx * P.step + (ij & 0xFFFF), ly * P.step + (ij >> 16));
@@ -342,6 +374,7 @@ __device__ inline Lds carve_lds(unsigned char* smem, const Params& P) {
     return L;
 }
 
+#endif  // IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // cvTools.getConvexHullActions on the grids in LDS: L.posz = posZValid [R][AC] (1e3 where
 // invalid), `valid` given per thread/rotation through L.lev (255 = masked).  On return
@@ -475,10 +508,11 @@ __device__ inline int contour_list(const Lds& L, const uint16_t* const rows, uin
     return L.redi[10];
 }
 
+#if IRBPP_PASS == 1
 __device__ inline void contour_stage(const Params& P, const State& S, const Lds& L, long long* prof) {
     const int tid = threadIdx.x;
     constexpr int IMGS = CONTOUR_IMGS, CLIST = CONTOUR_CLIST;
-    const int ntasks = contour_tasks(P, L);
+    const int ntasks = IRBPP_HERE contour_tasks(P, L);
     uint16_t* const rows = L.img;                    // [IMGS][16] row words (bit x of word y)
     uint16_t* const cols = L.img + IMGS * 16;        // [IMGS][16] column words (bit y of word x)
     for (int base = 0; base < ntasks; base += IMGS) {
@@ -767,6 +801,7 @@ __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&
     for (int g = 0; g < G; ++g) z[g] = fmax(a0[g], a1[g]);
 }
 
+#endif  // IRBPP_PASS == 1
 template <int PATH>
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                    const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged, bool dense) {
@@ -1227,13 +1262,13 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
-    const int nvalid = overlap_test<PATH>(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged, false);
+    const int nvalid = IRBPP_HERE overlap_test<PATH>(P, T, S, io, L, b, item, debug_out, S.w_posz + (size_t)b * R * AC, sr_staged, false);
     if (debug_out) return;
     // the tile is done with: write its float32 copy and the item vector now, because the
     // contour scratch and the candidate keys reuse the tile's LDS
     if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
     for (int rep = 0; rep < IRBPP_REPS(8); ++rep)
-    for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) obs[5 * P.S + 9 + w.lin] = (float)L.hm[tile_walk_index(P, w)];
+    for (TileWalk w = IRBPP_HERE tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) obs[5 * P.S + 9 + w.lin] = (float)L.hm[tile_walk_index(P, w)];
     __syncthreads();
     stamp(io, b, 2);
 
@@ -1241,11 +1276,12 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
     // the trace and emit kernels take it from here
-    split_handover<CONTOUR_IPT>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);
+    IRBPP_HERE split_handover<(CONTOUR_IPT * 256) / BLOCK>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);    // (32 level images per batch)
     if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
         io.phase_cycles[(size_t)b * PHASE_ROW + 5] = (long long)clock64() - io.phase_cycles[(size_t)b * PHASE_ROW + 2];
 }
 
+#if IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // The `want` smallest of n <= R*AC values in (value, position) order -- np.argsort(...)[:S] with ties by
 // ascending position (binPhy.py:209-212, 217-225) -- without the n^2 ranking of everything against
@@ -1543,6 +1579,7 @@ __device__ inline void emit_observation(const Params& P, const State& S, const S
     stamp(io, b, 4);
 }
 
+#endif  // IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // Split pipeline, hand-over of one bin from the transition kernel: level images, candidate starts, the
 // vertex bits of isolated pixels and the scalars of the observation go to global memory for the trace and
@@ -1569,7 +1606,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         __syncthreads();
     }
     int ntasks = 0;
-    for (int rep = 0; rep < IRBPP_REPS(9); ++rep) { if (rep) __syncthreads(); ntasks = contour_tasks(P, L); }
+    for (int rep = 0; rep < IRBPP_REPS(9); ++rep) { if (rep) __syncthreads(); ntasks = IRBPP_HERE contour_tasks(P, L); }
     int ncand = 0, niso = 0;
     uint32_t* gi = (uint32_t*)(ka->S.w_img + (size_t)b * P.wimg * 16);
     uint8_t* gr = ka->S.w_imgrot + (size_t)b * P.wimg;
@@ -1577,8 +1614,8 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     for (int base = 0; base < ntasks; base += IMGS) {                        // one batch of level images at a time
         int batch_total = 0;
         for (int rep = 0; rep < IRBPP_REPS(9); ++rep) {
-            contour_images<IPT>(P, L, rows, base, false);
-            batch_total = contour_candidates<IPT>(P, L, rows, base, ntasks, cwords);
+            IRBPP_HERE contour_images<IPT>(P, L, rows, base, false);
+            batch_total = IRBPP_HERE contour_candidates<IPT>(P, L, rows, base, ntasks, cwords);
         }
         niso += batch_total >> 16;
         batch_total &= 0xFFFF;
@@ -1599,7 +1636,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
             int total = 0;
-            for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub, cwords);
+            for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = IRBPP_HERE contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub, cwords);
             if (tid == 0) {
                 // This die's list; should it be full (the dispatcher gave this die far more than its share of speckled
                 // bins, or the device runs in a partition mode where XCC_ID does not spread the workgroups over eight
@@ -1657,6 +1694,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
     }
 }
 
+#if IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // Split pipeline, last kernel: the observation of one bin from what the other two left in global memory.
 // ---------------------------------------------------------------------------------------
@@ -2219,6 +2257,7 @@ irbpp_polygon_kernel(const Params P, const State S
 #endif
 }
 
+#endif  // IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // The environment transition kernel: one workgroup per bin.
 // ---------------------------------------------------------------------------------------
@@ -2231,6 +2270,7 @@ template <int PATH, int SPEC, bool FUSED>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
+#if IRBPP_PASS == 1
 #ifndef IRBPP_ENV_WAVES
 #define IRBPP_ENV_WAVES 8
 #endif
@@ -2260,6 +2300,20 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_s2, PATH_BOX, 2, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s3, PATH_GENERIC, 3, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
 #endif
+
+#else
+// 512-thread builds of the generic path: the 64 x 64 heightmap's geometry as constants (SPEC 4) and the run-time build
+#define IRBPP_ENV_KERNEL_512(NAME, PATH, SPEC, ATTR)                                                                    \
+    extern "C" __global__ void __launch_bounds__(512) ATTR                                                             \
+    NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                             \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                           \
+        IRBPP_HERE env_transition<PATH, SPEC, true>(P, T, S, io, mode, smem);                                          \
+    }
+IRBPP_ENV_KERNEL_512(irbpp_env_kernel_generic_w512, PATH_GENERIC, 0, )
+#ifndef IRBPP_NO_SPEC
+IRBPP_ENV_KERNEL_512(irbpp_env_kernel_s4_w512, PATH_GENERIC, 4, )
+#endif
+#endif  // IRBPP_PASS
 
 template <int PATH, int SPEC, bool FUSED>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
@@ -2313,7 +2367,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
             __syncthreads();
         }
         for (int rep = 0; rep < IRBPP_REPS(5); ++rep)
-        for (TileWalk w = tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) L.hm[tile_walk_index(P, w)] = ghm[w.lin];
+        for (TileWalk w = IRBPP_HERE tile_walk_begin(P, tid); w.lin < P.Hc; tile_walk_next(w)) L.hm[tile_walk_index(P, w)] = ghm[w.lin];
     }
     uint32_t st_key = 0u;
     int st_next = -2;                                 // -2: not prefetched
@@ -2576,9 +2630,10 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
             for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
         }
     }
-    if (do_observe) observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
+    if (do_observe) IRBPP_HERE observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
 }
 
+#if IRBPP_PASS == 1
 // ---------------------------------------------------------------------------------------
 // PackingGame.step without its observation (binPhy.py:248-337 up to the cur_observation call): ONE WAVE per bin.
 // Applying an action is a chain of dependent global reads -- action and bin state; candidate key, the placed item's
@@ -3077,4 +3132,17 @@ irbpp_totals_kernel(const double* totals, int N, double* out) {
     }
 }
 
+#endif  // IRBPP_PASS == 1
+
+#if IRBPP_PASS == 2
+}  // namespace wg512
+#endif
 }  // namespace irbpp
+
+#if IRBPP_PASS == 1
+#undef IRBPP_PASS
+#define IRBPP_PASS 2
+#include "irbpp_kernels.hip"
+#undef IRBPP_PASS
+#define IRBPP_PASS 1
+#endif

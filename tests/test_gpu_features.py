@@ -229,13 +229,14 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
 
 
 @pytest.mark.parametrize("workload,n,steps,spec", [("blockout", 160, 130, "_s1"), ("cube", 128, 60, "_s2"), ("general", 96, 45, "_s3"),
-                                                   ("abc_fine", 64, 40, "_s4"), ("blockout_k10", 96, 120, "_s1"),
+                                                   ("abc_fine", 64, 40, "_s4_w512"), ("blockout_k10", 96, 120, "_s1"),
                                                    ("blockout_r8", 96, 100, "_s3")])
 def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, spec):
     """BASELINE.json's geometries run builds of the transition and emit kernels that have the grid sizes, LDS offsets and
     division constants as compile-time literals (irbpp_device.h: SPEC_KEYS), and a step applies its actions in
     irbpp_apply_kernel (a wave per bin) in front of the transition kernel.  IRBPP_TUNE_NO_SPECIALISED forces the builds that
-    read Params, IRBPP_TUNE_FUSED_APPLY the round-4 form (actions applied inside the transition kernel), IRBPP_TUNE_BLOCK_EMIT
+    read Params, IRBPP_TUNE_NO_WG512 / _WG512 the generic path's 256- / 512-thread workgroups, IRBPP_TUNE_FUSED_APPLY the round-4
+    form (actions applied inside the transition kernel), IRBPP_TUNE_BLOCK_EMIT
     the emit kernel with a workgroup per bin where lattice / box data take the one with a wave per bin.  Same observations,
     rewards, done flags, step outputs and heightmaps through whole episodes -- with the scripted policy, and with actions
     drawn at random over all S rows for some bins (zero-padded rows: the drop height is then recomputed, not looked up)."""
@@ -243,11 +244,13 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     shapes, seqs, kw = make_workload(workload)
     k = int(kw.get("bufferSize", 1))
     flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
-             _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT]
+             _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
+             _lib.TUNE_NO_WG512, _lib.TUNE_WG512]          # (256- / 512-thread workgroups of the generic path whatever the data)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
     assert names[1] == names[4] and "_s" not in names[1].replace("irbpp_env_kernel", ""), names
+    assert "w512" not in names[5] and (("w512" in names[6]) == ("generic" in names[4] or "_s3" in names[0] or "_s4" in names[0])), names
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)
