@@ -100,7 +100,7 @@ int raise_lds_limits() {
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
                              (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2,
-                             (const void*)wg512::irbpp_env_kernel_s4_w512,
+                             (const void*)wg512::irbpp_env_kernel_s4_w512, (const void*)wg512::irbpp_env_kernel_s4_w512c,
 #endif
                              (const void*)wg512::irbpp_env_kernel_generic_w512,
                              (const void*)irbpp_emit_wave_kernel,
@@ -508,10 +508,17 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
     // Generic path where the tile is so large that at most four 256-thread workgroups fit a CU's LDS (the 64 x 64 heightmap:
     // 40 KB per bin): 512-thread workgroups, eight waves on one tile (irbpp::wg512, the second pass of irbpp_kernels.hip)
     const bool generic = P.block_b == 0 && !P.box;
+#if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
+    if (generic && (t & IRBPP_TUNE_NARROW_KERNEL) && (t & IRBPP_TUNE_WG512) && spec_matches(P, spec_params(SPEC_KEYS[4])))
+        return {wg512::irbpp_env_kernel_s4_w512c, "irbpp_env_kernel_s4_w512c", 512};      // (A/B: under the 64-VGPR cap)
+#endif
     const bool wg512 = generic && !(t & (IRBPP_TUNE_NO_WG512 | IRBPP_TUNE_WIDE_KERNEL | IRBPP_TUNE_NARROW_KERNEL)) &&
                        ((t & IRBPP_TUNE_WG512) || 5 * P.lds_bytes > 160 * 1024);
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
-    if (wg512 && pick_spec(env) == 4) return {wg512::irbpp_env_kernel_s4_w512, "irbpp_env_kernel_s4_w512", 512};
+    // (under the 64-VGPR cap four such workgroups share a CU instead of three: level at 2048 bins, +10 % at 8192, profiles/r05/s30)
+    if (wg512 && pick_spec(env) == 4)
+        return P.N >= 4096 ? EnvKernel{wg512::irbpp_env_kernel_s4_w512c, "irbpp_env_kernel_s4_w512c", 512}
+                           : EnvKernel{wg512::irbpp_env_kernel_s4_w512, "irbpp_env_kernel_s4_w512", 512};
 #endif
     if (wg512 && (pick_spec(env) == 0 || (t & IRBPP_TUNE_WG512)))
         return {wg512::irbpp_env_kernel_generic_w512, "irbpp_env_kernel_generic_w512", 512};

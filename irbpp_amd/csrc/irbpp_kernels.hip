@@ -2312,6 +2312,7 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
 IRBPP_ENV_KERNEL_512(irbpp_env_kernel_generic_w512, PATH_GENERIC, 0, )
 #ifndef IRBPP_NO_SPEC
 IRBPP_ENV_KERNEL_512(irbpp_env_kernel_s4_w512, PATH_GENERIC, 4, )
+IRBPP_ENV_KERNEL_512(irbpp_env_kernel_s4_w512c, PATH_GENERIC, 4, __attribute__((amdgpu_waves_per_eu(8, 8))))
 #endif
 #endif  // IRBPP_PASS
 

@@ -29,7 +29,8 @@ def test_no_use_of_scalar_load_destinations_before_the_wait(disassembly):
                    "irbpp_trace_kernel", "irbpp_polygon_kernel", "irbpp_emit_kernel", "irbpp_heuristic_kernel"):
         assert kernel in funcs and len(funcs[kernel]) > 100
     # the pipelined 64-byte list loads are where they are expected (three walk depths x two address forms x three quads)
-    for kernel in ("irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide"):
+    for kernel in ("irbpp_env_kernel_generic8", "irbpp_env_kernel_generic", "irbpp_env_kernel_wide", "irbpp_env_kernel_s3", "irbpp_env_kernel_s4",
+                   "irbpp_env_kernel_generic_w512", "irbpp_env_kernel_s4_w512", "irbpp_env_kernel_s4_w512c"):
         n16 = sum(1 for _, m, o, _ in funcs[kernel] if m == "s_load_dwordx16" and o.rstrip().endswith("0x0"))
         assert n16 >= 6, (kernel, n16)
     assert _problems(disassembly) == []
@@ -62,6 +63,7 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
               # wave-per-bin emit kernel: its ordinary path (a wave's own bin) touches no scratch; the spills sit in the path behind
               # its early return (bins that need the workgroup: more than S candidates), around the loop over those bins
               "irbpp_emit_wave_kernel": 216, "irbpp_emit_wave_kernel_s1": 152, "irbpp_emit_wave_kernel_s2": 108,
+              "irbpp_env_kernel_generic_w512": 0, "irbpp_env_kernel_s4_w512": 0, "irbpp_env_kernel_s4_w512c": 16,
               "irbpp_env_kernel_wide": 36}           # (_wide: the A/B build that decides the overlap path at run time; not a default)
     for kernel, limit in limits.items():
         assert kernel in sizes, kernel
