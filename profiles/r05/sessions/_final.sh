@@ -11,4 +11,5 @@ timeout 500 bash tools/gpu_profile.sh final/prof_abc_fine abc_fine 8192 2>&1 | t
 timeout 200 bash tools/gpu_kernel_stats.sh final cube blockout_k10 blockout_r8 2>&1 | grep -c irbpp
 for wl in blockout general abc_fine cube; do timeout 120 python tools/phase_profile.py --workload $wl > $O/phase_$wl.json 2>/dev/null; done
 timeout 120 python tools/trace_profile.py --workload blockout > $O/trace_blockout.json 2>/dev/null
+timeout 400 python tools/ab_matrix.py --repeat 1 --min-seconds 0.4 blockout_k10:8192:2:0 blockout_k10:4096:2:0 blockout_k10:2048:2:0 blockout_k10:1024:1:0 abc_fine:16384:2:0 abc_fine:8192:2:0 abc_fine:4096:2:0 abc_fine:2048:2:0 abc_fine:2048:1:0 general:4096:1:0 > $O/scaling_points.jsonl 2>/dev/null
 ls $O

@@ -8,7 +8,7 @@ S=gpurun_out/final; D=profiles/r05/final; REV=${1:-$(git rev-parse --short HEAD)
 find $S -name "r0[0-9]_*" ! -name "r05_*" -delete
 mkdir -p $D/other_workloads
 for f in bench_default.json bench_driver_style.json pytest_gpu.txt trace_blockout.json phase_blockout.json phase_general.json \
-         phase_abc_fine.json phase_cube.json; do cp $S/$f $D/$f; done
+         phase_abc_fine.json phase_cube.json scaling_points.jsonl; do cp $S/$f $D/$f; done
 for f in bench_under_rocprof.json kernel_stats.csv kernel_trace_timed_region.json fetch_summary.json write_summary.json \
          sq_summary.json sq2_summary.json; do cp $S/prof_blockout/$f $D/$f; done
 for wl in general abc_fine; do
