@@ -1129,6 +1129,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         return __popcll(__ballot(lane >= 1 && lane < 8 && t >= my_first));
     };
     int pref = 0;
+    uint32_t task_lo = 0u, task_hi = 0u;                     // level bits of the lane's cells in the current task
     auto task_finish = [&](int r, int X, int s_ax, int s_ay, double ext_z_r, double z) {
         const bool in_range = X <= Ax - s_ax && Y <= Ay - s_ay;
         const bool valid = in_range && round6_scaled(z + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
@@ -1155,15 +1156,20 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         // naiveMask bit rows from the ballot: lane (row slot rs, Y == 0) stores its row's word
         const unsigned long long bal = __ballot(valid);
         if (Y == 0 && X < Ax) L.vbits[r * 16 + X] = (uint32_t)(bal >> (rs << ysh)) & ((1u << Ay) - 1u);
-        // presence mask of the rotation: OR over the wave on the DPP network, LDS atomics by its last lane (a rotation
-        // can have several tasks)
-        bits_lo = wave_or_to_lane63(bits_lo);
-        bits_hi = wave_or_to_lane63(bits_hi);
+        // presence mask of the rotation: the lane's bits join those of the task's other row groups (task_presence below)
+        task_lo |= bits_lo;
+        task_hi |= bits_hi;
+    };
+    // ... OR over the wave on the DPP network once per TASK (up to three row groups), LDS atomics by the wave's last lane (a
+    // rotation can have several tasks)
+    auto task_presence = [&](int r) {
+        const uint32_t lo = wave_or_to_lane63(task_lo), hi = wave_or_to_lane63(task_hi);
         if (lane == 63) {
             uint32_t* pw = (uint32_t*)&L.present[r];
-            if (bits_lo) atomicOr(pw, bits_lo);
-            if (bits_hi) atomicOr(pw + 1, bits_hi);
+            if (lo) atomicOr(pw, lo);
+            if (hi) atomicOr(pw + 1, hi);
         }
+        task_lo = task_hi = 0u;
     };
     auto prefetch_list = [&](int ob, int nb) {
         const char* lv = (const char*)(T.gcell + ob);
@@ -1231,6 +1237,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         task_finish(r, X0, s_ax, s_ay, ext_z_r, z[0]);
         if (G > 1) task_finish(r, X0 + rpw, s_ax, s_ay, ext_z_r, z[1]);
         if (G > 2) task_finish(r, X0 + 2 * rpw, s_ax, s_ay, ext_z_r, z[2]);
+        task_presence(r);
     }
     asm volatile("" :: "v"(pref));                           // the prefetch loads are complete by now; nothing uses their data
     if (debug_out)                                           // posZmap / naiveMask outside every rotation's range
