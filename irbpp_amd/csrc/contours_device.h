@@ -719,6 +719,16 @@ __device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) 
 __device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) { tail = seg >= 0; }       // every key goes to its word
 #endif
 
+// Set bits of a ballot below this lane (v_mbcnt_lo / v_mbcnt_hi take the mask as a scalar pair: two instructions).
+__device__ __forceinline__ int wave_count_below(unsigned long long mask, int lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+#else
+    return __popcll(mask & (lane == 0 ? 0ull : (~0ull >> (64 - lane))));
+#endif
+}
+
 // A wave serves 64 * P contour points per round: position q = u * 64 + lane, u < P, borders packed back to
 // back over the positions (a border of up to 64 * P points fits).  Per position:
 //   live: a point sits here;  pv: the point (x | y<<4);  j, n: its index in / the size of its border;
@@ -798,7 +808,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     // 2. Douglas-Peucker, all slices of one recursion level per round; every lane keeps the end points of its
     // slice in registers, the split point's coordinates arrive with the arg-max
     bool keep[P], active[P];
-    int ss[P], se[P], s0[P], axy[P], bxy[P];
+    int ss[P], se[P], s0[P], axy[P], bxy[P], t[P];                 // t: my distance from my slice's start point, along the border
     bool any_active = false;
 #pragma unroll
     for (int u = 0; u < P; ++u) {
@@ -810,8 +820,8 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         if (len_a < 0) len_a += n[u];
         keep[u] = live[u] && (le_eps[u] ? j[u] == s0[u] : (j[u] == s0[u] || j[u] == far));
         active[u] = live[u] && !le_eps[u] && !keep[u];
-        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; axy[u] = sxy[u]; bxy[u] = fxy[u]; }
-        else { ss[u] = far; se[u] = s0[u]; axy[u] = fxy[u]; bxy[u] = sxy[u]; }
+        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; axy[u] = sxy[u]; bxy[u] = fxy[u]; t[u] = t0; }
+        else { ss[u] = far; se[u] = s0[u]; axy[u] = fxy[u]; bxy[u] = sxy[u]; t[u] = t0 - len_a; }
         any_active |= active[u];
     }
     while (__ballot(any_active) != 0ull) {
@@ -819,18 +829,16 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
-        int t[P], dx[P], dy[P], dseg[P];
+        int dx[P], dy[P], dseg[P];
         uint32_t dkey[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-            t[u] = dx[u] = dy[u] = 0;
+            dx[u] = dy[u] = 0;
             dseg[u] = -1;
             dkey[u] = 0u;
             if (active[u]) {
                 dx[u] = IRBPP_PX(bxy[u]) - IRBPP_PX(axy[u]);
                 dy[u] = IRBPP_PY(bxy[u]) - IRBPP_PY(axy[u]);
-                t[u] = j[u] - ss[u];
-                if (t[u] < 0) t[u] += n[u];
                 int dist = (py[u] - IRBPP_PY(axy[u])) * dx[u] - (px[u] - IRBPP_PX(axy[u])) * dy[u];
                 dist = dist < 0 ? -dist : dist;
                 dseg[u] = sb[u] + ss[u];
@@ -860,7 +868,7 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
                     if (sp >= n[u]) sp -= n[u];
                     if (t[u] == ts) { keep[u] = true; active[u] = false; }
                     else if (t[u] < ts) { se[u] = sp; bxy[u] = (int)(best[u] & 255u); }
-                    else { ss[u] = sp; axy[u] = (int)(best[u] & 255u); }
+                    else { ss[u] = sp; axy[u] = (int)(best[u] & 255u); t[u] -= ts; }
                 }
             }
             any_active |= active[u];
@@ -872,25 +880,27 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     unsigned long long kept[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) kept[u] = __ballot(keep[u]);
+    // kept points at positions below mine = bit counts on the ballots; every position files that count, and a point's rank
+    // among the kept points of its border (and the border's polygon size) are differences to the counts filed at the
+    // border's first position and behind its last one.  (Until round 5 session 32 every lane counted the bits of its
+    // border's range in every ballot word: ~60 vector instructions per position of 64-bit mask arithmetic.)
+    int below[P], total = 0;
+#pragma unroll
+    for (int u = 0; u < P; ++u) {
+        below[u] = total + wave_count_below(kept[u], lane);
+        total += __popcll(kept[u]);
+        slots[u * 64 + lane] = (uint32_t)below[u];
+    }
+    IRBPP_WAVE_SYNC();
     int m[P], rank[P];
 #pragma unroll
     for (int u = 0; u < P; ++u) {
-        m[u] = 0;
-        rank[u] = 0;
-        const int q = u * 64 + lane;
-#pragma unroll
-        for (int w = 0; w < P; ++w) {                    // kept points of my border in word w: all, and those before me
-            int lo = sb[u] - 64 * w, hi = sb[u] + n[u] - 64 * w, me = q - 64 * w;
-            lo = lo < 0 ? 0 : (lo > 64 ? 64 : lo);
-            hi = hi < 0 ? 0 : (hi > 64 ? 64 : hi);
-            me = me < lo ? lo : (me > hi ? hi : me);
-            const unsigned long long below_hi = hi >= 64 ? ~0ull : ((1ull << hi) - 1ull);
-            const unsigned long long below_lo = lo >= 64 ? ~0ull : ((1ull << lo) - 1ull);
-            const unsigned long long below_me = me >= 64 ? ~0ull : ((1ull << me) - 1ull);
-            m[u] += __popcll(kept[w] & below_hi & ~below_lo);
-            rank[u] += __popcll(kept[w] & below_me & ~below_lo);
-        }
+        const int first = (int)slots[sb[u]], e = sb[u] + n[u];
+        const int behind = e < 64 * P ? (int)slots[e < 64 * P ? e : 0] : total;
+        m[u] = behind - first;
+        rank[u] = below[u] - first;
     }
+    IRBPP_WAVE_SYNC();
 #pragma unroll
     for (int u = 0; u < P; ++u)
         if (keep[u]) slots[sb[u] + rank[u]] = (uint32_t)j[u] | ((uint32_t)pv[u] << 16);   // index and point
