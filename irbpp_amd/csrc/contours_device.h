@@ -698,7 +698,7 @@ __device__ inline void cleanup_convex_serial(uint8_t* dst, int cnt, uint32_t* vr
 // made 66 % of the polygon kernel's LDS cycles bank conflicts and the LDS, busy for two thirds of the kernel's duration,
 // its bottleneck (profiles/r03/final/sq2_summary.json).  Any way of combining keys of one segment is right (the result is
 // their maximum; keys are unique), so a wrapped slice -- two runs of one segment -- needs no special care.
-// MEASURED AND NOT TAKEN (profiles/r04/s10, build with -DIRBPP_AB_ROW_ARGMAX): the conflict share of the polygon kernel's LDS
+// MEASURED AND NOT TAKEN (profiles/r04/s10, build with -DIRBPP_AB_ROW_ARGMAX; the hook is left in the hop rounds only): the conflict share of the polygon kernel's LDS
 // cycles fell from 66 % to 15 % and its LDS cycles by 58 %, and the kernel got SLOWER, 24.1 -> 27.9 us on BlockOut and
 // 26.9 -> 33.3 us on "general": it is bound by its vector instructions (4.4 cycles each per SIMD), and the ~21 added per
 // point set and round cost more than the serialised atomics did -- the LDS takes those in its stride.
@@ -806,10 +806,18 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
     }
     IRBPP_POLY_STAMP(1);
     // 2. Douglas-Peucker, all slices of one recursion level per round; every lane keeps the end points of its
-    // slice in registers, the split point's coordinates arrive with the arg-max
-    bool keep[P], active[P];
-    int ss[P], se[P], s0[P], axy[P], bxy[P], t[P];                 // t: my distance from my slice's start point, along the border
-    bool any_active = false;
+    // slice in registers, the split point's coordinates arrive with the arg-max.
+    // A position's whole state is four words: seg >= 0: it is an interior point of the slice whose arg-max word is slots[seg]
+    // (seg = position of the slice's start point), -1: dropped, -2: kept; axy / bxy: the slice's end points; tk: the low half
+    // of its arg-max key, (255 - t) << 8 | point with t = its distance from the slice's start along the border.  The level
+    // is STRAIGHT-LINE code for every position -- a masked-off vector instruction costs the issue slot it saves nothing of, and
+    // the kernel is bound by issue --: a position that is not active bids 0 (which changes no word) at its own word, and its
+    // state passes through selects.  (Until round 5 session 33 the level was three `if (active)` regions per position with
+    // two flags carried in vector registers: 112 vector instructions per level of two positions, a third of them moves and
+    // flag tests.)
+    int s0[P], seg[P], axy[P], bxy[P];
+    uint32_t tk[P];
+    int any_seg = -1;                                               // sign bit clear iff some position is active
 #pragma unroll
     for (int u = 0; u < P; ++u) {
         s0[u] = pos[u];
@@ -818,62 +826,61 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         int t0 = j[u] - s0[u], len_a = far - s0[u];
         if (t0 < 0) t0 += n[u];
         if (len_a < 0) len_a += n[u];
-        keep[u] = live[u] && (le_eps[u] ? j[u] == s0[u] : (j[u] == s0[u] || j[u] == far));
-        active[u] = live[u] && !le_eps[u] && !keep[u];
-        if (t0 < len_a) { ss[u] = s0[u]; se[u] = far; axy[u] = sxy[u]; bxy[u] = fxy[u]; t[u] = t0; }
-        else { ss[u] = far; se[u] = s0[u]; axy[u] = fxy[u]; bxy[u] = sxy[u]; t[u] = t0 - len_a; }
-        any_active |= active[u];
+        const bool keep0 = live[u] && (le_eps[u] ? j[u] == s0[u] : (j[u] == s0[u] || j[u] == far));
+        const bool act0 = live[u] && !le_eps[u] && !keep0;
+        const bool first = t0 < len_a;                              // my slice: (s0, far) or (far, s0)
+        axy[u] = first ? sxy[u] : fxy[u];
+        bxy[u] = first ? fxy[u] : sxy[u];
+        tk[u] = ((uint32_t)(255 - (first ? t0 : t0 - len_a)) << 8) | (uint32_t)pv[u];
+        seg[u] = act0 ? sb[u] + (first ? s0[u] : far) : (keep0 ? -2 : -1);
+        any_seg &= seg[u];
     }
-    while (__ballot(any_active) != 0ull) {
+    while (__ballot(any_seg >= 0) != 0ull) {
         IRBPP_POLY_COUNT(5);
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
-        int dx[P], dy[P], dseg[P];
-        uint32_t dkey[P];
+        int dx[P], dy[P], word[P];
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-            dx[u] = dy[u] = 0;
-            dseg[u] = -1;
-            dkey[u] = 0u;
-            if (active[u]) {
-                dx[u] = IRBPP_PX(bxy[u]) - IRBPP_PX(axy[u]);
-                dy[u] = IRBPP_PY(bxy[u]) - IRBPP_PY(axy[u]);
-                int dist = (py[u] - IRBPP_PY(axy[u])) * dx[u] - (px[u] - IRBPP_PX(axy[u])) * dy[u];
-                dist = dist < 0 ? -dist : dist;
-                dseg[u] = sb[u] + ss[u];
-                dkey[u] = ((uint32_t)dist << 16) | ((uint32_t)(255 - t[u]) << 8) | (uint32_t)pv[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < P; ++u) {
-            bool tail;
-            row_run_max(dseg[u], dkey[u], tail);
-            if (tail) atomicMax(&slots[dseg[u]], dkey[u]);
+            const int ax = IRBPP_PX(axy[u]), ay = IRBPP_PY(axy[u]);
+            dx[u] = IRBPP_PX(bxy[u]) - ax;
+            dy[u] = IRBPP_PY(bxy[u]) - ay;
+            int dist = (py[u] - ay) * dx[u] + (ax - px[u]) * dy[u];
+            dist = dist < 0 ? -dist : dist;
+            const bool act = seg[u] >= 0;
+            word[u] = act ? seg[u] : u * 64 + lane;
+            atomicMax(&slots[word[u]], act ? (((uint32_t)dist << 16) | tk[u]) : 0u);
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
 #pragma unroll
-        for (int u = 0; u < P; ++u) best[u] = active[u] ? slots[sb[u] + ss[u]] : 0u;
+        for (int u = 0; u < P; ++u) best[u] = slots[word[u]];
         IRBPP_WAVE_SYNC();
-        any_active = false;
+        any_seg = -1;
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-            if (active[u]) {
-                const int md = (int)(best[u] >> 16), ts = 255 - (int)((best[u] >> 8) & 255u);
-                if (md * md <= dx[u] * dx[u] + dy[u] * dy[u]) {
-                    active[u] = false;                   // slice accepted: its interior points are dropped
-                } else {
-                    int sp = ss[u] + ts;
-                    if (sp >= n[u]) sp -= n[u];
-                    if (t[u] == ts) { keep[u] = true; active[u] = false; }
-                    else if (t[u] < ts) { se[u] = sp; bxy[u] = (int)(best[u] & 255u); }
-                    else { ss[u] = sp; axy[u] = (int)(best[u] & 255u); t[u] -= ts; }
-                }
-            }
-            any_active |= active[u];
+            const bool act = seg[u] >= 0;
+            const int md = (int)(best[u] >> 16);
+            const bool accept = md * md <= dx[u] * dx[u] + dy[u] * dy[u];      // slice accepted: its interior points are dropped
+            const uint32_t bt = best[u] & 0xFF00u, mt = tk[u] & 0xFF00u;       // 255 - t of the split point / of me
+            const bool split = act && !accept;
+            const bool right = split && mt < bt;                              // I lie behind the split point: my slice starts there now
+            const bool left = split && mt > bt;                               //   before it: my slice ends there
+            const int np = (int)(best[u] & 255u);
+            const int ts = 255 - (int)(bt >> 8);
+            int s2 = seg[u] + ts;
+            s2 -= s2 >= sb[u] + n[u] ? n[u] : 0;
+            axy[u] = right ? np : axy[u];
+            bxy[u] = left ? np : bxy[u];
+            tk[u] = right ? tk[u] + ((uint32_t)ts << 8) : tk[u];
+            seg[u] = !act ? seg[u] : accept ? -1 : right ? s2 : left ? seg[u] : -2;      // (neither side: I am the split point, kept)
+            any_seg &= seg[u];
         }
     }
+    bool keep[P];
+#pragma unroll
+    for (int u = 0; u < P; ++u) keep[u] = seg[u] == -2;
     IRBPP_POLY_STAMP(2);
     // 3. the polygon = kept points in contour order: every kept point files its index at its rank among the
     // kept points of its border (bit counts on the ballots), neighbours are the entries next to it
