@@ -358,7 +358,7 @@ def vecenv_rate(bins, dev, steps=100):
 
     out = {"bins": bins, "with_trainer_per_env_loop": run(True), "without_per_env_loop": run(False),
            "device_action_tensor_no_loop": run(False, True), "unit": "placement-steps/s",
-           "note": "GpuVecEnv.step incl. host actions H2D, one pinned D2H of reward/done/info + sync per step"}
+           "note": "GpuVecEnv.step as ONE group (make_vec_envs' default: the synchronous step is fastest that way) incl. host actions H2D, one pinned D2H of reward/done/info + sync per step"}
     envs.close()
     return out
 

@@ -293,10 +293,18 @@ class GpuPackingEnv(object):
         stream synchronisation -> dict of numpy arrays that belong to the caller (a copy of the pinned landing buffer:
         a rollout may keep `done` / `infos` of step t for as long as it likes, as with the reference's fresh arrays).
         Raises if a kernel raised its error word."""
-        n = self.num_bins
         st = torch.cuda.current_stream(self.device)
-        self._out_host.copy_(self._out, non_blocking=True)
+        self._info_copy_async()
         st.synchronize()
+        return self._info_parse()
+
+    def _info_copy_async(self) -> None:
+        """the copy alone, on the current stream (GroupedPackingEnv issues every group's on the group's own stream before it
+        waits for any of them)"""
+        self._out_host.copy_(self._out, non_blocking=True)
+
+    def _info_parse(self):
+        n = self.num_bins
         h = self._out_host.numpy().copy()
         err = int(h[-4:].view(np.int32)[0])
         if err:
@@ -397,6 +405,15 @@ class GroupedPackingEnv(object):
         with torch.cuda.stream(self.streams[g]):
             return self.groups[g].policy_minz(loc_obs, actions_out=actions_out)
 
+    def policy_minz(self, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The scripted MINZ policy over all bins, on the caller's current stream (as GpuPackingEnv.policy_minz: the
+        observation is the caller's, e.g. what a synchronous step() returned)."""
+        act = actions_out if actions_out is not None else \
+            torch.empty((self.num_bins,), dtype=torch.int32, device=self.device)
+        for g, e in enumerate(self.groups):
+            e.policy_minz(loc_obs[self.rows(g)], actions_out=act[self.rows(g)])
+        return act
+
     def get_action_candidates_group(self, g: int, order_actions: torch.Tensor, obs_out: Optional[torch.Tensor] = None,
                                     wait: bool = True):
         self._enter(g, order_actions, obs_out, wait=wait)
@@ -451,8 +468,16 @@ class GroupedPackingEnv(object):
             e.check_device_error()
 
     def step_info_host(self):
-        self.synchronize()
-        parts = [e.step_info_host() for e in self.groups]
+        """Every group's copy goes out on the group's own stream, behind its kernels, before the first wait: a group's
+        D2H overlaps the other groups' kernels, and the step has one synchronisation per stream (until round 5 session 34:
+        all streams joined first, then copy + wait group by group on the caller's stream)."""
+        for e, st in zip(self.groups, self.streams):
+            with torch.cuda.stream(st):
+                e._info_copy_async()
+        parts = []
+        for e, st in zip(self.groups, self.streams):
+            st.synchronize()
+            parts.append(e._info_parse())
         return {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
 
     def close(self):
@@ -592,7 +617,8 @@ class GpuVecEnv(object):
                  allow_early_resets: bool = True, num_groups: int = 1, obs_ring: int = 3, feeder=None, **env_kw):
         """``num_groups`` > 1: the envs are stepped as that many independent groups on their own HIP streams
         (GroupedPackingEnv); 0: as many as ``groups_for`` recommends for this data set and size; ``step()`` still covers all envs, and ``step_async(actions, group=g)`` /
-        ``step_wait(group=g)`` let an actor loop work on one group while the others step.
+        ``step_wait(group=g)`` let an actor loop work on one group while the others step.  (A caller that only ever calls the
+        synchronous ``step()`` is best served by one group: the groups' launches are host time on its one dependent chain.)
         ``feeder``: an ``itemgen.StreamFeeder`` for environments created with ``item_stream=1``."""
         self.num_groups = int(num_groups)
         if self.num_groups == 0:            # the library's own choice (groups_for): which overlap path does this data set take?
@@ -862,13 +888,17 @@ def make_vec_envs(args, log_dir=None, allow_early_resets=False):
     if getattr(args, "tuning", 0):           # (not a reference argument: irbpp_config::tuning, A/B runs and tests)
         kw["tuning"] = int(args.tuning)
     # (args.num_groups is not a reference argument: > 1 steps the envs as that many independent groups on their own HIP
-    # streams, item streams included -- GroupedPackingEnv; default 0 = the library's own choice, groups_for: two groups on the
-    # process's checked pair of streams from 2048 lattice / 1024 free-form environments on, one below)
+    # streams, item streams included -- GroupedPackingEnv; 0 = the library's own choice for PIPELINED stepping, groups_for.
+    # Default 1: the reference's trainer calls envs.step() for all environments and waits (trainer.py:165) -- one dependent
+    # chain per step either way, and the second group's launches are host time on that chain: 4096 BlockOut environments
+    # 21.3 M steps/s as one group, 18.6 M as two; 8192: 29.4 / 27.5; 2048: 12.9 / 10.7, profiles/r05/s35.  Groups pay for
+    # callers that keep the device busy across steps: step_async(group=g) / step_wait(group=g) actor loops, device-resident
+    # policies)
     # args.obs_ring (not a reference argument either): 0 (default here) = every call returns a fresh observation tensor, the
     # reference's behaviour; 3 = the ring of library-registered buffers GpuVecEnv uses by default (+10 % step rate; an
     # observation is overwritten three calls later, which the reference's trainer never notices)
     envs = GpuVecEnv(shapes, sequences, args.num_processes, device=dev, allow_early_resets=allow_early_resets,
-                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 0)), obs_ring=int(getattr(args, "obs_ring", 0)), **kw)
+                     feeder=feeder, num_groups=int(getattr(args, "num_groups", 1)), obs_ring=int(getattr(args, "obs_ring", 0)), **kw)
     return envs, [envs.observation_space, envs.action_space], envs.obs_len
 
 

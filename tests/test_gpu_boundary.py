@@ -236,6 +236,7 @@ def test_make_vec_envs_hands_out_observations_that_stay():
         num_processes=8, device=0, seed=1, shapes=sh, sequences=seqs, resolutionA=0.02, resolutionH=0.01, resolutionZ=0.01,
         bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S, bufferSize=1, scale=[100, 100, 100], evaluate=True)
     envs, _, _ = make_vec_envs(args, "./logs/runinfo", True)
+    assert envs.num_groups == 1            # the trainer's synchronous step() is fastest as one group at every size (profiles/r05/s35)
     cenv = CO(8, sh, seqs)
     states = [envs.reset()]
     want = [_f32(cenv.reset())]

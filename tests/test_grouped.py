@@ -52,8 +52,11 @@ def test_grouped_stepping_matches_c_oracle(workload, n, steps):
             np.testing.assert_array_equal(gloc.cpu().numpy(), cloc, err_msg=f"grouped location obs, step {t}")
             np.testing.assert_array_equal(sloc.cpu().numpy(), cloc)
             act = single.env.policy_minz(sloc).cpu().numpy()
+            np.testing.assert_array_equal(grouped.env.policy_minz(gloc).cpu().numpy(), act)      # the grouped env's policy over all bins
         else:
             act = single.env.policy_minz(sobs).cpu().numpy()
+            grouped.env.synchronize()
+            np.testing.assert_array_equal(grouped.env.policy_minz(gobs).cpu().numpy(), act)
         cobs, crew, cdone, cinfo = cenv.step(act)
         cobs = _f32(cobs)
         sobs, srew, sdone, sinfo = single.step(act)
