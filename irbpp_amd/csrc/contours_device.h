@@ -690,34 +690,13 @@ __device__ inline void cleanup_convex_serial(uint8_t* dst, int cnt, uint32_t* vr
     }
 }
 
-// Arg-max keys of one segment pre-reduced inside each row of 16 lanes before they meet in LDS.  Lanes next to each other
-// that carry the same segment (`seg` >= 0: the segment's arg-max word; -1: no key) form a run; four row shifts on the DPP
-// network give every lane the maximum of its run up to itself, and only the run's last lane of the row (`tail`) sends its
-// key to the word with ds_max_u32.  A segment then costs at most a handful of LDS atomics instead of one per point: all
-// points of a border (hop rounds) or a slice (Douglas-Peucker rounds) hitting ONE word were serialised by the LDS, which
-// made 66 % of the polygon kernel's LDS cycles bank conflicts and the LDS, busy for two thirds of the kernel's duration,
-// its bottleneck (profiles/r03/final/sq2_summary.json).  Any way of combining keys of one segment is right (the result is
-// their maximum; keys are unique), so a wrapped slice -- two runs of one segment -- needs no special care.
-// MEASURED AND NOT TAKEN (profiles/r04/s10, build with -DIRBPP_AB_ROW_ARGMAX; the hook is left in the hop rounds only): the conflict share of the polygon kernel's LDS
-// cycles fell from 66 % to 15 % and its LDS cycles by 58 %, and the kernel got SLOWER, 24.1 -> 27.9 us on BlockOut and
-// 26.9 -> 33.3 us on "general": it is bound by its vector instructions (4.4 cycles each per SIMD), and the ~21 added per
-// point set and round cost more than the serialised atomics did -- the LDS takes those in its stride.
-#if defined(__HIP_DEVICE_COMPILE__) && defined(IRBPP_AB_ROW_ARGMAX)
-__device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) {
-#define IRBPP_ROW_STEP(CTRL)                                                                                      \
-    {                                                                                                             \
-        const int pseg = __builtin_amdgcn_update_dpp(-2, seg, CTRL, 0xF, 0xF, false);                             \
-        const uint32_t pkey = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, CTRL, 0xF, 0xF, false);          \
-        key = pseg == seg ? (pkey > key ? pkey : key) : key;                                                      \
-    }
-    IRBPP_ROW_STEP(0x111) IRBPP_ROW_STEP(0x112) IRBPP_ROW_STEP(0x114) IRBPP_ROW_STEP(0x118)      // row_shr:1, 2, 4, 8
-#undef IRBPP_ROW_STEP
-    const int nseg = __builtin_amdgcn_update_dpp(-2, seg, 0x101, 0xF, 0xF, false);                // row_shl:1: my right neighbour's
-    tail = seg >= 0 && nseg != seg;
-}
-#else
-__device__ __forceinline__ void row_run_max(int seg, uint32_t& key, bool& tail) { tail = seg >= 0; }       // every key goes to its word
-#endif
+// The arg-max words take one ds_max_u32 per point; all points of a border (hop rounds) or a slice (Douglas-Peucker rounds) hit
+// ONE word and are serialised by the LDS, which made 66 % of the polygon kernel's LDS cycles bank conflicts (profiles/r03/final/
+// sq2_summary.json).  MEASURED AND NOT TAKEN (profiles/r04/s10, a build that pre-reduced the keys of a segment inside each row
+// of 16 lanes on the DPP network and sent one key per run to the word): the conflict share fell to 15 % and the LDS cycles by
+// 58 %, and the kernel got SLOWER, 24.1 -> 27.9 us on BlockOut and 26.9 -> 33.3 us on "general": it is bound by its vector
+// instructions (4.4 cycles each per SIMD), and the ~21 added per point set and round cost more than the serialised atomics did
+// -- the LDS takes those in its stride.  (The hook of that build was removed in round 5 with the straight-line rounds.)
 
 // Set bits of a ballot below this lane (v_mbcnt_lo / v_mbcnt_hi take the mask as a scalar pair: two instructions).
 __device__ __forceinline__ int wave_count_below(unsigned long long mask, int lane) {
@@ -764,43 +743,37 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
         sxy[u] = live[u] ? (int)pts[u][0] : 0;
         fxy[u] = sxy[u];
     }
+    // (straight-line code like the Douglas-Peucker level below: a position without a bid -- no point, or the hop's start point
+    // itself -- sends 0, which changes no word; a position without a point has sb = 0, n = 1 and carries values nobody reads)
     for (int it = 0; it < 3; ++it) {
 #pragma unroll
         for (int u = 0; u < P; ++u) slots[u * 64 + lane] = 0u;
         IRBPP_WAVE_SYNC();
-        int hseg[P];
-        uint32_t hkey[P];
-#pragma unroll
-        for (int u = 0; u < P; ++u) { hseg[u] = -1; hkey[u] = 0u; }
 #pragma unroll
         for (int u = 0; u < P; ++u) {
-            if (live[u]) {
-                int t = j[u] - pos[u];
-                if (t < 0) t += n[u];
-                const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
-                if (t >= 1) { hseg[u] = sb[u]; hkey[u] = ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u]; }
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < P; ++u) {                        // (all lanes: the row shifts read their neighbours)
-            bool tail;
-            row_run_max(hseg[u], hkey[u], tail);
-            if (tail) atomicMax(&slots[hseg[u]], hkey[u]);
+            int t = j[u] - pos[u];
+            t += t < 0 ? n[u] : 0;
+            const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
+            const uint32_t key = ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u];
+            atomicMax(&slots[sb[u]], live[u] && t >= 1 ? key : 0u);
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
 #pragma unroll
-        for (int u = 0; u < P; ++u) best[u] = live[u] ? slots[sb[u]] : 0u;
+        for (int u = 0; u < P; ++u) best[u] = slots[sb[u]];
         IRBPP_WAVE_SYNC();
 #pragma unroll
         for (int u = 0; u < P; ++u) {
             const int max_dist = (int)(best[u] >> 16);
-            if (max_dist > 0) { right_start[u] = 255 - (int)((best[u] >> 8) & 255u); fxy[u] = (int)(best[u] & 255u); }
+            const bool found = max_dist > 0;
+            right_start[u] = found ? 255 - (int)((best[u] >> 8) & 255u) : right_start[u];
+            fxy[u] = found ? (int)(best[u] & 255u) : fxy[u];
             le_eps[u] = max_dist <= 1;
-            if (it < 2 && max_dist > 0) {                    // the next hop starts at the farthest point found
-                pos[u] += right_start[u];
-                if (pos[u] >= n[u]) pos[u] -= n[u];
-                sxy[u] = fxy[u];
+            if (it < 2) {                                    // (uniform) the next hop starts at the farthest point found
+                int p2 = pos[u] + right_start[u];
+                p2 -= p2 >= n[u] ? n[u] : 0;
+                pos[u] = found ? p2 : pos[u];
+                sxy[u] = found ? fxy[u] : sxy[u];
             }
         }
     }

@@ -620,27 +620,66 @@ __device__ inline void contour_stage(const Params& P, const State& S, const Lds&
 // np.sum over the window of np.max(((heightMapT + posZ) * maskH, heightmapC[window]), axis=0)
 // (space.py:213-214) in numpy's own summation order: float64 pairwise sum with eight
 // accumulators per block of <= 128 elements, halves split at multiples of 8 (numpy
-// loops_utils.h.src, @TYPE@_pairwise_sum).  `at(i)` yields element i of the row-major window.
-template <typename F>
-__device__ double np_pairwise_sum(const F& at, int lo, int n) {
+// loops_utils.h.src, @TYPE@_pairwise_sum).  The recursion visits the elements strictly in order, each once, so
+// `next()` is a generator (the caller's cursor over the window) and the recursion an explicit post-order walk
+// of the split tree with its few frames in registers (selected by unrolled compares: a frame is touched once per
+// block of 128 elements).  Until round 5 session 37 this was a recursive device function -- 784 bytes of stack per
+// lane -- over an `at(i)` that divided i by the window's width and searched the masked-in list by bisection for every
+// element.
+template <typename G>
+__device__ __forceinline__ double np_sum_block(G& next, int n) {               // n <= 128
     if (n < 8) {
         double res = 0.0;
-        for (int i = 0; i < n; ++i) res += at(lo + i);
+        for (int i = 0; i < n; ++i) res += next();
         return res;
     }
-    if (n <= 128) {
-        double r[8];
-        for (int k = 0; k < 8; ++k) r[k] = at(lo + k);
-        int i = 8;
-        for (; i < n - (n % 8); i += 8)
-            for (int k = 0; k < 8; ++k) r[k] += at(lo + i + k);
-        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
-        for (; i < n; ++i) res += at(lo + i);
-        return res;
+    double r[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[k] = next();
+    int i = 8;
+    for (; i < n - (n % 8); i += 8)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) r[k] += next();
+    double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+    for (; i < n; ++i) res += next();
+    return res;
+}
+template <typename G>
+__device__ __forceinline__ double np_pairwise_sum(G& next, int n) {
+    constexpr int DEPTH = 10;                          // 128 << 9 elements: far beyond any window (64 x 64 cells: depth 6)
+    int fn[DEPTH], phase[DEPTH];                       // frame d: elements of its subtree; 0 = entered, 1 = left half done, 2 = both
+    double left[DEPTH];
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) { fn[d] = 0; phase[d] = 0; left[d] = 0.0; }
+    fn[0] = n;
+    int sp = 0;
+    double ret = 0.0;
+    while (sp >= 0) {
+        int cn = 0, cp = 0;
+        double cl = 0.0;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) if (d == sp) { cn = fn[d]; cp = phase[d]; cl = left[d]; }
+        if (cp == 0 && (cn <= 128 || sp == DEPTH - 1)) {                     // a leaf (the depth bound is never reached: see DEPTH)
+            ret = np_sum_block(next, cn);
+            --sp;
+            continue;
+        }
+        int n2 = cn / 2;
+        n2 -= n2 % 8;
+        if (cp == 2) {                                                       // S(left) + S(right)
+            ret = cl + ret;
+            --sp;
+            continue;
+        }
+        const int child = cp == 0 ? n2 : cn - n2;
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (d == sp) { phase[d] = cp + 1; if (cp == 1) left[d] = ret; }
+            if (d == sp + 1) { fn[d] = child; phase[d] = 0; }
+        }
+        ++sp;
     }
-    int n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise_sum(at, lo, n2) + np_pairwise_sum(at, lo + n2, n - n2);
+    return ret;
 }
 
 // Space.get_heuristic_action (space.py:162-218) for one action cell; invalid cells score 1e6.
@@ -658,24 +697,24 @@ __device__ inline double heuristic_score(const Params& P, const Tables& T, const
         default: {                                                           // HM
             score = (cx + cy) * P.res_a;
             const Cell* top = T.tcell + sr.ot;
-            // dense row-major walk over the fx x fy window; the compact top list is in the same order
-            auto at = [&](int e) -> double {
-                const int i = e / sr.fy, j = e - i * sr.fy;
+            // dense row-major walk over the fx x fy window; the compact top list (masked-in cells, `pad` = row-major index
+            // in the window) is in the same order: one cursor over it
+            const int fy = sr.fy, nt = sr.nt;
+            int e = 0, i = 0, j = 0, cur = 0;
+            int next_in = nt > 0 ? top[0].pad : -1;                          // window index of the next masked-in cell
+            auto next = [&]() -> double {
                 const double h = L.hm[tile_rc(P, X * P.step + i, Y * P.step + j)];
-                // binary search of the masked-in list for this offset's row-major rank
-                int lo = 0, hi = sr.nt - 1;
                 double v = 0.0;                                             // (T + z) * 0 for masked-out cells
-                bool in = false;
-                while (lo <= hi) {
-                    const int mid = (lo + hi) >> 1;
-                    const int oi = top[mid].pad;                            // row-major index of the list entry
-                    if (oi == e) { v = top[mid].v + z; in = true; break; }
-                    if (oi < e) lo = mid + 1; else hi = mid - 1;
+                if (e == next_in) {
+                    v = top[cur].v + z;
+                    ++cur;
+                    next_in = cur < nt ? top[cur].pad : -1;
                 }
-                (void)in;
+                ++e;
+                if (++j == fy) { j = 0; ++i; }
                 return fmax(v, h);
             };
-            score += np_pairwise_sum(at, 0, sr.fx * sr.fy) * 100.0;
+            score += np_pairwise_sum(next, sr.fx * sr.fy) * 100.0;
         }
     }
     return round6(score);

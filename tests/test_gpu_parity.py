@@ -505,6 +505,39 @@ def test_heuristic_actions_match_oracle():
     genv.close()
 
 
+def test_heuristic_hm_sums_large_windows_in_numpys_order():
+    """HM on the 64 x 64 heightmap of BASELINE config 5 with its largest items first: windows of up to 56 x 56 = 3136 cells, i.e.
+    numpy's pairwise sum five splits deep (the kernel walks that tree with an explicit stack and one cursor over the masked-in
+    cells), on heightmaps that are no longer flat."""
+    from bench import make_workload
+    sh, _, kw = make_workload("abc_fine")
+    size = [max(np.asarray(t[r][0]).size for r in range(len(t))) for t in sh.tables]
+    big = np.argsort(size)[::-1][:12]
+    assert size[big[0]] > 2048 and size[big[5]] > 1024
+    seqs = np.stack([np.resize(np.roll(big, k), 40) for k in range(4)]).astype(np.int32)
+    n = 2
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, **kw)
+    oenv = OracleVecEnv(n, sh, seqs, **kw)
+    gobs = genv.reset()
+    oenv.reset()
+    asked = 0
+    for t in range(4):
+        for d in (0, 3):
+            got = genv.env.heuristic_action("HM", d).cpu().numpy()
+            for i, e in enumerate(oenv.envs):
+                if e.space.naiveMask.sum() == 0:
+                    continue
+                ref = e.space.get_heuristic_action("HM", e.next_item_ID, d)
+                assert tuple(got[i]) == tuple(int(v) for v in ref), (t, d, i)
+                asked += 1
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        gobs, _, _, _ = genv.step(act)
+        oobs, _, _, _ = oenv.step(act)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs))
+    genv.close()
+    assert asked >= 8
+
+
 @pytest.mark.parametrize("tag", ["general", "blockout"])
 def test_heuristic_actions_match_reference_golden(golden_dir, tag):
     """irbpp_heuristic_action against what the reference's own Space.get_heuristic_action (space.py:162-218) returned

@@ -64,6 +64,7 @@ def test_scratch_of_the_step_kernels_stays_where_it_was_measured():
               # its early return (bins that need the workgroup: more than S candidates), around the loop over those bins
               "irbpp_emit_wave_kernel": 216, "irbpp_emit_wave_kernel_s1": 152, "irbpp_emit_wave_kernel_s2": 108,
               "irbpp_env_kernel_generic_w512": 0, "irbpp_env_kernel_s4_w512": 0, "irbpp_env_kernel_s4_w512c": 16,
+              "irbpp_heuristic_kernel": 32,          # (784 until round 5 session 37: the recursion of numpy's pairwise sum)
               "irbpp_env_kernel_wide": 36}           # (_wide: the A/B build that decides the overlap path at run time; not a default)
     for kernel, limit in limits.items():
         assert kernel in sizes, kernel
