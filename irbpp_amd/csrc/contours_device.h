@@ -755,7 +755,9 @@ __device__ inline void approx_convex_segmented(int lane, const bool (&live)[P], 
             t += t < 0 ? n[u] : 0;
             const int dx = px[u] - IRBPP_PX(sxy[u]), dy = py[u] - IRBPP_PY(sxy[u]);
             const uint32_t key = ((uint32_t)(dx * dx + dy * dy) << 16) | ((uint32_t)(255 - t) << 8) | (uint32_t)pv[u];
-            atomicMax(&slots[sb[u]], live[u] && t >= 1 ? key : 0u);
+            const bool bids = live[u] && t >= 1;
+            atomicMax(&slots[bids ? sb[u] : u * 64 + lane], bids ? key : 0u);      // (no bid: 0 at the position's OWN word -- the empty
+                                                                                  //  positions of a round all sending to word 0 were serialised there)
         }
         IRBPP_WAVE_SYNC();
         uint32_t best[P];
