@@ -387,6 +387,9 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl is RCCL on ROCm "
                     "(gloo + several ranks on one device is only for dry runs of the multi-rank path)")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="create the torch.distributed process group even for ONE rank, so that the timed loop's barrier / "
+                         "agreement and the final all-reduce run through the backend (RCCL) on a one-GPU box")
     a = ap.parse_args()
 
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -417,7 +420,7 @@ def main():
     if a.backend == "nccl" and n_dev < world:
         raise SystemExit(f"--gpus {world} needs {world} visible GPUs, this node shows {n_dev} "
                          "(--backend gloo runs several ranks on one device as a dry run only)")
-    rank, world, local_rank = D.init_from_env(a.backend)    # nccl == RCCL on ROCm
+    rank, world, local_rank = D.init_from_env(a.backend, force=a.force_process_group)    # nccl == RCCL on ROCm
     if a.backend != "nccl":
         local_rank %= max(1, n_dev)                        # dry run: ranks may share a device
     torch.cuda.set_device(local_rank)
@@ -446,6 +449,8 @@ def main():
     my_elapsed, timed_steps, kernel_ms, finished = timed_run(env, a, dev, k, barrier, a.steps, a.prefill, a.warmup,
                                                              a.min_seconds, agree)
     lds_bytes, kernel_name = env.groups[0].kernel_info()
+    from irbpp_amd.vec_env import group_stream_report
+    probe = group_stream_report(dev)           # what the stream probe behind groups_for saw in this process
     elapsed = D.max_over_ranks(my_elapsed, dev)
     fastest = -D.max_over_ranks(-my_elapsed, dev)
     finished = float(D.reduce_totals(torch.tensor([finished, 0, 0, 0], dtype=torch.float64, device=dev))[0].item())
@@ -481,6 +486,8 @@ def main():
         if workload == "blockout":
             def recommended(wl, nb):
                 return side_run(wl, nb, groups_for(wl, nb, device=dev))
+            # round-over-round comparable: the definition `value` had until round 4 (configs[1] to the letter, ONE launch group)
+            extra["cfg2_4096_one_group"] = side_run("blockout", 4096, 1)
             if bins != 4096:
                 extra["bins4096_one_gpu"] = recommended("blockout", 4096)     # BASELINE configs[1] at its own size
             if bins != 8192:
@@ -515,8 +522,10 @@ def main():
                                    f"resolutionH={kw['resolutionH']}, R={shapes.n_rot}, S={S}, scripted MINZ policy"
                                    + (f", stepped as {groups} groups of bins on {groups} HIP streams (vec_env.groups_for)" if groups > 1 else ""),
                        "baseline_config": a.config, "bins_per_gpu": bins, "global_bins": bins * world,
-                       "parallelism": f"bins sharded x{world}", "groups_per_gpu": groups},
-            "ranks": {"world_size": world, "backend": a.backend if world > 1 else None, "devices": devices,
+                       "parallelism": f"bins sharded x{world}", "groups_per_gpu": groups,
+                       "group_stream_probe": probe},
+            "ranks": {"world_size": world, "backend": a.backend if dist.is_initialized() else None,
+                      "process_group": bool(dist.is_initialized()), "devices": devices,
                       "ms_per_step_min": fastest / timed_steps * 1e3, "ms_per_step_max": elapsed / timed_steps * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
@@ -535,12 +544,15 @@ def main():
             out["roofline"]["traffic_note"] = why
         if issue is not None:
             out["roofline"]["issue"] = issue       # the kernel is instruction-issue bound, not HBM bound: SQ busy shares
+        out["value_definition"] = f"{workload}, {bins} bins/GPU x {world} GPU(s), stepped as {groups} group(s) per GPU"
+        if extra and "cfg2_4096_one_group" in extra:
+            out["value_cfg2_one_group"] = extra["cfg2_4096_one_group"]["value"]     # stable key: 4096 BlockOut bins, one launch group
         if extra:
             out["extra"] = extra
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

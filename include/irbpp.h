@@ -276,6 +276,8 @@ int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* pos
 
 /* Space.heightmapC of every bin (space.py:26): float64[num_bins][Hx][Hy]. */
 int irbpp_get_heightmaps(irbpp_env* env, double* hm_dev, void* stream);
+/* (the drop heights a step takes from the last observation are forgotten with the old maps: a step that follows
+ * irbpp_set_heightmaps without a new observation recomputes its drop height on the new map) */
 int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream);
 
 /* Running totals over finished episodes since create/reset, for logging
@@ -370,6 +372,9 @@ int irbpp_device_error(irbpp_env* env, void* stream, int32_t* flags_out);
 #define IRBPP_DEVERR_BAD_BIN       8   /* irbpp_reset_bins: bin index outside [0, num_bins)  */
 #define IRBPP_DEVERR_CAPACITY     16   /* a die's candidate list overflowed (it holds twice the worst case of a fair
                                           share of the bins): results of that step are incomplete                */
+#define IRBPP_DEVERR_BAD_ACTION   64   /* irbpp_step / irbpp_get_action_candidates: an action outside [-S, S) (order action: [-k, k)):
+                                          the reference raises IndexError at binPhy.py:235 / :163; a negative index in
+                                          range counts from the end, as there.  The step ran on a clamped index       */
 #define IRBPP_DEVERR_STREAM_DRY   32   /* item_stream = 1: a bin fetched a ring slot it had consumed already and the host
                                           had not rewritten (irbpp_stream_write): its episode got no item there  */
 

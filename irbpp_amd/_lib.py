@@ -102,6 +102,7 @@ def load(path: str = "") -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    explicit = bool(path) or bool(os.environ.get("IRBPP_LIBRARY"))     # a library the caller names is the caller's business
     path = path or os.environ.get("IRBPP_LIBRARY", "") or LIB_PATH
     if not os.path.exists(path):
         raise RuntimeError(
@@ -119,9 +120,13 @@ def load(path: str = "") -> C.CDLL:
     # A binary built from other sources than the ones lying here is refused: every number and every test would be about
     # code nobody is looking at.  (IRBPP_LIBRARY names an A/B variant built with extra flags by tools/build_variant.sh: its
     # stamp is its own business.)
-    if not os.environ.get("IRBPP_LIBRARY") and not os.environ.get("IRBPP_ALLOW_STALE_LIBRARY"):
+    if not explicit and not os.environ.get("IRBPP_ALLOW_STALE_LIBRARY"):
         from . import build
-        have, want = lib.irbpp_source_hash().decode(), build.source_hash()
+        have = lib.irbpp_source_hash().decode()
+        try:
+            want = build.source_hash()
+        except OSError:                     # an installed copy without csrc/ next to it: nothing to compare the stamp with
+            want = have
         if have != want:
             raise RuntimeError(
                 f"{path} was built from sources {have}, the sources in {build.CSRC} hash to {want}: rebuild with "
@@ -132,6 +137,14 @@ def load(path: str = "") -> C.CDLL:
 
 class IrbppError(RuntimeError):
     pass
+
+
+DEVERR_BITS = {1: "LEVEL_RANGE", 2: "TRACE_GUARD", 4: "BAD_ITEM", 8: "BAD_BIN", 16: "CAPACITY", 32: "STREAM_DRY", 64: "BAD_ACTION"}
+
+
+def deverr_names(flags: int) -> str:
+    """IRBPP_DEVERR_* names of a device error word (include/irbpp.h)."""
+    return "|".join(name for bit, name in DEVERR_BITS.items() if flags & bit) or "0"
 
 
 def check(status: int, what: str = "") -> None:

@@ -134,7 +134,7 @@ const char* irbpp_status_string(int status) {
     }
 }
 
-int irbpp_version(void) { return 500; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen; 5xx: source hash, overlap path, specialised builds
+int irbpp_version(void) { return 600; }      // 3xx: irbpp_config::tuning / item_stream, unregister / invalidate_obs_buffer, stream ring, itemgen; 5xx: source hash, overlap path, specialised builds
 
 #ifndef IRBPP_SOURCE_HASH
 #define IRBPP_SOURCE_HASH "unstamped"
@@ -658,6 +658,12 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
 // step never repeats one and is launched directly.  Everything issued while the caller's stream is itself being captured
 // is launched directly too (into the caller's capture).
 constexpr int GRAPH_CACHE = 24;
+// A captured graph holds Params / Tables / State BY VALUE in its kernel nodes: every setter that changes one of them after
+// graphs may exist (the placement log's pointers, a tooling switch) drops the cache; the next launches capture again.
+static void drop_graphs(irbpp_env* env) {
+    for (auto& g : env->graphs) { if (g.exec) hipGraphExecDestroy(g.exec); if (g.graph) hipGraphDestroy(g.graph); }
+    env->graphs.clear();
+}
 static bool graph_wanted(const irbpp_env* env, int) { return (env->cfg.tuning & IRBPP_TUNE_GRAPH) != 0; }
 
 static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int grid = 0) {
@@ -920,6 +926,9 @@ int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream) {
     if (!env || !hm_dev) return IRBPP_ERR_ARG;
     HIP_TRY(hipMemcpyAsync(env->S.hm, hm_dev, (size_t)env->P.N * env->P.Hc * sizeof(double), hipMemcpyDeviceToDevice,
                            (hipStream_t)stream));
+    // the drop heights of the last observation (w_posz, marked by w_valid) belong to the OLD maps: a step that follows
+    // without a new observation recomputes its drop height from the footprint's bottom cells instead
+    HIP_TRY(hipMemsetAsync(env->S.w_valid, 0, (size_t)env->P.N * env->P.R * 16 * sizeof(uint32_t), (hipStream_t)stream));
     return IRBPP_OK;
 }
 
@@ -931,6 +940,7 @@ int irbpp_episode_totals(irbpp_env* env, double* out_dev, void* stream) {
 
 int irbpp_set_placement_log(irbpp_env* env, uint32_t* meta_dev, double* z_dev, int32_t capacity) {
     if (!env || capacity < 0 || ((meta_dev == nullptr) != (z_dev == nullptr))) return IRBPP_ERR_ARG;
+    drop_graphs(env);                      // (captured kernel nodes carry State by value)
     env->S.log_meta = meta_dev;
     env->S.log_z = z_dev;
     env->S.log_cap = meta_dev ? capacity : 0;
@@ -994,6 +1004,7 @@ int irbpp_replay_gather(const irbpp_replay_view* v, int32_t draws, float beta, c
 
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
+    drop_graphs(env);
     env->phase_cycles = (long long*)cycles_dev;
     return IRBPP_OK;
 }

@@ -2426,7 +2426,10 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         if (ob_staged && tid < P.R * SRW_) L.sr[tid] = ((const int*)(T.sr + (size_t)ob_item * P.R))[tid];
     }
     if (FUSED && mode == MODE_STEP) {                 //   the overlap test.  round 2: candidate key, the next item of the trajectory,
-        st_a = st_a < 0 ? 0 : (st_a >= P.S ? P.S - 1 : st_a);            //   and those ShapeRots (one dword per thread, coalesced)
+        // candidates[action] (binPhy.py:235): a negative index counts from the end, anything else outside [0, S) is the
+        // reference's IndexError -- here IRBPP_DEVERR_BAD_ACTION (the step then uses a clamped index: results are void)
+        st_a += st_a < 0 ? P.S : 0;                                        //   and those ShapeRots (one dword per thread, coalesced)
+        if (st_a < 0 || st_a >= P.S) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ACTION); st_a = st_a < 0 ? 0 : P.S - 1; }
         st_key = st_a < st_nrows ? S.cand[(size_t)b * P.S + st_a] : 0u;     // rows beyond the last are zeros
         if (P.K == 1) {
             const int at = T.stream ? (int)((uint32_t)st_cursor % (uint32_t)T.seq_len) : st_cursor;
@@ -2446,7 +2449,8 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         debug_out = true;
     } else if (mode == MODE_CANDS) {     // PackingGame.get_action_candidates (binPhy.py:161-169)
         int oa = io.actions[b];
-        oa = oa < 0 ? 0 : (oa >= P.K ? P.K - 1 : oa);
+        oa += oa < 0 ? P.K : 0;                  // next_k_item_ID[orderAction] (binPhy.py:163): a list index
+        if (oa < 0 || oa >= P.K) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ACTION); oa = oa < 0 ? 0 : P.K - 1; }
         obs_item = q[oa];
         if (tid == 0) S.bs[b].order_action = oa;
     } else if (mode == MODE_OBSERVE) {   // cur_observation of the item the split step left at the head of the queue
@@ -2714,7 +2718,8 @@ __device__ __forceinline__ void apply_body(const Params& P, const Tables& T, con
     const int cursor = ps0->cursor, trow = ps0->traj_row;
     // round 2: candidate key; ALL rotations' ShapeRots of the placed item, sixteen bytes per lane (R x 112 bytes are
     // contiguous), so that the one the key names needs no round trip of its own; its volume; the next item of the trajectory
-    a = a < 0 ? 0 : (a >= P.S ? P.S - 1 : a);
+    a += a < 0 ? P.S : 0;                                            // candidates[action] (binPhy.py:235): a negative index counts from the end
+    if (a < 0 || a >= P.S) { if (lane == 0) raise_error(S, IRBPP_DEVERR_BAD_ACTION); a = a < 0 ? 0 : P.S - 1; }   // the reference's IndexError
     const uint32_t key = (uint32_t)__builtin_amdgcn_readfirstlane(a < nrows ? (int)S.cand[(size_t)b * P.S + a] : 0);   // action_to_position (:234-236)
     int nxt = -2;
     if (P.K == 1) {

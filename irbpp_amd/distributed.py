@@ -13,13 +13,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str = "nccl"):
+def init_from_env(backend: str = "nccl", force: bool = False):
     """(rank, world, local_rank) from the torchrun environment; initialises the process group
-    when WORLD_SIZE > 1."""
+    when WORLD_SIZE > 1 -- or, with ``force``, also for a single rank, so that every collective below runs through the
+    backend's communicator (RCCL with one rank: the multi-rank code path of bench.py on a one-GPU box)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         dist.init_process_group(backend, rank=rank, world_size=world)
@@ -33,7 +34,8 @@ def shard(rank: int, world: int, bins_per_rank: int):
 
 
 def _active() -> bool:
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """a process group exists (one rank only if init_from_env was forced: the collectives then still go through the backend)"""
+    return dist.is_available() and dist.is_initialized()
 
 
 def _all_reduce(t: torch.Tensor, op) -> torch.Tensor:
@@ -67,7 +69,10 @@ def barrier(device=None):
     if on_gpu:
         torch.cuda.synchronize(device)
     if _active():
-        dist.barrier()
+        if on_gpu and dist.get_backend() == "nccl":
+            dist.barrier(device_ids=[torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()])
+        else:
+            dist.barrier()
     if on_gpu:
         torch.cuda.synchronize(device)
 

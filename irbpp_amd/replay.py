@@ -37,6 +37,9 @@ def _p(t: Optional[torch.Tensor]):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+_WARNED_TORCH_PATH = False
+
+
 def _stream(device):
     return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
@@ -71,6 +74,15 @@ class VectorReplayMemory(object):
         if use_hip and self._lib is None:
             raise RuntimeError("use_hip=True needs a HIP device")
         if self._lib is not None and 2 * cap - 1 > 16384:
+            # said once per process, not silently: every sum-tree call of this memory is torch indexing from here on
+            if use_hip:
+                raise RuntimeError(f"use_hip=True: a sum tree of {2 * cap - 1} floats per env exceeds the HIP kernels' LDS row (16384)")
+            global _WARNED_TORCH_PATH
+            if not _WARNED_TORCH_PATH:
+                import warnings
+                warnings.warn(f"VectorReplayMemory: capacity {cap} per env (tree row of {2 * cap - 1} floats) exceeds the HIP sum-tree "
+                              "kernels' LDS row of 16384 floats: using the torch formulation (several launches per call)", RuntimeWarning)
+                _WARNED_TORCH_PATH = True
             self._lib = None
 
     # ------------------------------------------------------------------ sum tree ------------

@@ -286,7 +286,7 @@ class GpuPackingEnv(object):
     def check_device_error(self) -> None:
         flags = C.c_int32(0)
         _lib.check(self.lib.irbpp_device_error(self._h, self._stream(), C.byref(flags)),
-                   f"device error flags={flags.value}")
+                   f"device error flags={flags.value} ({_lib.deverr_names(flags.value)})")
 
     def step_info_host(self):
         """ONE pinned asynchronous D2H copy of the small per-step outputs + the device error word, then one
@@ -308,7 +308,7 @@ class GpuPackingEnv(object):
         h = self._out_host.numpy().copy()
         err = int(h[-4:].view(np.int32)[0])
         if err:
-            raise _lib.IrbppError(f"device error flags={err}: " + _lib.load().irbpp_status_string(-4).decode())
+            raise _lib.IrbppError(f"device error flags={err} ({_lib.deverr_names(err)}): " + _lib.load().irbpp_status_string(-4).decode())
         f64 = h[:24 * n].view(np.float64).reshape(3, n)
         i32 = h[24 * n:32 * n].view(np.int32).reshape(2, n)
         return dict(reward=f64[0], ratio=f64[1], ep_reward=f64[2], counter=i32[0], ep_len=i32[1],
@@ -486,6 +486,16 @@ class GroupedPackingEnv(object):
 
 
 _STREAM_PAIRS = {}
+_STREAM_PROBE = {}           # what the probe saw (pair / single time of every candidate tried): group_stream_report()
+
+
+def group_stream_report(device) -> dict:
+    """The outcome of this process's stream probe on ``device`` (bench.py prints it next to `value`): streams checked to overlap,
+    candidates tried, the pair / single spin-kernel time ratios measured (< 1.5 = side by side)."""
+    device = torch.device(device)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    chosen, tried = _STREAM_PAIRS.get(key, ([], [0]))
+    return {"overlapping_streams": len(chosen), "candidates_tried": tried[0], "pair_over_single": list(_STREAM_PROBE.get("ratios", []))}
 
 
 def _run_side_by_side(a, b, device, cycles=1_500_000) -> bool:
@@ -507,9 +517,15 @@ def _run_side_by_side(a, b, device, cycles=1_500_000) -> bool:
         return time.perf_counter() - t0
 
     timed([a, b])                                      # (first launches on a stream pay for its set-up)
-    single = min(timed([a]) for _ in range(2))
-    pair = min(timed([a, b]) for _ in range(2))
-    return pair < 1.5 * single
+    ratio = 0.0
+    for _ in range(3):                                 # a busy device can make one measurement look shared: ask again before rejecting
+        single = min(timed([a]) for _ in range(2))
+        pair = min(timed([a, b]) for _ in range(2))
+        ratio = pair / single if single > 0 else 2.0
+        if ratio < 1.5:
+            break
+    _STREAM_PROBE.setdefault("ratios", []).append(round(ratio, 3))
+    return ratio < 1.5
 
 
 def group_streams(device, count: int = 2):
@@ -559,7 +575,8 @@ def groups_for(workload_kind: str, num_bins: int, buffered: bool = False, device
     42.4 -> 48.4 M, at 4096 bins 34.1 -> 37.8 M and at 2048 bins 24.5 -> 26.6 M -- but at 1024 bins (BASELINE config 4 per GPU) level at best (15.3 M; figures of session 12, before the buffered step became an apply kernel): a
     chain of short latency-bound launches whose length does not depend on the number of bins.  More than two groups are not
     recommended: their streams come from torch's pool and share hardware queues as the runtime sees fit (BlockOut 8192 bins
-    as four groups: 43.7 / 30 M); ``irbpp_amd.use_hardware_queues`` remains for callers who manage their own streams.
+    as four groups: 43.7 / 30 M).  A caller with a preference passes ``num_groups`` itself (GpuVecEnv, GroupedPackingEnv,
+    ``bench.py --groups``).
 
     ``workload_kind``: "general" / "abc_fine" (free-form cell lists, the generic overlap path) or anything else (lattice /
     box data); ``buffered``: bufferSize > 1 (also recognised from a kind that ends in "_k<digits>"); ``device``: if given,

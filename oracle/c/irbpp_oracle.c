@@ -47,7 +47,8 @@ typedef struct {
     double *cand;                            /* [S][5] */
     int item_idx;
     int packed_ids[1024];
-    double *pool;                            /* copies of all tables */
+    double *pool;                            /* copies of all tables (NULL: borrowed from the caller, orc_create_borrowed) */
+    int borrowed;                            /* tables and trajectories belong to the caller and outlive the handle */
 } orc_env;
 
 static double round6(double x) { return nearbyint(x * 1e6) / 1e6; }
@@ -312,11 +313,12 @@ static void cur_observation(orc_env *e, int gen_item, double *obs) {
 }
 
 /* ---------------------------------------------------------------- public API */
-orc_env *orc_create(int R, int S, int K, double resA, double resH, double resZ, const double *bin, double scale_z,
-                    int n_shapes, const double *extents, const double *volumes, const int *dims,
-                    const int64_t *offsets, int64_t pool_len, const double *T, const double *B, const double *mH,
-                    const double *mB, const int *seq, int n_traj, int seq_len, int first_traj, int stride) {
+static orc_env *create_env(int R, int S, int K, double resA, double resH, double resZ, const double *bin, double scale_z,
+                           int n_shapes, const double *extents, const double *volumes, const int *dims,
+                           const int64_t *offsets, int64_t pool_len, const double *T, const double *B, const double *mH,
+                           const double *mB, const int *seq, int n_traj, int seq_len, int first_traj, int stride, int borrowed) {
     orc_env *e = calloc(1, sizeof(orc_env));
+    e->borrowed = borrowed;
     e->R = R; e->S = S; e->K = K; e->resA = resA; e->resH = resH; e->resZ = resZ; e->scale_z = scale_z;
     for (int i = 0; i < 3; ++i) e->bin[i] = bin[i];
     e->bin_vol = bin[0] * bin[1] * bin[2];
@@ -325,23 +327,30 @@ orc_env *orc_create(int R, int S, int K, double resA, double resH, double resZ, 
     e->Hx = (int)ceil(bin[0] / resH); e->Hy = (int)ceil(bin[1] / resH);
     e->Ax = (int)ceil(bin[0] / resA); e->Ay = (int)ceil(bin[1] / resA);
     e->n_shapes = n_shapes;
-    e->pool = malloc(sizeof(double) * 4 * pool_len);
-    memcpy(e->pool, T, sizeof(double) * pool_len);
-    memcpy(e->pool + pool_len, B, sizeof(double) * pool_len);
-    memcpy(e->pool + 2 * pool_len, mH, sizeof(double) * pool_len);
-    memcpy(e->pool + 3 * pool_len, mB, sizeof(double) * pool_len);
+    if (!borrowed) {
+        e->pool = malloc(sizeof(double) * 4 * pool_len);
+        memcpy(e->pool, T, sizeof(double) * pool_len);
+        memcpy(e->pool + pool_len, B, sizeof(double) * pool_len);
+        memcpy(e->pool + 2 * pool_len, mH, sizeof(double) * pool_len);
+        memcpy(e->pool + 3 * pool_len, mB, sizeof(double) * pool_len);
+        T = e->pool; B = e->pool + pool_len; mH = e->pool + 2 * pool_len; mB = e->pool + 3 * pool_len;
+    }
     e->tab = calloc((size_t)n_shapes * R, sizeof(orc_table));
     for (int i = 0; i < n_shapes * R; ++i) {
         orc_table *t = &e->tab[i];
         t->fx = dims[2 * i]; t->fy = dims[2 * i + 1];
         for (int k = 0; k < 3; ++k) t->ext[k] = extents[3 * i + k];
-        t->T = e->pool + offsets[i]; t->B = e->pool + pool_len + offsets[i];
-        t->mH = e->pool + 2 * pool_len + offsets[i]; t->mB = e->pool + 3 * pool_len + offsets[i];
+        t->T = T + offsets[i]; t->B = B + offsets[i];
+        t->mH = mH + offsets[i]; t->mB = mB + offsets[i];
     }
     e->volume = malloc(sizeof(double) * n_shapes);
     memcpy(e->volume, volumes, sizeof(double) * n_shapes);
-    e->seq = malloc(sizeof(int) * (size_t)n_traj * seq_len);
-    memcpy(e->seq, seq, sizeof(int) * (size_t)n_traj * seq_len);
+    if (borrowed) {
+        e->seq = (int *)seq;
+    } else {
+        e->seq = malloc(sizeof(int) * (size_t)n_traj * seq_len);
+        memcpy(e->seq, seq, sizeof(int) * (size_t)n_traj * seq_len);
+    }
     e->n_traj = n_traj; e->seq_len = seq_len; e->stride = stride; e->traj_index = (long)first_traj - stride;
     e->hm = calloc((size_t)e->Hx * e->Hy, sizeof(double));
     e->cand = calloc((size_t)S * 5, sizeof(double));
@@ -349,9 +358,28 @@ orc_env *orc_create(int R, int S, int K, double resA, double resH, double resZ, 
     return e;
 }
 
+orc_env *orc_create(int R, int S, int K, double resA, double resH, double resZ, const double *bin, double scale_z,
+                    int n_shapes, const double *extents, const double *volumes, const int *dims,
+                    const int64_t *offsets, int64_t pool_len, const double *T, const double *B, const double *mH,
+                    const double *mB, const int *seq, int n_traj, int seq_len, int first_traj, int stride) {
+    return create_env(R, S, K, resA, resH, resZ, bin, scale_z, n_shapes, extents, volumes, dims, offsets, pool_len, T, B, mH, mB,
+                      seq, n_traj, seq_len, first_traj, stride, 0);
+}
+
+/* The same environment on tables and trajectories that stay the CALLER's (read-only, alive until orc_destroy): thousands
+ * of bins of one data set share one copy (the 64 x 64 data set's tables are 54 MB). */
+orc_env *orc_create_borrowed(int R, int S, int K, double resA, double resH, double resZ, const double *bin, double scale_z,
+                             int n_shapes, const double *extents, const double *volumes, const int *dims,
+                             const int64_t *offsets, int64_t pool_len, const double *T, const double *B, const double *mH,
+                             const double *mB, const int *seq, int n_traj, int seq_len, int first_traj, int stride) {
+    return create_env(R, S, K, resA, resH, resZ, bin, scale_z, n_shapes, extents, volumes, dims, offsets, pool_len, T, B, mH, mB,
+                      seq, n_traj, seq_len, first_traj, stride, 1);
+}
+
 void orc_destroy(orc_env *e) {
     if (!e) return;
-    free(e->pool); free(e->tab); free(e->volume); free(e->seq); free(e->hm); free(e->cand); free(e);
+    if (!e->borrowed) { free(e->pool); free(e->seq); }
+    free(e->tab); free(e->volume); free(e->hm); free(e->cand); free(e);
 }
 
 int orc_obs_len(const orc_env *e, int which) {
@@ -432,3 +460,46 @@ void orc_get_grids(const orc_env *e, double *posz, double *mask) {
 }
 void orc_get_heightmap(const orc_env *e, double *hm) { memcpy(hm, e->hm, sizeof(double) * e->Hx * e->Hy); }
 void orc_set_heightmap(orc_env *e, const double *hm) { memcpy(e->hm, hm, sizeof(double) * e->Hx * e->Hy); }
+
+/* ---------------------------------------------------------------- many bins per call (parity runs at thousands of bins)
+ * The same calls for n independent handles, dealt to `threads` host threads (joined before returning: nothing outlives
+ * the call), results written straight into the caller's [n][obs_len] block.  orc_step_many applies the worker's
+ * auto-reset (shmem_vec_env.py:141-144): a finished bin's row holds the next episode's first observation. */
+#include <pthread.h>
+typedef struct {
+    orc_env **envs; int lo, hi, what; const int *arg; double *obs; size_t stride; double *rew; int *done, *counter; double *ratio;
+} orc_job;
+static void *orc_job_run(void *p) {
+    orc_job *j = p;
+    for (int i = j->lo; i < j->hi; ++i) {
+        double *o = j->obs + (size_t)i * j->stride;
+        if (j->what == 0) orc_reset(j->envs[i], o);
+        else if (j->what == 1) orc_get_action_candidates(j->envs[i], j->arg[i], o);
+        else {
+            j->done[i] = orc_step(j->envs[i], j->arg[i], o, &j->rew[i], &j->counter[i], &j->ratio[i]);
+            if (j->done[i]) orc_reset(j->envs[i], o);
+        }
+    }
+    return NULL;
+}
+static void orc_many(orc_env **envs, int n, int threads, int what, const int *arg, double *obs, size_t stride, double *rew,
+                     int *done, int *counter, double *ratio) {
+    if (threads < 1) threads = 1;
+    if (threads > 64) threads = 64;
+    if (threads > n) threads = n > 0 ? n : 1;
+    orc_job jobs[64]; pthread_t tid[64];
+    for (int t = 0; t < threads; ++t) {
+        jobs[t] = (orc_job){envs, (int)((long)n * t / threads), (int)((long)n * (t + 1) / threads), what, arg, obs, stride, rew, done, counter, ratio};
+        if (t > 0 && pthread_create(&tid[t], NULL, orc_job_run, &jobs[t]) != 0) { orc_job_run(&jobs[t]); tid[t] = 0; }
+    }
+    orc_job_run(&jobs[0]);
+    for (int t = 1; t < threads; ++t) if (tid[t]) pthread_join(tid[t], NULL);
+}
+void orc_reset_many(orc_env **envs, int n, int threads, double *obs, long stride) { orc_many(envs, n, threads, 0, NULL, obs, (size_t)stride, NULL, NULL, NULL, NULL); }
+void orc_get_action_candidates_many(orc_env **envs, int n, int threads, const int *order_actions, double *obs, long stride) {
+    orc_many(envs, n, threads, 1, order_actions, obs, (size_t)stride, NULL, NULL, NULL, NULL);
+}
+void orc_step_many(orc_env **envs, int n, int threads, const int *actions, double *obs, long stride, double *rew, int *done,
+                   int *counter, double *ratio) {
+    orc_many(envs, n, threads, 2, actions, obs, (size_t)stride, rew, done, counter, ratio);
+}

@@ -140,3 +140,31 @@ def test_c_oracle_more_than_S_candidates_and_speed():
         obs, _, _, _ = env.step([minz_action(o, S) for o in obs])
     rate = 400 / (time.perf_counter() - t0)
     assert rate > 500, rate
+
+
+def test_c_oracle_threads_and_shared_tables_change_nothing():
+    """COracleVecEnv deals its bins to host threads inside the C library (orc_*_many) and all bins borrow ONE copy of the
+    tables (orc_create_borrowed): same observations, rewards, done flags and infos as a handle per bin that owns its copy,
+    stepped one by one."""
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    n, k = 12, 3
+    many = COracleVecEnv(n, sh, seqs, threads=5, bufferSize=k, global_offset=7, global_num=40)
+    ones = [CPackingGame(sh, seqs, bufferSize=k, first_traj=1 + 7 + g, traj_stride=40) for g in range(n)]
+    np.testing.assert_array_equal(many.reset(), np.array([e.reset() for e in ones]))
+    ndone = 0
+    for t in range(80):
+        oa = [(3 * i + t) % k for i in range(n)]
+        loc = many.get_action_candidates(oa)
+        np.testing.assert_array_equal(loc, np.array([e.get_action_candidates(a) for e, a in zip(ones, oa)]))
+        act = [minz_action(o.astype(np.float32), S) for o in loc]
+        obs, rew, done, infos = many.step(act)
+        for i, e in enumerate(ones):
+            o, r, d, info = e.step(act[i])
+            assert r == rew[i] and d == done[i]
+            if d:
+                assert info["counter"] == infos[i]["counter"] and info["ratio"] == infos[i]["ratio"]
+                o = e.reset()
+                ndone += 1
+            np.testing.assert_array_equal(obs[i], o)
+    assert ndone >= 3

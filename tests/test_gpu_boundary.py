@@ -284,3 +284,118 @@ def test_num_groups_zero_lets_the_library_choose():
     if seen:
         assert list(lat.env.streams) == list(pair)          # ... the process's one checked pair
     lat.close()
+
+
+@pytest.mark.parametrize("tuning", [0, _lib.TUNE_SPLIT_APPLY])
+def test_action_outside_the_candidate_rows_raises_bad_action(tuning):
+    """candidates[action] (binPhy.py:235): a negative index counts from the end like any numpy index, anything else outside
+    [0, S) is an IndexError in the reference -- IRBPP_DEVERR_BAD_ACTION in the step's error word here, from the fused apply
+    phase and from irbpp_apply_kernel alike; never a silent clamp."""
+    from irbpp_amd.vec_env import GpuPackingEnv
+    sh = synthetic.blockout_shapes(n_shapes=8, n_rot=4, cube=0.06, seed=1)
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 40, seed=2)
+    a, b = (GpuPackingEnv(sh, seqs, 4, device=DEV, tuning=tuning) for _ in range(2))
+    oa, ob = a.reset(), b.reset()
+    act = a.policy_minz(oa)
+    neg = act.clone(); neg[1] = -1                                         # row S - 1: a zero-padded row
+    pos = act.clone(); pos[1] = S - 1
+    ra, rb = a.step(neg), b.step(pos)
+    for x, y in zip(ra, rb):
+        assert torch.equal(x, y)
+    a.step_info_host(); b.step_info_host()                                  # no error so far
+    bad = a.policy_minz(ra[0]); bad[2] = S
+    a.step(bad)
+    with pytest.raises(_lib.IrbppError, match="BAD_ACTION"):
+        a.step_info_host()
+    bad = b.policy_minz(rb[0]); bad[0] = -S - 1
+    b.step(bad)
+    with pytest.raises(_lib.IrbppError, match="flags=64"):
+        b.check_device_error()
+    a.close(); b.close()
+
+
+def test_order_action_outside_the_buffer_raises_bad_action():
+    """next_k_item_ID[orderAction] (binPhy.py:163): a Python list index -- -1 is the last slot, k is an IndexError."""
+    from irbpp_amd.vec_env import GpuPackingEnv
+    sh = synthetic.blockout_shapes(n_shapes=8, n_rot=4, cube=0.06, seed=1)
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 40, seed=2)
+    k = 3
+    env = GpuPackingEnv(sh, seqs, 4, device=DEV, bufferSize=k)
+    env.reset()
+    last = env.get_action_candidates(torch.full((4,), k - 1, dtype=torch.int32, device=DEV)).clone()
+    wrap = env.get_action_candidates(torch.full((4,), -1, dtype=torch.int32, device=DEV))
+    assert torch.equal(last, wrap)
+    env.check_device_error()
+    env.get_action_candidates(torch.tensor([0, k, 0, 0], dtype=torch.int32, device=DEV))
+    with pytest.raises(_lib.IrbppError, match="BAD_ACTION"):
+        env.check_device_error()
+    env.close()
+
+
+def test_step_right_after_set_heightmaps_drops_onto_the_new_map():
+    """irbpp_set_heightmaps forgets the drop heights of the last observation (they belong to the old maps): a step that
+    follows without a new observation recomputes posZmap[rot, lx, ly] on the new map (space.py:118-119)."""
+    from irbpp_amd.vec_env import GpuPackingEnv
+    sh = synthetic.cube_shapes()
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 40, seed=2)
+    for tuning in (0, _lib.TUNE_SPLIT_APPLY):
+        env = GpuPackingEnv(sh, seqs, 3, device=DEV, tuning=tuning)
+        obs = env.reset()
+        item = obs[:, 5 * S].long().cpu().numpy()
+        hm = torch.full((3, 32, 32), 0.05, dtype=torch.float64, device=DEV)
+        hm[1, 0, 0] = 0.11                                                  # bin 1: one tall cell under the footprint
+        env.set_heightmaps(hm)
+        env.step(torch.zeros(3, dtype=torch.int32, device=DEV))            # row 0 of the empty-bin observation: rot 0, cell (0, 0)
+        env.step_info_host()
+        got = env.get_heightmaps().cpu().numpy()
+        for b in range(3):
+            T, _, mH, _ = sh.tables[item[b]][0]
+            fx, fy = T.shape
+            z = 0.11 if b == 1 else 0.05
+            want = hm[b].cpu().numpy().copy()
+            want[:fx, :fy] = np.maximum(want[:fx, :fy], (T + z) * mH)
+            np.testing.assert_array_equal(got[b], want)
+        env.close()
+
+
+def test_graph_replay_follows_the_placement_log():
+    """IRBPP_TUNE_GRAPH: captured kernel nodes carry the placement log's pointers by value, so irbpp_set_placement_log drops
+    the cached graphs -- the log switched off, then moved to new buffers between replays: entries land where the direct
+    launches of a second environment put them, and the old buffers stay as they were."""
+    from irbpp_amd.vec_env import GpuPackingEnv
+    sh = synthetic.blockout_shapes(n_shapes=8, n_rot=4, cube=0.06, seed=1)
+    seqs = synthetic.make_sequences(sh.n_shapes, 16, 40, seed=2)
+    n = 8
+    g = GpuPackingEnv(sh, seqs, n, device=DEV, tuning=_lib.TUNE_GRAPH)
+    d = GpuPackingEnv(sh, seqs, n, device=DEV)
+    bufs = [[torch.empty((n, e.obs_len), dtype=torch.float32, device=DEV) for _ in range(2)] for e in (g, d)]
+    og, od = g.reset(), d.reset()
+    acts = [torch.empty((n,), dtype=torch.int32, device=DEV) for _ in range(2)]
+    t = 0
+
+    def steps(count):
+        nonlocal og, od, t
+        for _ in range(count):
+            a = d.policy_minz(od)
+            for ab in acts:
+                ab.copy_(a)
+            og = g.step(acts[0], obs_out=bufs[0][t & 1])[0]
+            od = d.step(acts[1], obs_out=bufs[1][t & 1])[0]
+            assert torch.equal(og, od)
+            t += 1
+    steps(6)                                                                # (replays from the third step on)
+    lg, ld = g.enable_placement_log(64), d.enable_placement_log(64)
+    steps(6)
+    assert torch.equal(lg[0], ld[0]) and torch.equal(lg[1], ld[1]) and int((ld[0] != 0).sum()) > 0
+    keep = (lg[0].clone(), lg[1].clone())
+    for e in (g, d):
+        _lib.check(e.lib.irbpp_set_placement_log(e._h, None, None, 0), "irbpp_set_placement_log")
+    steps(6)
+    assert torch.equal(lg[0], keep[0]) and torch.equal(lg[1], keep[1])     # switched off: a replay must not write the old buffers
+    ng, nd = g.enable_placement_log(64), d.enable_placement_log(64)
+    steps(6)
+    assert torch.equal(ng[0], nd[0]) and torch.equal(ng[1], nd[1]) and int((nd[0] != 0).sum()) > 0
+    assert torch.equal(lg[0], keep[0])
+    for e in (g, d):
+        e.check_device_error()
+        e.close()

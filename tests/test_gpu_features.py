@@ -245,12 +245,14 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     k = int(kw.get("bufferSize", 1))
     flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
              _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
-             _lib.TUNE_NO_WG512, _lib.TUNE_WG512]          # (256- / 512-thread workgroups of the generic path whatever the data)
+             _lib.TUNE_NO_WG512, _lib.TUNE_WG512,          # (256- / 512-thread workgroups of the generic path whatever the data)
+             _lib.TUNE_NARROW_KERNEL | _lib.TUNE_WG512]    # (the 512-thread build under the 64-VGPR cap: the default from 4096 bins on)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
     assert names[1] == names[4] and "_s" not in names[1].replace("irbpp_env_kernel", ""), names
     assert "w512" not in names[5] and (("w512" in names[6]) == ("generic" in names[4] or "_s3" in names[0] or "_s4" in names[0])), names
+    assert names[7] == ("irbpp_env_kernel_s4_w512c" if workload == "abc_fine" else names[7].replace("w512", "")), names
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)
