@@ -551,9 +551,14 @@ def main():
             out["extra"] = extra
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line is the LAST thing on stdout: librccl announces itself through C stdio ("Librccl path : ..."), which sits
+        # in the C library's buffer until flushed -- at exit, i.e. behind a line Python printed earlier
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -101,6 +101,9 @@ typedef struct {
 #define IRBPP_TUNE_WG512 65536 /* generic overlap path: the transition kernel with 512-thread workgroups (eight waves share a bin's tile)
                                   whatever the LDS per bin; default: where at most four 256-thread workgroups fit a CU's LDS      */
 #define IRBPP_TUNE_NO_WG512 131072 /* ... never                                                                                 */
+#define IRBPP_TUNE_TRACE_REFILL 262144 /* border following in batches of 128 candidate starts per wave whose lanes take the next candidate as
+                                         they close their borders.  Off by default: measured slower at every size (profiles/r06/LOG.md,
+                                         session 2); identical results, parity-tested                                                       */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

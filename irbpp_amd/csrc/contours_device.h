@@ -378,6 +378,104 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
     return !active ? 0 : (isolated ? 1 : result);
 }
 
+// ---------------------------------------------------------------------------------------
+// The same walk once more, cut into START and ONE ITERATION, for the trace kernel's lane-refill form (irbpp_kernels.hip:
+// trace_refill_body): a wave owns a batch of candidate starts and hands a lane the next one as soon as enough lanes have
+// closed their borders, instead of walking until the longest of 64 borders is done (a BlockOut lane walks 9 iterations on
+// average, the longest of 64 takes 34: tools/trace_length_study.py).  Statement for statement the loop body of
+// trace_border_fast; tests/host/ runs both against the oracle on the same images.
+// ---------------------------------------------------------------------------------------
+struct WalkTables { uint32_t DELTA_LO, DELTA_HI, FLAG_LO, FLAG_HI, LSH_LO, LSH_HI, FOFF_LO, FOFF_HI; NbTables NT; };
+struct Walk {
+    int pos, n, result, pos0, pos1;            // current pixel, points so far, points of the closed border (0: none), start, its first neighbour
+    uint32_t nb16, k2, prev, s_close, run;     // neighbour mask (twice), next search direction, last move, closing move, 1 while walking
+};
+#define IRBPP_WALK_TABLES(WT)                                                                                               \
+    WalkTables WT;                                                                                                          \
+    WT.DELTA_LO = 0x00010212u; WT.DELTA_HI = 0x22212010u; WT.FLAG_LO = 0x000b000du; WT.FLAG_HI = 0x00070001u;               \
+    WT.LSH_LO = 0x04000404u; WT.FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16; WT.NT = nb_tables();                            \
+    IRBPP_WALK_PIN(WT)                                                                                                      \
+    WT.LSH_HI = WT.LSH_LO; WT.FOFF_HI = WT.FOFF_LO;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define IRBPP_WALK_PIN(WT)                                                                                                  \
+    asm volatile("" : "+v"(WT.DELTA_LO), "+s"(WT.DELTA_HI), "+v"(WT.FLAG_LO), "+s"(WT.FLAG_HI), "+s"(WT.LSH_LO), "+s"(WT.FOFF_LO)); \
+    asm volatile("" : "+s"(WT.NT.rev_hi), "+v"(WT.NT.rev_lo), "+s"(WT.NT.ew_hi), "+v"(WT.NT.ew_lo));
+#else
+#define IRBPP_WALK_PIN(WT)
+#endif
+// the border that starts at (x0, y0) of the image in `fr`: a lane without one passes active = false.  An isolated pixel is its
+// own one-point border: stored, result = 1, nothing to walk.
+__device__ __forceinline__ void walk_start(Walk& w, const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active, const WalkTables& T) {
+    constexpr uint32_t SEL = 0x0c0c0c00u;
+    const int pos0 = x0 | (y0 << 4);
+    const uint32_t nb0 = nb_frame(fr[y0], fr[y0 + 1], fr[y0 + 2], x0, T.NT);
+    const uint32_t rot = ((nb0 << 4) | (nb0 >> 4)) & 0xFFu;                // direction 3 -> bit 7
+    const bool isolated = rot == 0u;
+    const int s_first = (3 - (7 - (31 - __builtin_clz(rot | (isolated ? 1u : 0u))))) & 7;
+    w.pos0 = pos0;
+    w.pos1 = pos0 + (int)byte_table(T.DELTA_HI, T.DELTA_LO, (uint32_t)s_first | SEL) - 17;
+    w.s_close = (uint32_t)(s_first ^ 4) | SEL;
+    w.pos = pos0;
+    w.n = 0;
+    w.result = (active && isolated) ? 1 : 0;
+    w.nb16 = nb0 | (nb0 << 8);
+    w.k2 = (uint32_t)(s_first + 1);
+    w.prev = (uint32_t)(s_first ^ 4) | SEL;
+    w.run = (active && !isolated) ? 1u : 0u;
+    if (active && isolated && cap > 0) pts[0] = (uint8_t)pos0;
+}
+// one step of a walking lane (call under `if (w.run != 0u)`); when the border closes w.result = its points and w.run = 0; a
+// walk that meets a pixel before its start in raster order (not the first pixel of its component) ends with result 0
+__device__ __forceinline__ void walk_iter(Walk& w, const uint32_t* fr, uint8_t* pts, int cap, uint8_t* spill, int spill_cap, const WalkTables& T) {
+    constexpr uint32_t SEL = 0x0c0c0c00u;
+    IRBPP_TRACE_ITER();
+    const uint32_t k2 = w.k2 & 7u;
+    const uint32_t s2 = ((k2 + (uint32_t)__builtin_ctz(w.nb16 >> k2)) & 7u) | SEL;
+    const int n = w.n, pos = w.pos;
+    pts[n < cap ? n : cap] = (uint8_t)pos;                                // CHAIN_APPROX_SIMPLE: kept iff the direction changed
+    if (n >= cap && n - cap < spill_cap) spill[n - cap] = (uint8_t)pos;
+    const int n1 = n + (s2 != w.prev ? 1 : 0);
+    int pos4 = pos + (int)byte_table(T.DELTA_HI, T.DELTA_LO, s2) - 17;
+    const bool closed1 = pos4 == w.pos0 && pos == w.pos1;
+    const uint32_t flags = byte_table(T.FLAG_HI, T.FLAG_LO, s2);
+    const uint32_t lsh = byte_table(T.LSH_HI, T.LSH_LO, s2), psh = lsh ^ 4u;
+    const uint32_t li = bit_field((uint32_t)pos4, lsh, 4);
+    int p = (int)bit_field((uint32_t)pos4, psh, 4);
+    const uint32_t* ln = (const uint32_t*)((const char*)fr + ((li << 2) + byte_table(T.FOFF_HI, T.FOFF_LO, s2)));
+    const uint32_t wa = ln[0], wm = ln[1], wb = ln[2];
+    {
+        const uint32_t side = bit_select(bit_flag<3>(flags), wb, wa);
+        const uint32_t blocked = side | (side << 1) | (side >> 1);
+        const uint32_t lf = (uint32_t)__builtin_ctz(~(((wm >> 1) & ~blocked) >> (p + 1)));
+        const uint32_t lb = (uint32_t)__builtin_clz(~(((wm << 1) & ~blocked) << (30 - p)));
+        const int dp = (int)(bit_select(bit_flag<2>(flags), lf, 0u - lb) & bit_flag<0>(flags));
+        p += dp;
+        pos4 += dp * (1 << psh);
+    }
+    const bool closed2 = pos4 == w.pos0 && s2 == w.s_close;
+    const uint32_t nbl = nb_frame(wa, wm, wb, p, T.NT);
+    const uint32_t nb = bit_select(bit_flag<1>(flags), nb_untranspose(nbl), nbl);
+    const bool ends = closed1 || closed2;
+    w.result = ends ? n1 : w.result;
+    w.run = (ends || pos4 < w.pos0) ? 0u : 1u;                            // run interiors lie between their end points in raster order
+    w.n = n1;
+    w.prev = s2;
+    w.pos = pos4;
+    w.k2 = s2 + 5u;
+    w.nb16 = nb | (nb << 8);
+}
+// the whole border through walk_start / walk_iter (tests/host/: must equal trace_border_fast)
+__device__ inline int trace_border_walk(const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, uint8_t* spill = nullptr, int spill_cap = 0) {
+    IRBPP_WALK_TABLES(T)
+    Walk w;
+    walk_start(w, fr, x0, y0, pts, cap, true, T);
+    for (int guard = 4096; w.run != 0u; )  {
+        walk_iter(w, fr, pts, cap, spill, spill_cap, T);
+        if (--guard == 0) return -1;
+    }
+    return w.result;
+}
+
 #define IRBPP_PX(p) ((int)((p) & 15))
 #define IRBPP_PY(p) ((int)((p) >> 4))
 

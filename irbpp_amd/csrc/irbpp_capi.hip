@@ -557,6 +557,11 @@ static int pick_trace_cpw(const irbpp_env* env, int n) {
     if (t & IRBPP_TUNE_TRACE_CPW64) return 64;
     if (t & IRBPP_TUNE_TRACE_CPW32) return 32;
     if (t & IRBPP_TUNE_TRACE_CPW16) return 16;
+    if (t & IRBPP_TUNE_TRACE_REFILL) return TRACE_REFILL_BATCH;
+    // (lane refill -- a wave owns a batch of 128 candidates and hands a lane the next one as borders close, trace_refill_body --
+    // is OPT-IN: measured slower at every size, profiles/r06/LOG.md session 2: 8192 BlockOut bins 54.9 -> 51.4 M as one group,
+    // 63.8 -> 59.0 M as two, the kernel 36.2 -> 46.0 us.  The chip has as many lane slots as a launch has candidates, so a
+    // refilled lane's work is taken from another wave, not from idleness, and one wave then pays every refill's latencies in turn)
     return n <= TRACE_CPW16_BINS ? 16 : (n <= TRACE_CPW32_BINS ? 32 : 64);
 }
 
@@ -614,9 +619,9 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         const bool inline_polygon = (tune & IRBPP_TUNE_INLINE_POLYGON) != 0;
         Params Pt = env->P;
         if (inline_polygon) Pt.round_cap = 0;
-        int tgrid = n * (64 / cpw);
+        int tgrid = cpw > 64 ? (n * 64 + cpw - 1) / cpw : n * (64 / cpw);
         if (tgrid > trace_grid_cap(env->P.N)) tgrid = trace_grid_cap(env->P.N);      // (w_big holds one scratch per wave of the grid)
-        auto trace_fn = cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
+        auto trace_fn = cpw > 64 ? irbpp_trace_kernel_refill : cpw == 64 ? irbpp_trace_kernel : (cpw == 32 ? irbpp_trace_kernel_c32 : irbpp_trace_kernel_c16);
         hipLaunchKernelGGL(trace_fn, dim3(tgrid), dim3(64), 0, st, Pt, env->S, env->phase_cycles);
 #ifdef IRBPP_AB_POLY_ACCOUNT
         if (!inline_polygon) hipLaunchKernelGGL(irbpp_polygon_kernel, dim3(pgrid), dim3(64), 0, st, env->P, env->S, env->phase_cycles);
@@ -1021,7 +1026,7 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
     snprintf(emit, sizeof emit, "%s%s", wave_emit ? "irbpp_emit_wave_kernel" : "irbpp_emit_kernel",
              spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : "");
     snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s + irbpp_trace_kernel%s + irbpp_polygon_kernel + %s%s",
-             pick_env_kernel(env).name, cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
+             pick_env_kernel(env).name, cpw > 64 ? "_refill" : cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
              !split_apply(env, n) ? "" : (env->P.K > 1 ? (n < 2048 ? " (step: irbpp_apply_wg_kernel alone)" : " (step: irbpp_apply_kernel alone)")
                                                        : " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)"));
     *kernel_name = env->kernel_names;

@@ -2214,6 +2214,255 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
     }
 }
 
+// ---------------------------------------------------------------------------------------
+// Border following with LANE REFILL (round 6; opt-in: IRBPP_TUNE_TRACE_REFILL -- measured SLOWER, see pick_trace_cpw in irbpp_capi.hip).  A wave of trace_body walks
+// until the LONGEST of its 64 borders is closed: on BlockOut a lane walks 9.4 iterations on average and the longest of 64
+// takes 34 (tools/trace_length_study.py; profiles/r06), i.e. lanes idle for three quarters of the loop, and no cheap
+// property of a level image predicts which border is the long one (correlations <= 0.4).  Here a wave owns a BATCH of
+// candidate starts: it starts 64 walks and, whenever THR lanes have closed their borders (or nobody walks any more), (1)
+// hands the finished borders on -- the same round records, packed by the same code -- and (2) gives every idle lane the
+// next candidate of the batch: the candidate's image words were requested a refill earlier by the lane of the same RANK
+// among the idle ones and change lanes with a handful of ds_bpermute, the 16 x 16 transpose and the frame stores run once per
+// refill for all takers together.  The loop executes sum / 64 iterations (+ the refills) instead of max per 64.
+// Results are the old kernel's, record for record up to their order in the lists (which no consumer looks at).
+// ---------------------------------------------------------------------------------------
+constexpr int TRACE_REFILL_BATCH = 128, TRACE_REFILL_THR = 32;
+template <int BATCH, int THR>
+__device__ __forceinline__ void trace_refill_body(const Params& P, const State& S, long long* prof) {
+    constexpr int SLOT = TRACE_SLOT, CAP = TRACE_CAP, LCAP = TRACE_LDS_CAP, PP = TRACE_P, NCE = BATCH / 64;
+    static_assert(BATCH % 64 == 0 && NCE >= 1 && NCE <= 4, "a batch is a whole number of wave-wide candidate loads");
+    __shared__ __attribute__((aligned(16))) uint8_t slots[64 * SLOT];
+    __shared__ __attribute__((aligned(16))) uint32_t sfr[64 * TRACE_FSTRIDE];
+    __shared__ uint32_t dps[64 * PP];
+    __shared__ uint8_t dpscratch[64 * PP];
+    const int lane = threadIdx.x;
+    const int seg_cap = P.seg_cap;
+    int seg_n[NXCD], seg_first[NXCD + 1];
+    seg_first[0] = 0;
+#pragma unroll
+    for (int s = 0; s < NXCD; ++s) {
+        const int n = S.w_total[s * XCD_STRIDE];
+        seg_n[s] = n < seg_cap ? n : seg_cap;
+        seg_first[s + 1] = seg_first[s] + (seg_n[s] + BATCH - 1) / BATCH;
+    }
+    uint32_t* const fr = sfr + lane * TRACE_FSTRIDE;
+    uint8_t* const my_slot = slots + lane * SLOT;
+    uint8_t* const wave_spill = S.w_big + (size_t)blockIdx.x * TRACE_WAVE_BYTES + TRACE_BIG_BYTES;    // [64][TRACE_SPILL]
+    uint8_t* const my_spill = wave_spill + lane * TRACE_SPILL;
+    IRBPP_WALK_TABLES(WT)
+    const int round_cap = P.round_cap;
+    const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));
+    for (int chunk = blockIdx.x; chunk < seg_first[NXCD]; chunk += gridDim.x) {
+        const long long t_start = prof ? (long long)clock64() : 0;
+        int seg = 0;
+#pragma unroll
+        for (int s = 1; s < NXCD; ++s) seg += chunk >= seg_first[s] ? 1 : 0;
+        int first_chunk = 0, count = 0;
+#pragma unroll
+        for (int s = 0; s < NXCD; ++s) if (s == seg) { first_chunk = seg_first[s]; count = seg_n[s]; }
+        const int gi0 = (chunk - first_chunk) * BATCH;
+        const int nb = count - gi0 < BATCH ? count - gi0 : BATCH;        // candidates of this batch (uniform, >= 1)
+        const uint2* const cl = S.w_cand + (size_t)seg * seg_cap + gi0;
+        uint2 ce[NCE];                                                    // candidate u * 64 + lane of the batch: (bin, image << 8 | y0 << 4 | x0)
+#pragma unroll
+        for (int u = 0; u < NCE; ++u) ce[u] = u * 64 + lane < nb ? cl[u * 64 + lane] : make_uint2(0u, 0u);
+        Walk w;
+        w.pos = w.n = w.result = w.pos0 = w.pos1 = 0;
+        w.nb16 = w.k2 = w.prev = w.s_close = w.run = 0u;
+        int rk = 0, x0 = 0, y0 = 0, nxt = 0, n_dp_total = 0, refills = 0;
+        // the image of candidate nxt + lane, requested a refill ahead of its use
+        uint2 pf_e = make_uint2(0u, 0u);
+        uint4 pf0 = make_uint4(0u, 0u, 0u, 0u), pf1 = pf0;
+        uint32_t pf_rot = 0u;
+        auto prefetch = [&]() {
+            const int c = nxt + lane;
+            uint2 e = make_uint2(0u, 0u);
+#pragma unroll
+            for (int u = 0; u < NCE; ++u) {
+                const uint32_t ex = (uint32_t)__shfl((int)ce[u].x, c & 63), ey = (uint32_t)__shfl((int)ce[u].y, c & 63);
+                if ((c >> 6) == u) e = make_uint2(ex, ey);
+            }
+            pf_e = e;
+            if (c < nb) {
+                const size_t at = (size_t)e.x * P.wimg + ((e.y >> 8) & 511u);
+                pf_rot = S.w_imgrot[at];
+                const uint4* gi = (const uint4*)(S.w_img + at * 16);
+                pf0 = gi[0];
+                pf1 = gi[1];
+            }
+        };
+        // the closed borders of the lanes that do not walk go to the polygon kernel (trace_body's code, on w.result)
+        auto flush = [&]() {
+            int my_n = w.run == 0u ? w.result : 0;
+            w.result = w.run == 0u ? 0 : w.result;
+            if (__ballot(my_n != 0) == 0ull) return;
+            {   // a border of more than 128 points (not seen in any workload): sequential, in global scratch
+                unsigned long long big = __ballot(my_n > CAP);
+                while (big != 0ull) {
+                    const int l0 = __ffsll((long long)big) - 1;
+                    big &= big - 1ull;
+                    if (lane == l0) {
+                        uint8_t* gsc = S.w_big + (size_t)blockIdx.x * TRACE_WAVE_BYTES;
+                        SlotMem m;
+                        m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
+                        uint16_t* im = (uint16_t*)(gsc + 6 * TRACE_BIG);
+                        for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)(fr[1 + q] >> 1); im[16 + q] = (uint16_t)(fr[FRAME_COLS + 1 + q] >> 1); }
+                        if (contour_vertices(im, im + 16, x0, y0, m, S.w_vmask + (size_t)rk * 16) != 0)
+                            atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
+                        my_n = 0;
+                    }
+                }
+            }
+            const bool spilled = __ballot(my_n > LCAP) != 0ull;
+            if (spilled) {
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+            auto next_round = [&](int left, int& wn, int& excl, int& base) -> unsigned long long {
+                wn = left;
+                const int incl = wave_inclusive_sum(wn);
+                excl = incl - wn;
+                if (__builtin_amdgcn_readlane(incl, 63) == 0) return 0ull;
+                const unsigned long long todo = __ballot(wn > 0);
+                base = __builtin_amdgcn_readlane(excl, __ffsll((long long)todo) - 1);
+                return __ballot(wn > 0 && incl - base <= 64 * PP);
+            };
+            int n_rounds = 0;
+            {
+                int left = my_n;
+                for (;;) {
+                    int wn, excl, base = 0;
+                    const unsigned long long sel = next_round(left, wn, excl, base);
+                    if (sel == 0ull) break;
+                    if ((sel >> lane) & 1ull) left = 0;
+                    ++n_rounds;
+                }
+            }
+            int at = 0;
+            if (n_rounds > 0) {
+                if (lane == 0) at = atomicAdd(S.w_nround + xcd * XCD_STRIDE, n_rounds);
+                at = __builtin_amdgcn_readfirstlane(at);
+            }
+            const bool inline_dp = at + n_rounds > round_cap;
+            uint8_t* const rec0 = S.w_round + ((size_t)xcd * round_cap + at) * ROUND_BYTES;
+            int left = my_n, n_dp = 0;
+            for (;;) {
+                int wn, excl, base = 0;
+                const unsigned long long sel = next_round(left, wn, excl, base);
+                if (sel == 0ull) break;
+#pragma unroll
+                for (int u = 0; u < PP; ++u) dps[u * 64 + lane] = 0u;
+                IRBPP_WAVE_SYNC();
+                if ((sel >> lane) & 1ull) dps[excl - base] = (uint32_t)lane + 1u;
+                IRBPP_WAVE_SYNC();
+                int mark[PP];
+#pragma unroll
+                for (int u = 0; u < PP; ++u) mark[u] = (int)dps[u * 64 + lane];
+                IRBPP_WAVE_SYNC();
+                bool live[PP];
+                int pv[PP], jj[PP], nn[PP], sbq[PP], prk[PP];
+                const uint8_t* pts[PP];
+                int carry = 0;
+#pragma unroll
+                for (int u = 0; u < PP; ++u) {
+                    const int run = imax(wave_inclusive_max(mark[u]), carry);
+                    carry = __builtin_amdgcn_readlane(run, 63);
+                    const int owner = run - 1;
+                    const int on = owner >= 0 ? owner : 0;
+                    const int ns = __shfl(wn | ((excl - base) << 8), on);
+                    nn[u] = ns & 255;
+                    sbq[u] = ns >> 8;
+                    prk[u] = __shfl(rk, on);
+                    live[u] = owner >= 0 && u * 64 + lane < sbq[u] + nn[u];
+                    pts[u] = slots + on * SLOT;
+                    jj[u] = u * 64 + lane - sbq[u];
+                    if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
+                    pv[u] = live[u] ? (int)pts[u][jj[u] < LCAP ? jj[u] : LCAP] : 0;
+                    if (spilled && live[u] && jj[u] >= LCAP) pv[u] = (int)wave_spill[on * TRACE_SPILL + jj[u] - LCAP];
+                }
+                if (inline_dp) {
+                    approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
+                } else {
+                    uint8_t* const rec = rec0 + (size_t)n_dp * ROUND_BYTES;
+#pragma unroll
+                    for (int u = 0; u < PP; ++u) {
+                        const int q = u * 64 + lane;
+                        rec[q] = (uint8_t)pv[u];
+                        rec[64 * PP + q] = (uint8_t)(live[u] ? nn[u] : 0);
+                        rec[2 * 64 * PP + q] = (uint8_t)sbq[u];
+                        ((uint32_t*)(rec + 3 * 64 * PP))[q] = (uint32_t)prk[u];
+                    }
+                }
+                if ((sel >> lane) & 1ull) left = 0;
+                ++n_dp;
+            }
+            if (inline_dp && n_rounds > 0 && at < round_cap) {
+                const int lim = at + n_rounds < round_cap ? n_rounds : round_cap - at;
+                for (int i = 0; i < lim; ++i)
+#pragma unroll
+                    for (int u = 0; u < PP; ++u) rec0[(size_t)i * ROUND_BYTES + 64 * PP + u * 64 + lane] = 0;
+            }
+            n_dp_total += n_dp;
+            IRBPP_WAVE_SYNC();
+        };
+        prefetch();
+        int guard = 16384;                                                // (uniform: iterations of this batch's loop)
+        for (;;) {
+            const unsigned long long walking = __ballot(w.run != 0u);
+            const int idle = 64 - __popcll(walking);
+            if ((idle >= THR && nxt < nb) || walking == 0ull) {
+                flush();
+                if (nxt >= nb) break;                                     // (nobody walks and the batch is handed out)
+                // every idle lane takes the next candidate: rank r among the idle lanes gets candidate nxt + r, whose image
+                // lane r requested at the last refill
+                const int rank = (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(~walking >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)~walking, 0u));
+                const bool take = w.run == 0u && nxt + rank < nb;
+                const uint32_t ex = (uint32_t)__shfl((int)pf_e.x, rank), ey = (uint32_t)__shfl((int)pf_e.y, rank);
+                const uint32_t rot = (uint32_t)__shfl((int)pf_rot, rank);
+                uint32_t wd[8];
+                wd[0] = (uint32_t)__shfl((int)pf0.x, rank); wd[1] = (uint32_t)__shfl((int)pf0.y, rank);
+                wd[2] = (uint32_t)__shfl((int)pf0.z, rank); wd[3] = (uint32_t)__shfl((int)pf0.w, rank);
+                wd[4] = (uint32_t)__shfl((int)pf1.x, rank); wd[5] = (uint32_t)__shfl((int)pf1.y, rank);
+                wd[6] = (uint32_t)__shfl((int)pf1.z, rank); wd[7] = (uint32_t)__shfl((int)pf1.w, rank);
+                if (take) {
+                    x0 = (int)(ey & 15u);
+                    y0 = (int)((ey >> 4) & 15u);
+                    rk = (int)ex * P.R + (int)rot;
+                    uint32_t r[16], c[16];
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        r[2 * q] = c[2 * q] = wd[q] & 0xFFFFu;
+                        r[2 * q + 1] = c[2 * q + 1] = wd[q] >> 16;
+                    }
+                    transpose16(c);
+                    frames_store(fr, r, c);
+                    walk_start(w, fr, x0, y0, my_slot, LCAP, true, WT);
+                }
+                nxt += idle < nb - nxt ? idle : nb - nxt;
+                ++refills;
+                if (nxt < nb) prefetch();
+                continue;
+            }
+            if (w.run != 0u) walk_iter(w, fr, my_slot, LCAP, my_spill, TRACE_SPILL, WT);
+            if (--guard == 0) { if (lane == 0) atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD); break; }
+        }
+        if (prof && lane == 0) {                 // tooling: this wave's account of its first batch, in the row of that batch's first bin
+            const int b0 = (int)cl[0].x;
+            long long* row = prof + (size_t)b0 * PHASE_ROW;
+            const long long t_end = (long long)clock64();
+            row[11] = t_end - t_start;
+            row[12] = 0;
+            row[13] = t_end - t_start;
+            row[14] = (long long)refills | ((long long)(16384 - guard) << 16);     // refills, loop iterations
+            row[15] = 1 | ((long long)n_dp_total << 20) | ((long long)nb << 40);
+        }
+        IRBPP_WAVE_SYNC();
+    }
+}
+extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_refill(const Params P, const State S, long long* prof) {
+    trace_refill_body<TRACE_REFILL_BATCH, TRACE_REFILL_THR>(P, S, prof);
+}
+
 extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel(const Params P, const State S, long long* prof) { trace_body<64>(P, S, prof); }
 extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c32(const Params P, const State S, long long* prof) { trace_body<32>(P, S, prof); }
 extern "C" __global__ void __launch_bounds__(64) irbpp_trace_kernel_c16(const Params P, const State S, long long* prof) { trace_body<16>(P, S, prof); }

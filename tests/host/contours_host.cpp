@@ -90,6 +90,29 @@ int host_trace_border_fast_spill(const uint16_t* rows, int x0, int y0, uint8_t* 
     return n;
 }
 
+// the walk in its start / iteration form (the trace kernel's lane-refill build): same contracts as the two above
+int host_trace_border_walk(const uint16_t* rows, int x0, int y0, uint8_t* pts, int cap) {
+    uint32_t r[16], c[16], fr[FRAME_WORDS];
+    for (int y = 0; y < 16; ++y) r[y] = c[y] = rows[y];
+    transpose16(c);
+    frames_store(fr, r, c);
+    return trace_border_walk(fr, x0, y0, pts, cap);
+}
+int host_trace_border_walk_spill(const uint16_t* rows, int x0, int y0, uint8_t* pts, int cap_lds, int spill_cap) {
+    uint32_t r[16], c[16], fr[FRAME_WORDS];
+    for (int y = 0; y < 16; ++y) r[y] = c[y] = rows[y];
+    transpose16(c);
+    frames_store(fr, r, c);
+    static uint8_t head[4096], tail[4096];
+    memset(head, 0xEE, sizeof head);
+    memset(tail, 0xEE, sizeof tail);
+    const int n = trace_border_walk(fr, x0, y0, head, cap_lds, tail, spill_cap);
+    for (int i = 0; i < n && i < cap_lds + spill_cap; ++i) pts[i] = i < cap_lds ? head[i] : tail[i - cap_lds];
+    for (int i = cap_lds + 1; i < 4096; ++i) if (head[i] != 0xEE) return -100;
+    for (int i = spill_cap; i < 4096; ++i) if (tail[i] != 0xEE) return -101;
+    return n;
+}
+
 // approx_and_convex on a point list: vrows[16] gets the vertex bits; returns 1 ok, 0 stack overflow.
 int host_approx_and_convex(const uint8_t* pts, int count, int cap_stk, uint32_t* vrows) {
     static uint8_t dst[4096];

@@ -54,6 +54,10 @@ def host():
     lib.host_trace_border_fast.restype = C.c_int
     lib.host_trace_border_fast_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
     lib.host_trace_border_fast_spill.restype = C.c_int
+    lib.host_trace_border_walk.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
+    lib.host_trace_border_walk.restype = C.c_int
+    lib.host_trace_border_walk_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
+    lib.host_trace_border_walk_spill.restype = C.c_int
     lib.host_approx_and_convex.argtypes = [u8p, C.c_int, C.c_int, u32p]
     lib.host_approx_and_convex.restype = C.c_int
     lib.host_contour_vertices.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
@@ -110,7 +114,7 @@ def test_candidates_and_trace_equal_the_oracle_borders(host, seed):
         host.host_start_candidates(rows, cand)
         listed = {(x, y) for y in range(16) for x in range(16) if (cand[y] >> x) & 1}
         assert set(starts) <= listed                                   # every true start is a candidate
-        for trace in (host.host_trace_border, host.host_trace_border_fast):     # the plain walk and the trace kernel's
+        for trace in (host.host_trace_border, host.host_trace_border_fast, host.host_trace_border_walk):     # the plain walk, the trace kernel's, and its start / iteration form
             for (x, y) in listed:
                 n = trace(rows, x, y, pts, 511)
                 if (x, y) in starts:
@@ -133,10 +137,11 @@ def test_trace_with_split_slot_equals_the_oracle_borders(host, seed):
         outer, _, _ = _oracle_outer(img)
         for c in outer:
             for cap_lds, spill_cap in ((1, 255), (3, 200), (7, 3), (56, 72)):
-                n = host.host_trace_border_fast_spill(rows, c[0][0], c[0][1], pts, cap_lds, spill_cap)
-                assert n == len(c)                                     # the true length, whatever fits
-                m = min(n, cap_lds + spill_cap)
-                assert [(pts[i] & 15, pts[i] >> 4) for i in range(m)] == c[:m]
+                for trace in (host.host_trace_border_fast_spill, host.host_trace_border_walk_spill):
+                    n = trace(rows, c[0][0], c[0][1], pts, cap_lds, spill_cap)
+                    assert n == len(c)                                     # the true length, whatever fits
+                    m = min(n, cap_lds + spill_cap)
+                    assert [(pts[i] & 15, pts[i] >> 4) for i in range(m)] == c[:m]
 
 
 def _oracle_vertices(contour_xy):

@@ -207,7 +207,8 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
     from bench import make_workload
     shapes, seqs, kw = make_workload(workload)
     flags = [_lib.TUNE_TRACE_CPW64, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
-             _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON, _lib.TUNE_NO_HEAVY_FIRST]
+             _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON, _lib.TUNE_NO_HEAVY_FIRST,
+             _lib.TUNE_TRACE_REFILL, _lib.TUNE_TRACE_REFILL | _lib.TUNE_INLINE_POLYGON]      # (lane refill: the default of large launches)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)] + \
            [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     obs = [e.reset() for e in envs]

@@ -43,7 +43,7 @@ def _env():
 def test_collectives_run_through_a_single_rank_rccl_communicator():
     res = subprocess.run([sys.executable, "-c", _SCRIPT], env=_env(), capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stderr[-2000:]
-    out = json.loads(res.stdout.strip().splitlines()[-1])
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])    # (librccl prints its path on stdout too)
     assert out["backend"] == "nccl" and out["world"] == 1
     assert out["totals"] == [3.0, 1.5, 12.0, 7.25] and out["max"] == 2.5 and out["names"] == ["rank 0"]
     assert any("rccl" in l.lower() for l in out["libs"]), out["libs"]       # librccl is what `nccl` loads on ROCm
@@ -59,6 +59,6 @@ def test_bench_timed_loop_under_a_forced_rccl_process_group():
                           "--bins", "2048", "--prefill", "20", "--warmup", "5", "--steps", "10", "--min-seconds", "0.2"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = json.loads(res.stdout.strip().splitlines()[-1])
+    line = json.loads(res.stdout.strip().splitlines()[-1])             # bench.py keeps its JSON line the last one on stdout
     assert line["ranks"]["process_group"] is True and line["ranks"]["backend"] == "nccl" and line["n_gpus"] == 1
     assert line["value"] > 1e6 and line["episodes"]["finished_since_reset"] >= 0
