@@ -363,6 +363,41 @@ def vecenv_rate(bins, dev, steps=100):
     return out
 
 
+def actor_loop_rate(bins, dev, steps=100, capacity=64):
+    """SURVEY 8f-3, the caller side kept on the device: environment step + scripted policy (stands for Agent.act) + the
+    vectorised replay memory's append (irbpp_amd.replay.actor_step over VectorReplayMemory: one tensor set for the N
+    per-env memories of main.py:61-63) -- the acting loop of trainer.py:161-186 without its per-env Python loop and without
+    a host round trip per step -- and one sample + priority update per env (memory.py:178-204, 206-210)."""
+    from irbpp_amd.replay import VectorReplayMemory, actor_step
+    from irbpp_amd.vec_env import GpuPackingEnv
+    shapes, seqs, kw = make_workload("blockout")
+    env = GpuPackingEnv(shapes, seqs, bins, device=dev, **kw)
+    mem = VectorReplayMemory(bins, capacity, env.obs_len, device=dev)
+    policy = lambda s_, m_: env.policy_minz(s_).to(torch.int64)      # noqa: E731
+    state = env.reset()
+    for _ in range(capacity + 8):
+        state, _, _ = actor_step(env, policy, mem, state)
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(steps):
+        state, _, _ = actor_step(env, policy, mem, state)
+    torch.cuda.synchronize(dev)
+    t_act = (time.perf_counter() - t) / steps
+    t = time.perf_counter()
+    for _ in range(20):
+        batch = mem.sample(1)
+        mem.update_priorities(batch[0], torch.rand(bins, device=dev) + 0.1)
+    torch.cuda.synchronize(dev)
+    t_learn = (time.perf_counter() - t) / 20
+    env.check_device_error()
+    env.close()
+    return {"bins": bins, "replay_capacity_per_env": capacity, "actor_steps_per_s": bins / t_act, "ms_per_actor_step": t_act * 1e3,
+            "sample_plus_priority_update_ms": t_learn * 1e3, "unit": "placement-steps/s",
+            "note": "GpuPackingEnv.step + policy kernel + VectorReplayMemory.append per step, everything on the device, one launch "
+                    "group; the reference's structure for the same work is extra.vecenv_step.with_trainer_per_env_loop plus one "
+                    "ReplayMemory.append per env in Python"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -497,6 +532,8 @@ def main():
             extra["cfg5_abc_fine_2048_per_gpu"] = recommended("abc_fine", 2048)
             extra["cfg1_cube_4096"] = recommended("cube", 4096)
             extra["vecenv_step"] = vecenv_rate(4096, dev)
+            extra["actor_loop"] = actor_loop_rate(4096, dev)
+            extra["blockout_r8_8192"] = recommended("blockout_r8", 8192)      # cfg 2 at the README command's eight rotations (README.md:100)
 
     if rank == 0:
         total_steps = bins * world * timed_steps

@@ -104,6 +104,9 @@ typedef struct {
 #define IRBPP_TUNE_TRACE_REFILL 262144 /* border following in batches of 128 candidate starts per wave whose lanes take the next candidate as
                                          they close their borders.  Off by default: measured slower at every size (profiles/r06/LOG.md,
                                          session 2); identical results, parity-tested                                                       */
+#define IRBPP_TUNE_NO_MIXED_PATH 524288 /* a data set of which only SOME rotations are lattice footprints (BlockOut at eight rotations) through
+                                          the cell lists entirely, as until round 5 (default: those rotations on the block path, the others on
+                                          their lists, in one kernel); identical results                                                    */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */
@@ -191,6 +194,14 @@ int irbpp_step(irbpp_env* env, const int32_t* actions_dev, float* obs_dev,
  * buffer slots; loc_obs_dev: float32[num_bins][obs_len(1)].  Hierarchical mode only. */
 int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev,
                                 float* loc_obs_dev, void* stream);
+
+/* replaces: PackingGame.get_all_possible_observation (binPhy.py:171-180; no caller in the reference): the location
+ * observation of EVERY buffer slot of every bin on the current heightmaps, loc_obs_dev: float32[num_bins][k][obs_len(1)]
+ * -- per bin the concatenation the reference returns.  Hierarchical mode only.  As there, the candidate rows a following
+ * irbpp_step would index are those of the LAST slot, and the slot chosen by the last irbpp_get_action_candidates
+ * (self.orderAction) is left as it is.  Ignores irbpp_set_auto_policy's buffer semantics only in that the action written is
+ * the last slot's. */
+int irbpp_get_all_possible_observation(irbpp_env* env, float* loc_obs_dev, void* stream);
 
 /* The scripted policy used by the benchmark and the parity tests: per bin the candidate
  * row with V==1 and the lowest H (first on ties), 0 if none.  loc_obs_dev has row stride
@@ -357,7 +368,8 @@ int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev);
  * environment, rewritten by the next call).  Valid after irbpp_load_shapes. */
 int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char** kernel_name);
 /* The overlap path irbpp_load_shapes chose for the data set: 1 block path (every footprint a union of uniform b x b
- * tiles: lattice data), 2 box path (every footprint a solid box), 3 generic cell lists; IRBPP_ERR_STATE before the
+ * tiles: lattice data), 2 box path (every footprint a solid box), 3 generic cell lists, 4 mixed (the block path for the rotations
+ * whose footprints are lattice footprints, cell lists for the others: BlockOut at eight rotations); IRBPP_ERR_STATE before the
  * shapes are loaded.  (vec_env.groups_for decides by it how many groups of bins to step a data set as.) */
 int irbpp_overlap_path(const irbpp_env* env);
 int irbpp_debug_kernel_timing(irbpp_env* env, int32_t capacity);

@@ -24,7 +24,7 @@ class IrbppConfig(C.Structure):
 TUNE_NO_BLOCK_PATH, TUNE_WIDE_KERNEL, TUNE_NARROW_KERNEL, TUNE_NO_BOX_PATH, TUNE_NO_ITEM_ORDER = 1, 2, 4, 8, 16
 TUNE_TRACE_CPW64, TUNE_TRACE_CPW32, TUNE_TRACE_CPW16, TUNE_INLINE_POLYGON, TUNE_NO_HEAVY_FIRST = 32, 64, 128, 256, 512
 TUNE_NO_SPECIALISED, TUNE_FUSED_APPLY, TUNE_SPLIT_APPLY, TUNE_BLOCK_EMIT, TUNE_WAVE_EMIT = 1024, 2048, 4096, 8192, 16384
-TUNE_GRAPH, TUNE_WG512, TUNE_NO_WG512, TUNE_TRACE_REFILL = 32768, 65536, 131072, 262144
+TUNE_GRAPH, TUNE_WG512, TUNE_NO_WG512, TUNE_TRACE_REFILL, TUNE_NO_MIXED_PATH = 32768, 65536, 131072, 262144, 524288
 
 
 class IrbppReplayView(C.Structure):
@@ -56,6 +56,7 @@ SIGNATURES = {
     "irbpp_reset_bins": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(IrbppStepOut), C.c_void_p]),
     "irbpp_get_action_candidates": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_get_all_possible_observation": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_policy_minz": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "irbpp_set_auto_policy": (C.c_int, [C.c_void_p, C.c_void_p]),
     "irbpp_register_obs_buffer": (C.c_int, [C.c_void_p, C.c_void_p]),

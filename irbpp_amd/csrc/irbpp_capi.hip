@@ -94,12 +94,13 @@ void layout_lds_host(Params& P) {
 int raise_lds_limits() {
     const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_env_kernel_box,
                              (const void*)irbpp_env_kernel_box8, (const void*)irbpp_env_kernel_generic,
-                             (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_hull_kernel,
+                             (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_env_kernel_mixed8, (const void*)irbpp_hull_kernel,
 #if !defined(IRBPP_NO_SPEC)
                              (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
-                             (const void*)irbpp_env_kernel_s4, (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
+                             (const void*)irbpp_env_kernel_s4, (const void*)irbpp_env_kernel_s5, (const void*)irbpp_emit_kernel_s5,
+                             (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
-                             (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2,
+                             (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2, (const void*)irbpp_emit_wave_kernel_s5,
                              (const void*)wg512::irbpp_env_kernel_s4_w512, (const void*)wg512::irbpp_env_kernel_s4_w512c,
 #endif
                              (const void*)wg512::irbpp_env_kernel_generic_w512,
@@ -111,6 +112,14 @@ int raise_lds_limits() {
 }
 
 }  // namespace
+
+// lattice data through and through (every rotation on the block path) or box data: what the wave-per-bin emit kernel and the
+// early split of the apply phase are for; a data set with list rotations (PATH_MIXED) is treated like free-form data there
+static bool all_block(const Params& P) { return P.block_b > 0 && P.block_rots == (1 << P.R) - 1; }
+static bool lattice_or_box(const Params& P) { return all_block(P) || P.box != 0; }
+// ... except in what its level images look like: unions of rectangles with a few dozen candidates per bin, practically never more
+// than S of them -- the wave-per-bin emit kernel's case, not the speckled free-form images the heavy-first list is for
+static bool lattice_images(const Params& P) { return P.block_b > 0 || P.box != 0; }
 
 // waves of the largest trace grid a launch over this environment's bins can ask for (16 candidates per wave: four waves per
 // bin), at most TRACE_SMALL_GRID of them beyond one per bin: State::w_big holds one scratch per wave of the grid (9 KB each:
@@ -268,30 +277,44 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
         if (fx < 1 || fy < 1 || fx > 4096 || fy > 4096 || offsets[i] < 0 || offsets[i] + fx * fy > pool_len) return IRBPP_ERR_ARG;
     }
     // Block path: the largest b (multiple of step, <= 8) such that every footprint of the dataset is a
-    // union of b x b tiles that are fully masked out or fully masked in with one bottom height.
-    int block_b = 0;
+    // union of b x b tiles that are fully masked out or fully masked in with one bottom height -- decided per ROTATION:
+    // if every rotation qualifies the data set is pure lattice data (BlockOut at R = 4); if only some do (BlockOut at the
+    // README's eight rotations: the four lattice rotations, not the 45-degree ones) those take the block loop and the
+    // others their cell lists, in one kernel (PATH_MIXED); b = the largest size with the most rotations.
+    int block_b = 0, block_rots = 0;
     if (!(env->cfg.tuning & IRBPP_TUNE_NO_BLOCK_PATH)) {
-        for (int b = 8; b >= 2 && block_b == 0; --b) {
+        int best_count = 0;
+        for (int b = 8; b >= 2; --b) {
             if (b % P.step != 0 || (P.Hx - b) % P.step != 0 || (P.Hy - b) % P.step != 0) continue;
-            bool ok = true;
-            for (int64_t i = 0; i < (int64_t)n_shapes * R && ok; ++i) {
-                const int fx = dims[i * 2], fy = dims[i * 2 + 1];
-                if (fx % b != 0 || fy % b != 0) { ok = false; break; }
-                for (int ti = 0; ti < fx / b && ok; ++ti)
-                    for (int tj = 0; tj < fy / b && ok; ++tj) {
-                        const int64_t e0 = offsets[i] + (int64_t)(ti * b) * fy + tj * b;
-                        for (int u = 0; u < b && ok; ++u)
-                            for (int v = 0; v < b && ok; ++v) {
-                                const int64_t e = offsets[i] + (int64_t)(ti * b + u) * fy + tj * b + v;
-                                if (mask_bottom[e] != mask_bottom[e0] ||
-                                    (mask_bottom[e0] != 0.0 && height_bottom[e] != height_bottom[e0]))
-                                    ok = false;
-                            }
-                    }
+            int mask = 0;
+            for (int r = 0; r < R; ++r) {
+                bool ok = true;
+                for (int64_t k = 0; k < n_shapes && ok; ++k) {
+                    const int64_t i = k * R + r;
+                    const int fx = dims[i * 2], fy = dims[i * 2 + 1];
+                    if (fx % b != 0 || fy % b != 0) { ok = false; break; }
+                    for (int ti = 0; ti < fx / b && ok; ++ti)
+                        for (int tj = 0; tj < fy / b && ok; ++tj) {
+                            const int64_t e0 = offsets[i] + (int64_t)(ti * b) * fy + tj * b;
+                            for (int u = 0; u < b && ok; ++u)
+                                for (int v = 0; v < b && ok; ++v) {
+                                    const int64_t e = offsets[i] + (int64_t)(ti * b + u) * fy + tj * b + v;
+                                    if (mask_bottom[e] != mask_bottom[e0] ||
+                                        (mask_bottom[e0] != 0.0 && height_bottom[e] != height_bottom[e0]))
+                                        ok = false;
+                                }
+                        }
+                }
+                if (ok) mask |= 1 << r;
             }
-            if (ok) block_b = b;
+            const int count = __builtin_popcount((unsigned)mask);
+            if (count > best_count) { best_count = count; block_b = b; block_rots = mask; }
+            if (count == R) break;
         }
+        // (a single lattice rotation among many list rotations is not worth the block-max grid; IRBPP_TUNE_NO_MIXED_PATH: A/B)
+        if (block_rots != (1 << R) - 1 && (2 * best_count < R || (env->cfg.tuning & IRBPP_TUNE_NO_MIXED_PATH))) { block_b = 0; block_rots = 0; }
     }
+    const bool mixed = block_b > 0 && block_rots != (1 << R) - 1;
     // Box path: every footprint of the dataset is a solid box -- maskB the rectangle [0,bx) x [0,by), one bottom height
     // over it (the Cube dataset: bottom 0, the ceil-fuzz row of space.py:105 masked out).  max over the window of (H - c)
     // is (max H) - c exactly, and the max over a rectangle is separable: row maxima first, then column maxima.
@@ -359,7 +382,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
                 s.com_y = mass > 0.0 ? my / mass : 0.5 * s.fy;
             }
             s.oblk = (int32_t)blkcell.size();
-            if (block_b)
+            if (block_b && ((block_rots >> r) & 1))
                 for (int ti = 0; ti < s.fx / block_b; ++ti)
                     for (int tj = 0; tj < s.fy / block_b; ++tj) {
                         const int64_t e0 = off + (int64_t)(ti * block_b) * s.fy + tj * block_b;
@@ -370,7 +393,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
             // generic path: the masked-in bottom cells again, as (height, byte offset in the LDS tile relative to the
             // action cell's own entry): cell (ci, cj) of an item on action cell (X, Y) is heightmap cell
             // (X*step + ci, Y*step + cj) = plane (ci % step, cj % step), entry (X + ci / step) * Ay + Y + cj / step
-            if (!block_b && !box)
+            if (!box && (!block_b || mixed))
                 for (int e = 0; e < s.nb; ++e) {
                     const Cell& c = bcell[s.ob + e];
                     const int ci = c.ij & 0xFFFF, cj = c.ij >> 16;
@@ -404,6 +427,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     T.n_shapes = n_shapes;
     if (block_b || box) {                        // switch the overlap test to the block / box path
         env->P.block_b = block_b;
+        env->P.block_rots = block_rots;
         env->P.mb_h = mb_h;
         env->P.mb_w = mb_w;
         env->P.box = box ? 1 : 0;
@@ -413,7 +437,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     }
     // generic path on a data set whose footprint lists do not fit a die's L2: online steps launch the bins grouped by
     // observed item per die (irbpp_item_order_kernel)
-    env->item_order = !block_b && !box && gcell.size() * sizeof(GCell) > (size_t)8 << 20 && env->P.N % NXCD == 0 &&
+    env->item_order = (!block_b || mixed) && !box && gcell.size() * sizeof(GCell) > (size_t)8 << 20 && env->P.N % NXCD == 0 &&
                       env->P.N >= 64 * NXCD && env->P.K == 1 && !(env->cfg.tuning & IRBPP_TUNE_NO_ITEM_ORDER);
     env->shapes_loaded = true;
     return IRBPP_OK;
@@ -469,8 +493,8 @@ static int pick_spec(const irbpp_env* env) {
 #else
     if (env->cfg.tuning & (IRBPP_TUNE_NO_SPECIALISED | IRBPP_TUNE_WIDE_KERNEL | IRBPP_TUNE_NARROW_KERNEL)) return 0;
     static const Params spec[N_SPECS] = {Params{}, spec_params(SPEC_KEYS[1]), spec_params(SPEC_KEYS[2]), spec_params(SPEC_KEYS[3]),
-                                         spec_params(SPEC_KEYS[4])};
-    static_assert(N_SPECS == 5, "one table entry and one kernel per SPEC_KEYS row");
+                                         spec_params(SPEC_KEYS[4]), spec_params(SPEC_KEYS[5])};
+    static_assert(N_SPECS == 6, "one table entry and one kernel per SPEC_KEYS row");
     for (int i = 1; i < N_SPECS; ++i)
         if (spec_matches(env->P, spec[i])) return i;
     return 0;
@@ -497,7 +521,7 @@ static bool split_apply(const irbpp_env* env, int n) {
     if (env->P.K > 1) return true;                 // buffered: the workgroup-per-bin form (apply + order observation), at every size
     const int per_cu = (160 * 1024) / (env->P.lds_bytes > 0 ? env->P.lds_bytes : 1);
     if (per_cu < 8) return false;
-    const bool lists = env->P.block_b == 0 && !env->P.box;
+    const bool lists = !lattice_or_box(env->P);
     return n >= (lists ? 4 : 2) * 256 * 8;
 }
 
@@ -508,6 +532,7 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
     // Generic path where the tile is so large that at most four 256-thread workgroups fit a CU's LDS (the 64 x 64 heightmap:
     // 40 KB per bin): 512-thread workgroups, eight waves on one tile (irbpp::wg512, the second pass of irbpp_kernels.hip)
     const bool generic = P.block_b == 0 && !P.box;
+    const bool mixed = P.block_b > 0 && !all_block(P);
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
     if (generic && (t & IRBPP_TUNE_NARROW_KERNEL) && (t & IRBPP_TUNE_WG512) && spec_matches(P, spec_params(SPEC_KEYS[4])))
         return {wg512::irbpp_env_kernel_s4_w512c, "irbpp_env_kernel_s4_w512c", 512};      // (A/B: under the 64-VGPR cap)
@@ -528,9 +553,11 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
         case 2: return {irbpp_env_kernel_s2, "irbpp_env_kernel_s2"};
         case 3: return {irbpp_env_kernel_s3, "irbpp_env_kernel_s3"};
         case 4: return {irbpp_env_kernel_s4, "irbpp_env_kernel_s4"};
+        case 5: return {irbpp_env_kernel_s5, "irbpp_env_kernel_s5"};
         default: break;
     }
 #endif
+    if (mixed) return (t & IRBPP_TUNE_WIDE_KERNEL) ? EnvKernel{irbpp_env_kernel_wide, "irbpp_env_kernel_wide"} : EnvKernel{irbpp_env_kernel_mixed8, "irbpp_env_kernel_mixed8"};
     if (P.block_b > 0) {
         if ((t & IRBPP_TUNE_WIDE_KERNEL) || 6 * P.lds_bytes > 150 * 1024) return {irbpp_env_kernel_wide, "irbpp_env_kernel_wide"};
         return {irbpp_env_kernel, "irbpp_env_kernel"};
@@ -590,7 +617,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     const bool split = env->P.split && observes;
     // expensive bins first in the emit kernel: free-form level images only (lattice and box data never get there), not for a
     // listed reset (its observation rows go by list position)
-    const bool heavy_first = split && env->P.heavy_cap > 0 && env->P.block_b == 0 && !env->P.box && io.bin_list == nullptr &&
+    const bool heavy_first = split && env->P.heavy_cap > 0 && !lattice_images(env->P) && io.bin_list == nullptr &&
                              !(env->cfg.tuning & IRBPP_TUNE_NO_HEAVY_FIRST);
     io.heavy_turn = heavy_first ? env->heavy_turn : -1;
     if (heavy_first) env->heavy_turn ^= 1;
@@ -630,7 +657,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
 #endif
         // lattice and box data (practically never more than S candidates per bin): a wave per bin, four bins per workgroup
         // -- from 2048 bins on: a launch over 1024 bins is one such workgroup per CU, 2.6 % slower than a workgroup per bin (profiles/r05/s7)
-        const bool wave_emit = (env->P.block_b > 0 || env->P.box) && !heavy_first && !(env->cfg.tuning & IRBPP_TUNE_BLOCK_EMIT) &&
+        const bool wave_emit = lattice_images(env->P) && !heavy_first && !(env->cfg.tuning & IRBPP_TUNE_BLOCK_EMIT) &&
                                (n >= 2048 || (env->cfg.tuning & IRBPP_TUNE_WAVE_EMIT));
         env_kernel_fn emit_fn = wave_emit ? irbpp_emit_wave_kernel : irbpp_emit_kernel;
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
@@ -639,6 +666,7 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
             case 2: emit_fn = wave_emit ? irbpp_emit_wave_kernel_s2 : irbpp_emit_kernel_s2; break;
             case 3: emit_fn = irbpp_emit_kernel_s3; break;
             case 4: emit_fn = irbpp_emit_kernel_s4; break;
+            case 5: emit_fn = wave_emit ? irbpp_emit_wave_kernel_s5 : irbpp_emit_kernel_s5; break;
             default: break;
         }
 #endif
@@ -727,7 +755,7 @@ static int launch_env(irbpp_env* env, StepIO io, int mode, void* stream, int gri
                     ++env->graph_replays;
                     // the host-side state a direct launch would have advanced
                     const bool observes = mode == MODE_CANDS || (mode == MODE_STEP && env->P.K == 1);
-                    const bool heavy_first = env->P.split && observes && env->P.heavy_cap > 0 && env->P.block_b == 0 && !env->P.box &&
+                    const bool heavy_first = env->P.split && observes && env->P.heavy_cap > 0 && !lattice_images(env->P) &&
                                              io.bin_list == nullptr && !(env->cfg.tuning & IRBPP_TUNE_NO_HEAVY_FIRST);
                     if (heavy_first) env->heavy_turn ^= 1;
                 }
@@ -814,6 +842,26 @@ int irbpp_get_action_candidates(irbpp_env* env, const int32_t* order_actions_dev
     io.obs_stride = env->P.obs_len1;
     io.err_out = env->err_mirror;          // the error word of the step outputs follows S.err through this call too
     return launch_env(env, io, MODE_CANDS, stream);
+}
+
+int irbpp_get_all_possible_observation(irbpp_env* env, float* loc_obs_dev, void* stream) {
+    if (!env || !loc_obs_dev) return IRBPP_ERR_ARG;
+    if (!env->was_reset) return IRBPP_ERR_STATE;
+    if (env->P.K < 2) return IRBPP_ERR_ARG;
+    // one full-width transition per buffer slot, all on the caller's stream: slot j of every bin is observed into row
+    // [b][j] of the [N][k][obs_len(1)] block (row stride k * obs_len(1)); like the reference's loop the last slot's
+    // candidates are the ones a following step would index, and the chosen slot (orderAction) is not touched
+    for (int j = 0; j < env->P.K; ++j) {
+        StepIO io;
+        memset(&io, 0, sizeof(io));
+        io.fixed_slot = j + 1;
+        io.obs = loc_obs_dev + (size_t)j * env->P.obs_len1;
+        io.obs_stride = env->P.K * env->P.obs_len1;
+        io.err_out = env->err_mirror;
+        const int rc = launch_env(env, io, MODE_CANDS, stream);
+        if (rc != IRBPP_OK) return rc;
+    }
+    return IRBPP_OK;
 }
 
 int irbpp_policy_minz(irbpp_env* env, const float* loc_obs_dev, int32_t obs_stride, int32_t* actions_dev, void* stream) {
@@ -1019,12 +1067,12 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
     *lds_bytes = env->P.lds_bytes;
     // the kernels of a step over all bins of this environment, in launch order behind the transition kernel's build
     const int n = env->P.N, spec = pick_spec(env);
-    const bool lattice = env->P.block_b > 0 || env->P.box;
+    const bool lattice = lattice_images(env->P);
     const bool wave_emit = lattice && !(env->cfg.tuning & IRBPP_TUNE_BLOCK_EMIT) && (n >= 2048 || (env->cfg.tuning & IRBPP_TUNE_WAVE_EMIT));
     const int cpw = pick_trace_cpw(env, n);
     char emit[48];
     snprintf(emit, sizeof emit, "%s%s", wave_emit ? "irbpp_emit_wave_kernel" : "irbpp_emit_kernel",
-             spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : "");
+             spec == 1 ? "_s1" : spec == 2 ? "_s2" : (spec == 3 && !wave_emit) ? "_s3" : (spec == 4 && !wave_emit) ? "_s4" : spec == 5 ? "_s5" : "");
     snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s + irbpp_trace_kernel%s + irbpp_polygon_kernel + %s%s",
              pick_env_kernel(env).name, cpw > 64 ? "_refill" : cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
              !split_apply(env, n) ? "" : (env->P.K > 1 ? (n < 2048 ? " (step: irbpp_apply_wg_kernel alone)" : " (step: irbpp_apply_kernel alone)")
@@ -1036,7 +1084,7 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
 int irbpp_overlap_path(const irbpp_env* env) {
     if (!env) return IRBPP_ERR_ARG;
     if (!env->shapes_loaded) return IRBPP_ERR_STATE;
-    return env->P.block_b > 0 ? 1 : (env->P.box ? 2 : 3);
+    return env->P.block_b > 0 ? (all_block(env->P) ? 1 : 4) : (env->P.box ? 2 : 3);
 }
 
 int irbpp_debug_kernel_timing_every(irbpp_env* env, int32_t every) {

@@ -150,6 +150,10 @@ struct Params {
     // mb[pi][pj] = max of the b x b heightmap block at (pi*step, pj*step) replaces the cell list:
     // max over the tile of (H - B) == (max over the tile of H) - B exactly (rounding is monotone).
     int32_t block_b, mb_w, mb_h, o_mb, o_c2;
+    // ... decided per ROTATION (round 6): bit r set = rotation r of every item has such footprints and takes the block loop;
+    // the other rotations (BlockOut at eight rotations: the 45-degree ones) walk their cell lists like free-form data, in the
+    // same kernel (PATH_MIXED).  All R bits set on pure lattice data; 0 when block_b == 0.
+    int32_t block_rots;
     // Division by the runtime grid sizes costs ~25 VALU instructions each; n / d == umulhi(n, mg_d) exactly
     // for n, d < 2^16 with mg_d = floor(2^32 / d) + 1 (d >= 2), see fdiv() in irbpp_kernels.hip.
     uint32_t mg_hy, mg_step, mg_ay, mg_ax, mg_ac, mg_mbw;
@@ -260,12 +264,12 @@ constexpr void layout_lds(Params& P, int32_t pad = 0) {
 // build was compiled with (spec_matches) -- same constexpr layout function on both sides, compared field by field -- and
 // the run-time build otherwise; results are identical by construction (tests/test_gpu_features.py runs both).
 // ---------------------------------------------------------------------------------------------------------------------
-struct SpecKey { int32_t Ax, Ay, step, R, S, block_b, box; };
+struct SpecKey { int32_t Ax, Ay, step, R, S, block_b, box, block_rots; };
 constexpr Params spec_params(const SpecKey& k) {
     Params P{};
     P.Ax = k.Ax; P.Ay = k.Ay; P.step = k.step; P.R = k.R; P.S = k.S;
     P.Hx = k.Ax * k.step; P.Hy = k.Ay * k.step; P.Hc = P.Hx * P.Hy; P.AC = k.Ax * k.Ay;
-    P.block_b = k.block_b; P.box = k.box;
+    P.block_b = k.block_b; P.box = k.box; P.block_rots = k.block_rots;
     P.mb_h = k.block_b ? (P.Hx - k.block_b) / k.step + 1 : 0;
     P.mb_w = k.block_b ? (P.Hy - k.block_b) / k.step + 1 : 0;
     P.split = 1;
@@ -284,7 +288,7 @@ constexpr Params spec_params(const SpecKey& k) {
     X(g_ysh) X(box) X(o_m1) X(o_vbits) X(o_sr) X(o_hm) X(o_posz) X(o_lev) X(o_present) X(o_taskidx) X(o_tasklist)      \
     X(o_img) X(o_clist) X(o_vmask) X(o_scratch) X(o_red) X(o_dps) X(nslot) X(slot_cap) X(slot_bytes) X(scratch_bytes)  \
     X(lds_bytes) X(lds_bytes_full) X(e_vmask) X(e_red) X(e_hist) X(e_keys) X(emit_lds_bytes) X(ew_bytes) X(e_need) X(big_slot_bytes)         \
-    X(block_b) X(mb_w) X(mb_h) X(o_mb) X(o_c2) X(mg_hy) X(mg_step) X(mg_ay) X(mg_ax) X(mg_ac) X(mg_mbw) X(dbg_repeat)  \
+    X(block_b) X(block_rots) X(mb_w) X(mb_h) X(o_mb) X(o_c2) X(mg_hy) X(mg_step) X(mg_ay) X(mg_ax) X(mg_ac) X(mg_mbw) X(dbg_repeat)  \
     X(split) X(wimg) X(heavy_thr) X(stability) X(obs_len1)
 constexpr bool spec_matches(const Params& P, const Params& C) {
 #define IRBPP_X(f) if (P.f != C.f) return false;
@@ -294,11 +298,12 @@ constexpr bool spec_matches(const Params& P, const Params& C) {
 }
 // SPEC 0 is the run-time build
 constexpr SpecKey SPEC_KEYS[] = {
-    {0, 0, 0, 0, 0, 0, 0},
-    {16, 16, 2, 4, 500, 4, 0},      // 1: BlockOut, R = 4 (BASELINE configs 2 and 4): block path, 4 x 4 cells
-    {16, 16, 2, 2, 500, 0, 1},      // 2: Cube, R = 2 (config 1): box path
-    {16, 16, 2, 8, 500, 0, 0},      // 3: free-form solids, R = 8, 32 x 32 heightmap (config 3; BlockOut at R = 8)
-    {16, 16, 4, 8, 500, 0, 0},      // 4: free-form solids, R = 8, 64 x 64 heightmap (config 5)
+    {0, 0, 0, 0, 0, 0, 0, 0},
+    {16, 16, 2, 4, 500, 4, 0, 0x0F},   // 1: BlockOut, R = 4 (BASELINE configs 2 and 4): block path, 4 x 4 cells
+    {16, 16, 2, 2, 500, 0, 1, 0},      // 2: Cube, R = 2 (config 1): box path
+    {16, 16, 2, 8, 500, 0, 0, 0},      // 3: free-form solids, R = 8, 32 x 32 heightmap (config 3)
+    {16, 16, 4, 8, 500, 0, 0, 0},      // 4: free-form solids, R = 8, 64 x 64 heightmap (config 5)
+    {16, 16, 2, 8, 500, 4, 0, 0x0F},   // 5: BlockOut at the README command's eight rotations (README.md:100): rotations 0 .. 3 block path, 4 .. 7 cell lists
 };
 constexpr int N_SPECS = (int)(sizeof(SPEC_KEYS) / sizeof(SPEC_KEYS[0]));
 template <int SPEC>
@@ -351,6 +356,8 @@ struct StepIO {
     int32_t block_off;          // grouped stepping: this launch covers launch slots block_off .. block_off + gridDim.x - 1
     int32_t heavy_turn;         // which of State::w_heavy's two lists this launch fills and serves (-1: none: listed resets, block / box data)
     int32_t n_slots;            // launch slots of this launch (irbpp_apply_kernel: one wave per slot, four per workgroup)
+    int32_t fixed_slot;         // MODE_CANDS: 0 = the buffer slot of bin b is actions[b]; j + 1 = slot j for every bin, and the bins' chosen slot
+                                // (BinState::order_action, which the next step pops) stays as it is: irbpp_get_all_possible_observation
 };
 
 }  // namespace irbpp

@@ -743,7 +743,8 @@ __device__ __forceinline__ double gcell_b(const gcell_words c) { return __hiloin
 // codes to L.lev, the levels present to L.present; returns np.sum(naiveMask).
 // PATH: the overlap path compiled in -- one of the three, so that a transition kernel carries (and allocates registers
 // for) only the path its data set takes, or PATH_ANY: decided at run time from Params (heuristic kernel, fallback build).
-enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3 };
+enum OverlapPath : int { PATH_ANY = 0, PATH_BLOCK = 1, PATH_BOX = 2, PATH_GENERIC = 3,
+                         PATH_MIXED = 4 };   // block loop for the rotations of Params::block_rots, cell lists for the others
 constexpr int GENERIC_TICKET = 40;               // word of Lds::redi that deals the generic path's tasks
 // One footprint cell list walked for G row groups at once (overlap_test's generic path): per cell one 16-byte scalar
 // load (bottom height, byte offset in the tile), per row group one LDS read at lane base + offset, one subtract and
@@ -844,8 +845,12 @@ __device__ inline void gcell_walk(ConstGCellPtr gc, int nb, const char* const (&
 template <int PATH>
 __device__ inline int overlap_test(const Params& P, const Tables& T, const State& S, const StepIO& io,
                                    const Lds& L, int b, int item, bool debug_out, double* zdst, bool sr_staged, bool dense) {
-    const bool use_block = PATH == PATH_BLOCK || (PATH == PATH_ANY && P.block_b > 0);
+    const bool use_block = PATH == PATH_BLOCK || PATH == PATH_MIXED || (PATH == PATH_ANY && P.block_b > 0);
     const bool use_box = PATH == PATH_BOX || (PATH == PATH_ANY && P.box != 0);
+    // rotations that take the block loop (all of them on pure lattice data); the others walk their cell lists below
+    const uint32_t rots_all = (1u << P.R) - 1u;
+    const uint32_t brots = PATH == PATH_BLOCK ? rots_all : ((PATH == PATH_MIXED || PATH == PATH_ANY) ? (uint32_t)P.block_rots : 0u);
+    const bool use_lists = PATH == PATH_GENERIC || PATH == PATH_MIXED || (PATH == PATH_ANY && !use_box && brots != rots_all);
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     constexpr int SRW = sizeof(ShapeRot) / 4;                // ShapeRot as dwords
@@ -966,7 +971,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     for (int r = 0; r < 8; ++r) {
         zs[r] = 1e3;
         vs[r] = false;
-        if (r >= R) continue;
+        if (r >= R || !((brots >> r) & 1u)) continue;
         const ShapeRot* sp = (const ShapeRot*)srw + r;
         const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
         const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
@@ -1015,7 +1020,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const int s_ax = __builtin_amdgcn_readfirstlane(sp->ax), s_ay = __builtin_amdgcn_readfirstlane(sp->ay);
         const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
         const double ext_z_r = sp->ext_z_r;
-        const int ncell = ncell_next, off0 = off_next;
+        const int ncell = ((brots >> r) & 1u) ? ncell_next : 0, off0 = off_next;     // (a list rotation has no blocks: nblk = 0 anyway)
         Cell c = pre;
         if (r + 1 < R) {                                     // issue the next rotation's first chunk now
             const ShapeRot* sn = sp + 1;
@@ -1064,7 +1069,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 }
             }
         }
-        if (in_range) {
+        if (in_range && ((brots >> r) & 1u)) {
             zs[r] = m;
             vs[r] = round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;     // np.round(.,6) <= 0 (space.py:120)
         }
@@ -1078,7 +1083,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         level_code[r] = 255;
-        if (r >= R) continue;
+        if (r >= R || (!use_box && !((brots >> r) & 1u))) continue;      // (a list rotation: below)
         const double z = zs[r];
         const bool valid = vs[r];
         if (tid < AC) {
@@ -1111,7 +1116,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // be serialised by the LDS lane by lane)
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-        if (r >= R) continue;
+        if (r >= R || (!use_box && !((brots >> r) & 1u))) continue;
         const int code = level_code[r];
         unsigned long long todo = __ballot(code != 255), bits = 0ull;
         while (todo) {
@@ -1122,7 +1127,8 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
     }
     }
-    } else {
+    }
+    if (use_lists) {
     // ---- generic path: ONE action cell per lane, and only cells that can be in range.  A wave task is (rotation r,
     // row group q): the wave's lanes are 64 >> ysh consecutive rows X of the action grid times 1 << ysh >= Ay
     // columns Y, and only the rows X <= Ax - ax_r get a task at all.  The lane walks the rotation's masked-in bottom
@@ -1152,7 +1158,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     // before the rotation.  (As three unrolled 8-element arrays in scalar registers with their select chains it cost the
     // capped build most of its 137 SGPR spills.)
     int my_grp = 0;
-    if (lane < R && item >= 0) {
+    if (lane < R && item >= 0 && !((brots >> lane) & 1u)) {            // (PATH_MIXED: the block loop above served the rotations of brots)
         const ShapeRot* sp = (const ShapeRot*)srw + lane;
         const int wx = Ax - sp->ax + 1, wy = Ay - sp->ay + 1;
         if (wx > 0 && wy > 0) my_grp = (wx + rpw - 1) >> (6 - ysh);
@@ -1283,7 +1289,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         for (int i = tid; i < R * AC; i += BLOCK) {
             const int r = fdiv(i, AC, P.mg_ac), cell = i - r * AC, X = fdiv(cell, Ay, P.mg_ay), Y = cell - X * Ay;
             const ShapeRot* sp = (const ShapeRot*)srw + r;
-            if (item < 0 || X > Ax - sp->ax || Y > Ay - sp->ay) {
+            if (((brots >> r) & 1u) == 0u && (item < 0 || X > Ax - sp->ax || Y > Ay - sp->ay)) {
                 const KernArgsPtr ka = cold_args();
                 ka->io.posz_out[((size_t)b * R + r) * AC + cell] = 1e3;
                 ka->io.mask_out[((size_t)b * R + r) * AC + cell] = 0;
@@ -1819,6 +1825,7 @@ IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s1, true, 1)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s2, true, 2)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s3, true, 3)
 IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s4, true, 4)
+IRBPP_EMIT_KERNEL(irbpp_emit_kernel_s5, true, 5)
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -1983,6 +1990,7 @@ IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel, 0)
 #ifndef IRBPP_NO_SPEC
 IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel_s1, 1)
 IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel_s2, 2)
+IRBPP_EMIT_WAVE_KERNEL(irbpp_emit_wave_kernel_s5, 5)
 #endif
 
 // ---------------------------------------------------------------------------------------
@@ -2588,12 +2596,14 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, 0, IRBPP_CAPPED)
 // accord -- changes the compiler's scheduling for the worse: general 12.8 -> 11.7, abc_fine 5.2 -> 3.8 M steps/s)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, 0, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, 0, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_mixed8, PATH_MIXED, 0, IRBPP_CAPPED)
 // specialised builds (irbpp_device.h: SPEC_KEYS): the geometries of BASELINE.json's configs as compile-time constants
 #ifndef IRBPP_NO_SPEC
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s1, PATH_BLOCK, 1, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s2, PATH_BOX, 2, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s3, PATH_GENERIC, 3, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
+IRBPP_ENV_KERNEL(irbpp_env_kernel_s5, PATH_MIXED, 5, IRBPP_CAPPED)
 #endif
 
 #else
@@ -2697,11 +2707,11 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         if (obs_item >= T.n_shapes) obs_item = -1;
         debug_out = true;
     } else if (mode == MODE_CANDS) {     // PackingGame.get_action_candidates (binPhy.py:161-169)
-        int oa = io.actions[b];
+        int oa = io.fixed_slot ? io.fixed_slot - 1 : io.actions[b];
         oa += oa < 0 ? P.K : 0;                  // next_k_item_ID[orderAction] (binPhy.py:163): a list index
         if (oa < 0 || oa >= P.K) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ACTION); oa = oa < 0 ? 0 : P.K - 1; }
         obs_item = q[oa];
-        if (tid == 0) S.bs[b].order_action = oa;
+        if (tid == 0 && !io.fixed_slot) S.bs[b].order_action = oa;     // (get_all_possible_observation, binPhy.py:171-180, leaves self.orderAction alone)
     } else if (mode == MODE_OBSERVE) {   // cur_observation of the item the split step left at the head of the queue
         obs_item = ob_item;
         sr_staged = ob_staged;

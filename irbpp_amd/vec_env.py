@@ -168,6 +168,17 @@ class GpuPackingEnv(object):
                    "irbpp_get_action_candidates")
         return obs
 
+    def get_all_possible_observation(self, obs_out: Optional[torch.Tensor] = None, stream=None) -> torch.Tensor:
+        """PackingGame.get_all_possible_observation (binPhy.py:171-180) of every bin: float32[N, k, loc_obs_len], the
+        location observation of each buffer slot on the current heightmap (row b reshaped to -1 is the reference's
+        concatenation).  The candidate rows a following step indexes are the last slot's, the chosen slot stays."""
+        obs = obs_out if obs_out is not None else \
+            torch.empty((self.num_bins, self.K, self.loc_obs_len), dtype=torch.float32, device=self.device)
+        assert obs.is_contiguous() and obs.shape == (self.num_bins, self.K, self.loc_obs_len)
+        _lib.check(self.lib.irbpp_get_all_possible_observation(self._h, _ptr(obs), self._stream(stream)),
+                   "irbpp_get_all_possible_observation")
+        return obs
+
     def policy_minz(self, loc_obs: torch.Tensor, actions_out: Optional[torch.Tensor] = None) -> torch.Tensor:
         act = actions_out if actions_out is not None else \
             torch.empty((self.num_bins,), dtype=torch.int32, device=self.device)
@@ -438,6 +449,15 @@ class GroupedPackingEnv(object):
             self.get_action_candidates_group(g, order_actions[self.rows(g)], obs_out=obs[self.rows(g)])
         return obs
 
+    def get_all_possible_observation(self) -> torch.Tensor:
+        """float32[N, k, loc_obs_len]: every buffer slot of every bin (binPhy.py:171-180), each group on its own stream."""
+        k = self.groups[0].K
+        obs = torch.empty((self.num_bins, k, self.loc_obs_len), dtype=torch.float32, device=self.device)
+        for g in range(self.num_groups):
+            self._enter(g, obs)
+            self.groups[g].get_all_possible_observation(obs_out=obs[self.rows(g)], stream=self.streams[g])
+        return obs
+
     def reset_bins(self, bins: torch.Tensor) -> torch.Tensor:
         """PackingGame.reset of the listed bins (distinct global-to-this-env indices), rows in list order."""
         self.synchronize()
@@ -640,7 +660,7 @@ class GpuVecEnv(object):
         self.num_groups = int(num_groups)
         if self.num_groups == 0:            # the library's own choice (groups_for): which overlap path does this data set take?
             probe = GpuPackingEnv(shapes, sequences[:1], 1, device=device, **{k: v for k, v in env_kw.items() if k != "item_stream"})
-            generic = probe.lib.irbpp_overlap_path(probe._h) == 3
+            generic = probe.lib.irbpp_overlap_path(probe._h) in (3, 4)        # cell lists for all or some rotations
             fine = probe.Hx * probe.Hy > 32 * 32
             probe.close()
             self.num_groups = groups_for(("abc_fine" if fine else "general") if generic else "lattice", num_envs,
@@ -834,6 +854,19 @@ class GpuVecEnv(object):
             self._loc_turn = (self._loc_turn + 1) % len(self._loc_ring)
         loc = self.env.get_action_candidates(self._actions_to_device(order_actions, "cands"), obs_out=out)
         self._staging_release("cands")
+        if self.candidates_on_device:
+            return loc
+        if self.num_groups > 1:
+            self.env.synchronize()
+        return loc.cpu().numpy()
+
+    def get_all_possible_observation(self):
+        """PackingGame.get_all_possible_observation (binPhy.py:171-180) of every env: [N, k * (5S+9+Hc)] -- per env the
+        concatenation of its k location observations -- as a host float32 array, or the device tensor with
+        ``candidates_on_device``.  (The reference has no caller for it and ShmemVecEnv no command: this is the method a
+        maintainer would forward.)"""
+        loc = self.env.get_all_possible_observation()
+        loc = loc.reshape(self.num_envs, -1)
         if self.candidates_on_device:
             return loc
         if self.num_groups > 1:

@@ -191,6 +191,16 @@ class PackingGame(object):
         self.orderAction = orderAction
         return locObservation
 
+    def get_all_possible_observation(self):                      # binPhy.py:171-180 (no caller in the reference)
+        self.chooseItem = False
+        all_obs = []
+        for itemID in self.next_k_item_ID:
+            self.next_item_ID = itemID
+            self.space.get_possible_position(self.next_item_ID)
+            all_obs.append(self.cur_observation(genItem=False))
+        self.chooseItem = True       # (the reference leaves it False, which would turn the next order observation into a location
+        return np.concatenate(all_obs, axis=0)      # observation with a fresh item: nobody calls it there; kept usable here)
+
     # -- observation -------------------------------------------------------------------
     def cur_observation(self, genItem=True):
         if not self.chooseItem:
@@ -314,6 +324,9 @@ class OracleVecEnv(object):
 
     def get_action_candidates(self, order_actions):
         return np.array([e.get_action_candidates(int(a)) for e, a in zip(self.envs, order_actions)])
+
+    def get_all_possible_observation(self):
+        return np.array([e.get_all_possible_observation() for e in self.envs])
 
     def step(self, actions):
         obs, rews, dones, infos = [], [], [], []

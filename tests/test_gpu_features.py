@@ -231,7 +231,7 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
 
 @pytest.mark.parametrize("workload,n,steps,spec", [("blockout", 160, 130, "_s1"), ("cube", 128, 60, "_s2"), ("general", 96, 45, "_s3"),
                                                    ("abc_fine", 64, 40, "_s4_w512"), ("blockout_k10", 96, 120, "_s1"),
-                                                   ("blockout_r8", 96, 100, "_s3")])
+                                                   ("blockout_r8", 96, 100, "_s5")])
 def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, spec):
     """BASELINE.json's geometries run builds of the transition and emit kernels that have the grid sizes, LDS offsets and
     division constants as compile-time literals (irbpp_device.h: SPEC_KEYS), and a step applies its actions in
@@ -247,13 +247,15 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     flags = [0, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT, _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
              _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
              _lib.TUNE_NO_WG512, _lib.TUNE_WG512,          # (256- / 512-thread workgroups of the generic path whatever the data)
-             _lib.TUNE_NARROW_KERNEL | _lib.TUNE_WG512]    # (the 512-thread build under the 64-VGPR cap: the default from 4096 bins on)
+             _lib.TUNE_NARROW_KERNEL | _lib.TUNE_WG512,    # (the 512-thread build under the 64-VGPR cap: the default from 4096 bins on)
+             _lib.TUNE_NO_MIXED_PATH]                      # (BlockOut at eight rotations through the cell lists entirely, as until round 5)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
     assert names[1] == names[4] and "_s" not in names[1].replace("irbpp_env_kernel", ""), names
     assert "w512" not in names[5] and (("w512" in names[6]) == ("generic" in names[4] or "_s3" in names[0] or "_s4" in names[0])), names
     assert names[7] == ("irbpp_env_kernel_s4_w512c" if workload == "abc_fine" else names[7].replace("w512", "")), names
+    assert names[8] == ("irbpp_env_kernel_s3" if workload == "blockout_r8" else names[0]), names
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)
@@ -322,3 +324,54 @@ def test_wave_emit_serves_bins_that_need_the_workgroup():
     for e in (wave, block):
         e.check_device_error()
         e.close()
+
+
+@pytest.mark.parametrize("n,groups", [(5, 1), (16, 2)])
+def test_get_all_possible_observation_matches_k_single_calls_and_the_oracle(n, groups):
+    """PackingGame.get_all_possible_observation (binPhy.py:171-180): the location observation of EVERY buffer slot of every
+    bin in one call ([N, k * (5S+9+Hc)]), against k calls of get_action_candidates and against the oracle's restatement;
+    and its side effects as the reference has them: a step that follows indexes the LAST slot's candidate rows and pops the
+    slot chosen before."""
+    from oracle.packing import OracleVecEnv
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    k = 4
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k, num_groups=groups)
+    genv.candidates_on_device = True
+    oenv = OracleVecEnv(n, sh, seqs, bufferSize=k)
+    np.testing.assert_array_equal(genv.reset().cpu().numpy(), _f32(oenv.reset()))
+    L = 5 * S + 9 + 1024
+    done_total = 0
+    for t in range(50 if n < 8 else 24):
+        every = genv.get_all_possible_observation()
+        if groups > 1:
+            genv.env.synchronize()
+        every = every.cpu().numpy()
+        assert every.shape == (n, k * L)
+        np.testing.assert_array_equal(every, _f32(oenv.get_all_possible_observation()), err_msg=f"placement {t}")
+        for j in range(k):
+            single = genv.get_action_candidates(np.full(n, j))
+            if groups > 1:
+                genv.env.synchronize()
+            np.testing.assert_array_equal(single.cpu().numpy(), every[:, j * L:(j + 1) * L], err_msg=f"slot {j}, placement {t}")
+            oenv.get_action_candidates(np.full(n, j))
+        # (the single calls left slot k - 1 chosen on both sides)
+        if t % 3 == 2:
+            # a step straight after get_all_possible_observation: the last slot's rows, the slot chosen before
+            every = genv.get_all_possible_observation().reshape(n, k, L)
+            oenv.get_all_possible_observation()
+            loc = every[:, k - 1]
+        else:
+            oa = (np.arange(n) + t) % k
+            loc = genv.get_action_candidates(oa)
+            oenv.get_action_candidates(oa)
+        act = genv.env.policy_minz(loc.contiguous()).cpu().numpy()
+        gobs, grew, gdone, _ = genv.step(act)
+        oobs, orew, odone, _ = oenv.step(act)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(oobs), err_msg=f"order observation, placement {t}")
+        np.testing.assert_array_equal(gdone, odone)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], orew.astype(np.float32))
+        done_total += int(odone.sum())
+    assert done_total >= (1 if n < 8 else 0)
+    genv.env.check_device_error()
+    genv.close()

@@ -41,7 +41,7 @@ def _fallback_rows(n_rot):
 
 @pytest.mark.parametrize("name,n,kernels", [
     ("bench_blockout_r4", 8192, ("irbpp_env_kernel_s1", "irbpp_trace_kernel +", "irbpp_emit_wave_kernel_s1", "irbpp_apply_kernel in front")),
-    ("bench_blockout_r8", 4096, ("irbpp_trace_kernel +",)),
+    ("bench_blockout_r8", 4096, ("irbpp_env_kernel_s5", "irbpp_trace_kernel +", "irbpp_emit_wave_kernel_s5")),
     ("bench_general", 4096, ("irbpp_env_kernel_s3", "irbpp_trace_kernel +", "irbpp_emit_kernel_s3")),
     ("bench_abc_fine", 4096, ("irbpp_env_kernel_s4_w512c", "irbpp_emit_kernel_s4"))])
 def test_reference_goldens_replayed_by_every_bin_of_a_large_launch(golden_dir, name, n, kernels):
@@ -114,7 +114,8 @@ def test_reference_hierarchical_golden_replayed_by_every_bin(golden_dir, n):
 
 @pytest.mark.parametrize("workload,n,groups,steps,min_episodes", [
     ("blockout", 4096, 1, 130, 2048), ("blockout", 8192, 2, 40, 0), ("cube", 4096, 1, 40, 2048), ("general", 2048, 2, 30, 2048),
-    ("blockout_k10", 2048, 1, 130, 512), ("blockout_k10", 1024, 1, 40, 0), ("abc_fine", 4096, 1, 12, 1024)])
+    ("blockout_k10", 2048, 1, 130, 512), ("blockout_k10", 1024, 1, 40, 0), ("abc_fine", 4096, 1, 12, 1024),
+    ("blockout_r8", 2048, 1, 130, 512)])
 def test_every_bin_of_a_large_launch_vs_c_oracle(workload, n, groups, steps, min_episodes):
     """ALL bins of the bench's workloads against the plain-C oracle (tools/soak_parity.py as a test): every observation,
     reward and done flag of every bin at every step, through auto-resets, as one launch group and as two on two streams."""
@@ -132,6 +133,8 @@ def test_every_bin_of_a_large_launch_vs_c_oracle(workload, n, groups, steps, min
         assert ("irbpp_apply_kernel in front" in info) == (per_launch >= 4096), info
     if workload == "abc_fine":
         assert "irbpp_env_kernel_s4_w512c" in info, info
+    if workload == "blockout_r8":
+        assert "irbpp_env_kernel_s5" in info, info             # rotations 0 .. 3 on the block path, 4 .. 7 on their cell lists
     cenv = COracleVecEnv(n, shapes, seqs, threads=THREADS, **kw)
     gobs = genv.reset()
     np.testing.assert_array_equal(gobs.cpu().numpy(), _f32(cenv.reset()))
