@@ -95,9 +95,11 @@ int raise_lds_limits() {
     const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_env_kernel_box,
                              (const void*)irbpp_env_kernel_box8, (const void*)irbpp_env_kernel_generic,
                              (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_env_kernel_mixed8, (const void*)irbpp_hull_kernel,
+                             (const void*)irbpp_env_kernel_chain,
 #if !defined(IRBPP_NO_SPEC)
                              (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_env_kernel_s5, (const void*)irbpp_emit_kernel_s5,
+                             (const void*)irbpp_env_kernel_chain_s1,
                              (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
                              (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2, (const void*)irbpp_emit_wave_kernel_s5,
@@ -115,6 +117,13 @@ int raise_lds_limits() {
 
 // lattice data through and through (every rotation on the block path) or box data: what the wave-per-bin emit kernel and the
 // early split of the apply phase are for; a data set with list rotations (PATH_MIXED) is treated like free-form data there
+// radix counters / sort keys of the emit routine's > S selection, behind the transition kernel's carve-up (CHAIN builds): the
+// emit kernel's own e_hist region (irbpp_device.h: layout_lds)
+static int chain_extra_lds(const Params& P) {
+    int npad = 64;
+    while (npad < P.S) npad <<= 1;
+    return align16(10 * npad > 1024 ? 10 * npad : 1024);
+}
 static bool all_block(const Params& P) { return P.block_b > 0 && P.block_rots == (1 << P.R) - 1; }
 static bool lattice_or_box(const Params& P) { return all_block(P) || P.box != 0; }
 // ... except in what its level images look like: unions of rectangles with a few dozen candidates per bin, practically never more
@@ -592,6 +601,26 @@ static int pick_trace_cpw(const irbpp_env* env, int n) {
     return n <= TRACE_CPW16_BINS ? 16 : (n <= TRACE_CPW32_BINS ? 32 : 64);
 }
 
+// One kernel per observation (OPT-IN, IRBPP_TUNE_CHAIN): the bin's own workgroup finishes its observation (CHAIN builds of the
+// transition kernel: contour stage and candidate rows in LDS, no trace / polygon / emit launches).  Built for launches of up to
+// ~2048 bins, where a step is a chain of launch and drain latencies whatever the number of bins, and measured SLOWER there
+// (profiles/r06/LOG.md session 6, placement-steps/s one kernel vs four): a buffered placement at 512 / 1024 / 2048 bins 8.1 vs
+// 9.0 / 12.8 vs 16.3 / 16.5 vs 25.9 M, BlockOut online at 1024 / 2048 bins 14.4 vs 18.7 / 18.0 vs 29.7 M, free-form solids at
+// 1024 bins 3.2 vs 8.7 M; only the Cube set gains (26.7 vs 24.4 M at 1024 bins).  A bin's observation is ~25 borders to follow
+// and approximate: inside its own workgroup that is one serial latency chain per bin on a CU with nobody else to issue,
+// while the split kernels spread the borders of ALL bins over every SIMD of the chip; the launch boundaries they pay
+// (~3 us each) are the smaller price.
+static bool chain_launch(const irbpp_env* env, int n) {
+    const int t = env->cfg.tuning;
+    (void)n;
+    if (!(t & IRBPP_TUNE_CHAIN) || env->P.stability != 0) return false;
+    if (t & (IRBPP_TUNE_TRACE_CPW64 | IRBPP_TUNE_TRACE_CPW32 | IRBPP_TUNE_TRACE_CPW16 | IRBPP_TUNE_TRACE_REFILL | IRBPP_TUNE_INLINE_POLYGON |
+             IRBPP_TUNE_BLOCK_EMIT | IRBPP_TUNE_WAVE_EMIT | IRBPP_TUNE_SPLIT_APPLY | IRBPP_TUNE_GRAPH | IRBPP_TUNE_WG512 | IRBPP_TUNE_NARROW_KERNEL))
+        return false;                                          // (a caller that forces a shape of the split pipeline gets the split pipeline)
+    if (env->P.lds_bytes > 32 * 1024) return false;            // (the 64 x 64 heightmap: 512-thread workgroups on a 40 KB tile, not this)
+    return true;
+}
+
 // One launch group: the launch slots [first, first + n) of a transition -- order (for step / candidates), the
 // transition kernel and, in the split pipeline, trace and emit -- on one stream.
 static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, int first, int n) {
@@ -614,7 +643,8 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         }
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
     // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
-    const bool split = env->P.split && observes;
+    const bool chain = observes && mode != MODE_POSSIBLE && chain_launch(env, n);
+    const bool split = env->P.split && observes && !chain;
     // expensive bins first in the emit kernel: free-form level images only (lattice and box data never get there), not for a
     // listed reset (its observation rows go by list position)
     const bool heavy_first = split && env->P.heavy_cap > 0 && !lattice_images(env->P) && io.bin_list == nullptr &&
@@ -622,6 +652,13 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
     io.heavy_turn = heavy_first ? env->heavy_turn : -1;
     if (heavy_first) env->heavy_turn ^= 1;
     int env_mode = mode;
+    if (chain && !(mode == MODE_STEP && env->P.K > 1)) {
+        // (a buffered step is the apply kernel below: it observes nothing)
+        const bool s1 = pick_spec(env) == 1;
+        hipLaunchKernelGGL(s1 ? irbpp_env_kernel_chain_s1 : irbpp_env_kernel_chain, dim3(n), dim3(256), env->P.lds_bytes + chain_extra_lds(env->P), st,
+                           env->P, env->T, env->S, io, mode);
+        return;
+    }
     if (mode == MODE_STEP && split_apply(env, n)) {
         // a buffered step: a workgroup per bin at launches of fewer than 2048 bins (a wave per bin leaves most of the chip
         // to one dependent chain per CU there: 15.7 vs 15.3 M at 1024 bins), a wave per bin from there on (every bin resident
@@ -1077,6 +1114,11 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
              pick_env_kernel(env).name, cpw > 64 ? "_refill" : cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
              !split_apply(env, n) ? "" : (env->P.K > 1 ? (n < 2048 ? " (step: irbpp_apply_wg_kernel alone)" : " (step: irbpp_apply_kernel alone)")
                                                        : " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)"));
+    if (chain_launch(env, n)) {
+        const bool s1 = spec == 1;
+        snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s alone (observation finished in the bin's workgroup)%s",
+                 s1 ? "irbpp_env_kernel_chain_s1" : "irbpp_env_kernel_chain", env->P.K > 1 ? " (step: irbpp_apply_wg_kernel alone)" : "");
+    }
     *kernel_name = env->kernel_names;
     return IRBPP_OK;
 }

@@ -1307,9 +1307,10 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 // ---------------------------------------------------------------------------------------
 // Location observation for `item` on the heightmap tile in LDS (binPhy.py:188-227).
 // ---------------------------------------------------------------------------------------
-template <int PATH>
+template <int PATH, bool CHAIN = false>
 __device__ inline void observe_location(const Params& P, const Tables& T, const State& S, const StepIO& io,
-                                        const Lds& L, int b, int item, float* obs, bool debug_out, bool sr_staged) {
+                                        const Lds& L, int b, int item, float* obs, bool debug_out, bool sr_staged,
+                                        unsigned char* chain_lds = nullptr) {
     item = __builtin_amdgcn_readfirstlane(item);     // block-uniform: footprint reads become scalar loads
     const int tid = threadIdx.x;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
@@ -1327,6 +1328,29 @@ __device__ inline void observe_location(const Params& P, const Tables& T, const 
     if (io.phase_cycles && tid == 0)
         for (int k = 5; k < PHASE_ROW; ++k)
             if (k < 8 || k > 10) io.phase_cycles[(size_t)b * PHASE_ROW + k] = 0;
+    if constexpr (CHAIN) {
+        // Small launches (irbpp_capi.hip: chain_launch): the bin's own workgroup finishes the observation -- level images, border
+        // following, approxPolyDP + convexity (contour_stage: the hull kernel's in-workgroup form of the same routines), then the
+        // candidate rows (emit_observation) -- with LDS hand-over: ONE launch per observation instead of four, where the chip has
+        // idle CUs anyway and the step is a chain of launch latencies.  Same results: same routines on the same level codes.
+        {   // naiveMask's bit rows: what the next apply looks its drop height up with, and the no-candidate fallback below
+            // (they share their LDS bytes with the task index the contour stage builds next)
+            uint32_t* gb = S.w_valid + (size_t)b * P.R * 16;
+#pragma unroll 1
+            for (int i = tid; i < P.R * 16; i += BLOCK) gb[i] = L.vbits[i];
+        }
+        __syncthreads();
+        ::irbpp::contour_stage(P, S, L, nullptr);
+        // posZmap (w_posz) and the bit rows were stored by this workgroup's threads and are read back by others below: workgroup
+        // scope (one CU, one L1: the release is a wait for the stores)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        Lds Le = L;
+        Le.img = (uint16_t*)chain_lds;               // radix counters / sort keys of a > S selection: behind the transition kernel's own carve-up
+        ::irbpp::emit_observation(P, S, io, Le, b, item, nvalid, obs, S.w_posz + (size_t)b * R * AC, S.w_valid + (size_t)b * R * 16);
+        return;
+    }
     // the trace and emit kernels take it from here
     IRBPP_HERE split_handover<(CONTOUR_IPT * 256) / BLOCK>(P, S, L, b, (int)blockIdx.x + io.block_off, item, nvalid);    // (32 level images per batch)
     if (io.phase_cycles && tid == 0)             // tooling: cycles of the hand-over (images, candidates, stores)
@@ -2569,7 +2593,7 @@ irbpp_polygon_kernel(const Params P, const State S
 // are exactly two rounds of the chip (measured on the block path: 24.5 / 25.1 / 25.6 M steps/s at 6 / 7 / 8 workgroups
 // per CU).  irbpp_env_kernel_wide decides the path at run time and lets the register allocator have what it wants: the
 // fallback that irbpp_config::tuning can force for A/B measurements (see pick_env_kernel in irbpp_capi.hip).
-template <int PATH, int SPEC, bool FUSED>
+template <int PATH, int SPEC, bool FUSED, bool CHAIN = false>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem);
 
@@ -2597,6 +2621,14 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_generic8, PATH_GENERIC, 0, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_generic, PATH_GENERIC, 0, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_wide, PATH_ANY, 0, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_mixed8, PATH_MIXED, 0, IRBPP_CAPPED)
+// CHAIN builds (launches of up to CHAIN_BINS bins): the whole observation in the bin's workgroup, one launch (observe_location)
+#define IRBPP_ENV_KERNEL_CHAIN(NAME, PATH, SPEC)                                                                        \
+    extern "C" __global__ void __launch_bounds__(BLOCK)                                                                \
+    NAME(const Params P, const Tables T, const State S, const StepIO io, const int mode) {                             \
+        extern __shared__ __attribute__((aligned(16))) unsigned char smem[];                                           \
+        env_transition<PATH, SPEC, true, true>(P, T, S, io, mode, smem);                                               \
+    }
+IRBPP_ENV_KERNEL_CHAIN(irbpp_env_kernel_chain, PATH_ANY, 0)
 // specialised builds (irbpp_device.h: SPEC_KEYS): the geometries of BASELINE.json's configs as compile-time constants
 #ifndef IRBPP_NO_SPEC
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s1, PATH_BLOCK, 1, IRBPP_CAPPED)
@@ -2604,6 +2636,7 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_s2, PATH_BOX, 2, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s3, PATH_GENERIC, 3, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s4, PATH_GENERIC, 4, )
 IRBPP_ENV_KERNEL(irbpp_env_kernel_s5, PATH_MIXED, 5, IRBPP_CAPPED)
+IRBPP_ENV_KERNEL_CHAIN(irbpp_env_kernel_chain_s1, PATH_BLOCK, 1)
 #endif
 
 #else
@@ -2621,7 +2654,7 @@ IRBPP_ENV_KERNEL_512(irbpp_env_kernel_s4_w512c, PATH_GENERIC, 4, __attribute__((
 #endif
 #endif  // IRBPP_PASS
 
-template <int PATH, int SPEC, bool FUSED>
+template <int PATH, int SPEC, bool FUSED, bool CHAIN>
 __device__ __forceinline__ void env_transition(const Params& P_run, const Tables& T, const State& S, const StepIO& io,
                                                const int mode, unsigned char* smem) {
     if constexpr (!FUSED) { if (mode == MODE_STEP) return; }         // (never launched that way: irbpp_capi.hip)
@@ -2940,7 +2973,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
             for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)L.hm[tile_of_linear(P, i)];
         }
     }
-    if (do_observe) IRBPP_HERE observe_location<PATH>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged);
+    if (do_observe) IRBPP_HERE observe_location<PATH, CHAIN>(P, T, S, io, L, b, obs_item, obs, debug_out, sr_staged, smem + P.lds_bytes);
 }
 
 #if IRBPP_PASS == 1

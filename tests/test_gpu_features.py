@@ -208,7 +208,8 @@ def test_trace_launch_shapes_change_nothing(workload, n, steps):
     shapes, seqs, kw = make_workload(workload)
     flags = [_lib.TUNE_TRACE_CPW64, _lib.TUNE_TRACE_CPW32, _lib.TUNE_TRACE_CPW16,
              _lib.TUNE_INLINE_POLYGON, _lib.TUNE_TRACE_CPW16 | _lib.TUNE_INLINE_POLYGON, _lib.TUNE_NO_HEAVY_FIRST,
-             _lib.TUNE_TRACE_REFILL, _lib.TUNE_TRACE_REFILL | _lib.TUNE_INLINE_POLYGON]      # (lane refill: the default of large launches)
+             _lib.TUNE_TRACE_REFILL, _lib.TUNE_TRACE_REFILL | _lib.TUNE_INLINE_POLYGON,      # (lane refill: opt-in, measured slower)
+             _lib.TUNE_CHAIN]                                                                # (one kernel per observation: opt-in, measured slower)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, **kw)] + \
            [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     obs = [e.reset() for e in envs]
@@ -248,7 +249,8 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
              _lib.TUNE_SPLIT_APPLY | _lib.TUNE_WAVE_EMIT | _lib.TUNE_GRAPH, _lib.TUNE_NO_SPECIALISED | _lib.TUNE_FUSED_APPLY | _lib.TUNE_BLOCK_EMIT,
              _lib.TUNE_NO_WG512, _lib.TUNE_WG512,          # (256- / 512-thread workgroups of the generic path whatever the data)
              _lib.TUNE_NARROW_KERNEL | _lib.TUNE_WG512,    # (the 512-thread build under the 64-VGPR cap: the default from 4096 bins on)
-             _lib.TUNE_NO_MIXED_PATH]                      # (BlockOut at eight rotations through the cell lists entirely, as until round 5)
+             _lib.TUNE_NO_MIXED_PATH,                      # (BlockOut at eight rotations through the cell lists entirely, as until round 5)
+             _lib.TUNE_CHAIN]                              # (ONE kernel per observation: contour stage and candidate rows in the bin's workgroup)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
@@ -256,6 +258,8 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     assert "w512" not in names[5] and (("w512" in names[6]) == ("generic" in names[4] or "_s3" in names[0] or "_s4" in names[0])), names
     assert names[7] == ("irbpp_env_kernel_s4_w512c" if workload == "abc_fine" else names[7].replace("w512", "")), names
     assert names[8] == ("irbpp_env_kernel_s3" if workload == "blockout_r8" else names[0]), names
+    chain = "irbpp_env_kernel_chain_s1 alone" if spec == "_s1" else "irbpp_env_kernel_chain alone"
+    assert names[9].startswith(chain) == (workload != "abc_fine"), names      # (not for the 40 KB tile)
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)
