@@ -550,8 +550,10 @@ def main():
         out = {
             "metric": "env steps/sec (placements/sec) across N parallel bins",
             "value": total_steps / elapsed, "unit": "placement-steps/s",
-            "n_gpus": world, "steps": timed_steps, "steps_requested": a.steps, "steps_per_block": a.steps,
-            "timed_blocks": timed_steps // a.steps, "min_seconds": a.min_seconds,
+            # `steps` = the K of the contract: every timed block is EXACTLY K steps between barrier + synchronize on both sides; the block
+            # is repeated until the blocks add up to --min-seconds and `value` / `ms_per_step` are the mean over the blocks
+            "n_gpus": world, "steps": a.steps, "steps_per_block": a.steps, "timed_blocks": timed_steps // a.steps,
+            "steps_timed_total": timed_steps, "min_seconds": a.min_seconds,
             "warmup": a.warmup, "prefill_steps": a.prefill,
             "ms_per_step": elapsed / timed_steps * 1e3, "higher_is_better": True, "scaling": scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",

@@ -99,7 +99,7 @@ int raise_lds_limits() {
 #if !defined(IRBPP_NO_SPEC)
                              (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_env_kernel_s5, (const void*)irbpp_emit_kernel_s5,
-                             (const void*)irbpp_env_kernel_chain_s1,
+                             (const void*)irbpp_env_kernel_chain_s1, (const void*)wg128::irbpp_env_kernel_s1_w128,
                              (const void*)irbpp_emit_kernel_s1, (const void*)irbpp_emit_kernel_s2,
                              (const void*)irbpp_emit_kernel_s3, (const void*)irbpp_emit_kernel_s4,
                              (const void*)irbpp_emit_wave_kernel_s1, (const void*)irbpp_emit_wave_kernel_s2, (const void*)irbpp_emit_wave_kernel_s5,
@@ -557,6 +557,8 @@ static EnvKernel pick_env_kernel(const irbpp_env* env) {
     if (wg512 && (pick_spec(env) == 0 || (t & IRBPP_TUNE_WG512)))
         return {wg512::irbpp_env_kernel_generic_w512, "irbpp_env_kernel_generic_w512", 512};
 #if !defined(IRBPP_NO_SPEC) && !defined(IRBPP_ABLATE)
+    if ((t & IRBPP_TUNE_WG128) && pick_spec(env) == 1)
+        return {wg128::irbpp_env_kernel_s1_w128, "irbpp_env_kernel_s1_w128", 128};        // (A/B: two waves per bin)
     switch (pick_spec(env)) {            // (a key fixes the overlap path: block_b and box are pinned fields)
         case 1: return {irbpp_env_kernel_s1, "irbpp_env_kernel_s1"};
         case 2: return {irbpp_env_kernel_s2, "irbpp_env_kernel_s2"};

@@ -40,22 +40,31 @@
 
 // (a call from twice-compiled code to a twice-compiled function names its namespace: argument-dependent lookup would
 // otherwise find the pass-1 function beside the pass-2 one)
+// (round 6: a THIRD pass, namespace irbpp::wg128, BLOCK = 128 -- two waves per bin for the block path of lattice data, whose
+// per-wave prologue, scalar bookkeeping and hand-over control are then executed twice per bin instead of four times)
 #undef IRBPP_HERE
+#undef IRBPP_PASS_NS
 #if IRBPP_PASS == 1
 #define IRBPP_HERE ::irbpp::
-#else
+#elif IRBPP_PASS == 2
 #define IRBPP_HERE ::irbpp::wg512::
+#define IRBPP_PASS_NS wg512
+#else
+#define IRBPP_HERE ::irbpp::wg128::
+#define IRBPP_PASS_NS wg128
 #endif
 
 namespace irbpp {
-#if IRBPP_PASS == 2
-namespace wg512 {
+#if IRBPP_PASS != 1
+namespace IRBPP_PASS_NS {
 #endif
 
 #if IRBPP_PASS == 1
 constexpr int BLOCK = 256;
-#else
+#elif IRBPP_PASS == 2
 constexpr int BLOCK = 512;                       // second pass: the transition kernel's code again for 512-thread workgroups (see the end of the file)
+#else
+constexpr int BLOCK = 128;                       // third pass: two waves per bin
 #endif
 constexpr int WAVES = BLOCK / 64;
 
@@ -416,7 +425,6 @@ template <int IPT>
 __device__ inline void contour_images(const Params& P, const Lds& L, uint16_t* const rows, int base, bool with_cols) {
     const int tid = threadIdx.x, R = P.R, AC = P.AC;
     constexpr int IMGS = IPT * (BLOCK / 16);
-    const int X = fdiv(tid, P.Ay, P.mg_ay), Y = tid - X * P.Ay;
     const int g = tid >> 4, y = tid & 15;            // this thread holds row y of the batch's images g, g+16, ...
     uint16_t* const cols = rows + IMGS * 16;         // [IMGS][16] column words (bit y of word x), after the row words
 #pragma unroll 1
@@ -426,13 +434,20 @@ __device__ inline void contour_images(const Params& P, const Lds& L, uint16_t* c
     // LDS atomic OR per rotation (16-bit half of a dword).  The lanes of a row hit one word and are serialised inside
     // the LDS unit, which has the time; building the words from wave ballots instead (one loop trip per distinct
     // image of the wave) cost ~30 VALU instructions per rotation and wave on a kernel that is VALU-bound.
+    // (two-wave build: two cells per thread)
+    constexpr int CELLS = BLOCK >= 256 ? 1 : 256 / BLOCK;
+#pragma unroll 1
+    for (int ci = 0; ci < CELLS; ++ci) {
+    const int cell = CELLS == 1 ? tid : tid + ci * BLOCK;
+    const int X = fdiv(cell, P.Ay, P.mg_ay), Y = cell - X * P.Ay;
     for (int r = 0; r < R; ++r) {
-        const int code = tid < AC ? (int)L.lev[r * AC + tid] : 255;
+        const int code = cell < AC ? (int)L.lev[r * AC + cell] : 255;
         int ti = code != 255 ? (int)L.taskidx[r * 64 + code] - base : -1;
         if (ti >= 0 && ti < IMGS) {
             const int w = ti * 16 + X;
             atomicOr((uint32_t*)rows + (w >> 1), (1u << Y) << ((w & 1) * 16));
         }
+    }
     }
     __syncthreads();
     if (!with_cols) return;
@@ -921,7 +936,13 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
     if (use_block || use_box) {
     // ---- one action cell per thread, all rotations: block path (footprint = list of uniform b x b blocks over the
     // block-max grid) or box path (footprint = one solid box: separable rectangle maximum) ---------------------------
-    const int X = fdiv(tid, Ay, P.mg_ay), Y = tid - X * Ay;
+    // (the two-wave build, BLOCK = 128: two cells per thread, one after the other; block path only)
+    constexpr int CELLS = BLOCK >= 256 ? 1 : 256 / BLOCK;
+    if (CELLS > 1 && use_box) __builtin_trap();
+#pragma unroll 1
+    for (int ci = 0; ci < CELLS; ++ci) {
+    const int cell = CELLS == 1 ? tid : tid + ci * BLOCK;
+    const int X = fdiv(cell, Ay, P.mg_ay), Y = cell - X * Ay;
     double zs[8];
     bool vs[8];
     if (use_box) {
@@ -948,7 +969,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                 }
             }
             __syncthreads();
-            const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+            const bool in_range = cell < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
             if (in_range) {
                 const double* colp = m1 + X * P.step * Ay + Y;
                 double m = -1e300;
@@ -977,7 +998,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         const int has_out = __builtin_amdgcn_readfirstlane(sp->has_out);
         const int ne = __builtin_amdgcn_readfirstlane(sp->nblk), e0 = __builtin_amdgcn_readfirstlane(sp->oblk) - bl_first;
         const double ext_z_r = sp->ext_z_r;
-        const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+        const bool in_range = cell < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
         if (in_range) {
             const char* const hb = (const char*)(L.mb + X * P.mb_w + Y);
             const bl_words* const be = bl + e0;                       // (one address for the whole wave: a broadcast read)
@@ -1029,7 +1050,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
             const Cell* cn = T.blkcell + off_next;
             if (ncell_next > 0) pre = cn[lane < ncell_next ? lane : ncell_next - 1];
         }
-        const bool in_range = tid < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+        const bool in_range = cell < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
         const double* h0 = L.mb + X * P.mb_w + Y;
         double m = has_out ? 0.0 : -1e300;
         // The block list is fetched 64 entries at a time, one 16-byte entry per lane (a coalesced
@@ -1086,15 +1107,15 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         if (r >= R || (!use_box && !((brots >> r) & 1u))) continue;      // (a list rotation: below)
         const double z = zs[r];
         const bool valid = vs[r];
-        if (tid < AC) {
+        if (cell < AC) {
             if (debug_out) {
                 const KernArgsPtr ka = cold_args();
-                ka->io.posz_out[((size_t)b * R + r) * AC + tid] = z;
-                ka->io.mask_out[((size_t)b * R + r) * AC + tid] = valid ? 1 : 0;
+                ka->io.posz_out[((size_t)b * R + r) * AC + cell] = z;
+                ka->io.mask_out[((size_t)b * R + r) * AC + cell] = valid ? 1 : 0;
             }
             int code = 255;
             if (valid) {
-                if (!debug_out) zdst[r * AC + tid] = z;                // (irbpp_possible_position leaves the last observation's hand-over alone: the next step reads its drop height there)
+                if (!debug_out) zdst[r * AC + cell] = z;                // (irbpp_possible_position leaves the last observation's hand-over alone: the next step reads its drop height there)
                 const int li = np_floor_divide_int(z, P.res_z, P.inv_res_z);   // cvTools.py:78
                 if (li != -1) {                                        // level -1 is skipped (cvTools.py:84)
                     const int idx = li + 32;
@@ -1102,14 +1123,14 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
                     else code = idx;
                 }
                 ++my_valid;
-                L.lev[r * AC + tid] = (uint8_t)code;
+                L.lev[r * AC + cell] = (uint8_t)code;
                 if (!rows_align) atomicOr(&L.vbits[r * 16 + X], 1u << Y);
             }
             level_code[r] = code;
         }
         if (rows_align) {                                    // naiveMask bit rows straight from the ballot
-            const unsigned long long bal = __ballot(valid && tid < AC);
-            if (Y == 0 && tid < AC) L.vbits[r * 16 + X] = (uint32_t)(bal >> (lane & ~(Ay - 1))) & ((1u << Ay) - 1u);
+            const unsigned long long bal = __ballot(valid && cell < AC);
+            if (Y == 0 && cell < AC) L.vbits[r * 16 + X] = (uint32_t)(bal >> (lane & ~(Ay - 1))) & ((1u << Ay) - 1u);
         }
     }
     // presence masks: one LDS atomic per distinct level per wave (64 lanes ORing into one word would
@@ -1127,6 +1148,7 @@ __device__ inline int overlap_test(const Params& P, const Tables& T, const State
         if ((tid & 63) == 0 && bits) atomicOr(&L.present[r], bits);
     }
     }
+    }       // cells of this thread
     }
     if (use_lists) {
     // ---- generic path: ONE action cell per lane, and only cells that can be in range.  A wave task is (rotation r,
@@ -2639,6 +2661,13 @@ IRBPP_ENV_KERNEL(irbpp_env_kernel_s5, PATH_MIXED, 5, IRBPP_CAPPED)
 IRBPP_ENV_KERNEL_CHAIN(irbpp_env_kernel_chain_s1, PATH_BLOCK, 1)
 #endif
 
+#elif IRBPP_PASS == 3
+// two waves per bin: the block path of BlockOut at R = 4 (SPEC 1), uncapped (LDS admits five waves per SIMD at most)
+extern "C" __global__ void __launch_bounds__(128)
+irbpp_env_kernel_s1_w128(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    IRBPP_HERE env_transition<PATH_BLOCK, 1, true>(P, T, S, io, mode, smem);
+}
 #else
 // 512-thread builds of the generic path: the 64 x 64 heightmap's geometry as constants (SPEC 4) and the run-time build
 #define IRBPP_ENV_KERNEL_512(NAME, PATH, SPEC, ATTR)                                                                    \
@@ -3478,14 +3507,17 @@ irbpp_totals_kernel(const double* totals, int N, double* out) {
 
 #endif  // IRBPP_PASS == 1
 
-#if IRBPP_PASS == 2
-}  // namespace wg512
+#if IRBPP_PASS != 1
+}  // namespace wg512 / wg128
 #endif
 }  // namespace irbpp
 
 #if IRBPP_PASS == 1
 #undef IRBPP_PASS
 #define IRBPP_PASS 2
+#include "irbpp_kernels.hip"
+#undef IRBPP_PASS
+#define IRBPP_PASS 3
 #include "irbpp_kernels.hip"
 #undef IRBPP_PASS
 #define IRBPP_PASS 1

@@ -250,7 +250,8 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
              _lib.TUNE_NO_WG512, _lib.TUNE_WG512,          # (256- / 512-thread workgroups of the generic path whatever the data)
              _lib.TUNE_NARROW_KERNEL | _lib.TUNE_WG512,    # (the 512-thread build under the 64-VGPR cap: the default from 4096 bins on)
              _lib.TUNE_NO_MIXED_PATH,                      # (BlockOut at eight rotations through the cell lists entirely, as until round 5)
-             _lib.TUNE_CHAIN]                              # (ONE kernel per observation: contour stage and candidate rows in the bin's workgroup)
+             _lib.TUNE_CHAIN,                              # (ONE kernel per observation: contour stage and candidate rows in the bin's workgroup)
+             _lib.TUNE_WG128, _lib.TUNE_WG128 | _lib.TUNE_SPLIT_APPLY]     # (two waves per bin: BlockOut at R = 4 only)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
@@ -260,6 +261,7 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
     assert names[8] == ("irbpp_env_kernel_s3" if workload == "blockout_r8" else names[0]), names
     chain = "irbpp_env_kernel_chain_s1 alone" if spec == "_s1" else "irbpp_env_kernel_chain alone"
     assert names[9].startswith(chain) == (workload != "abc_fine"), names      # (not for the 40 KB tile)
+    assert names[10] == names[11] == ("irbpp_env_kernel_s1_w128" if spec == "_s1" else names[0]), names
     obs = [e.reset() for e in envs]
     assert all(torch.equal(obs[0], o) for o in obs[1:])
     gen = torch.Generator(device="cpu").manual_seed(5)

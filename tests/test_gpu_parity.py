@@ -892,10 +892,11 @@ def test_bench_gpus2_spawns_two_real_ranks():
     assert strong["config"]["bins_per_gpu"] == 4096 and strong["config"]["global_bins"] == 8192 and strong["steps"] == 4
     assert strong["ranks"]["ms_per_step_min"] <= strong["ranks"]["ms_per_step_max"] == strong["ms_per_step"]
     assert abs(strong["value"] - 8192 * 4 / (strong["ms_per_step"] * 4e-3)) < 1e-3 * strong["value"]
-    # the timed region repeats in blocks until --min-seconds: `steps` reports what really ran
+    # the timed region repeats in blocks of EXACTLY --steps steps until --min-seconds: `steps` is the block (the K of the
+    # contract), `steps_timed_total` what really ran
     timed = run("--bins", "256", "--steps", "5", "--min-seconds", "0.2", "--prefill", "20")
-    assert timed["steps"] % 5 == 0 and timed["steps"] >= 10 and timed["steps_per_block"] == 5
-    assert timed["steps"] * timed["ms_per_step"] >= 200.0
+    assert timed["steps"] == 5 and timed["steps_per_block"] == 5 and timed["steps_timed_total"] == 5 * timed["timed_blocks"] >= 10
+    assert timed["steps_timed_total"] * timed["ms_per_step"] >= 200.0
 
     out = run("--bins", "256", "--steps", "5", "--min-seconds", "0", "--prefill", "120")
     assert out["n_gpus"] == 2 and out["ranks"]["world_size"] == 2 and len(out["ranks"]["devices"]) == 2
