@@ -1,11 +1,11 @@
 #!/bin/bash
-# Tooling: fold gpurun_out/final (written by profiles/r05/sessions/_final.sh on the GPU box) into profiles/r05/final and
+# Tooling: fold gpurun_out/final (written by profiles/r06/sessions/_final.sh on the GPU box) into profiles/r06/final and
 # profiles/pmc_hbm.json.   bash tools/fold_final.sh [<git rev the session ran on>]
 set -e
 cd "$(dirname "$0")/.."
-S=gpurun_out/final; D=profiles/r05/final; REV=${1:-$(git rev-parse --short HEAD)}
+S=gpurun_out/final; D=profiles/r06/final; REV=${1:-$(git rev-parse --short HEAD)}
 # (gpurun_out/ is merged into by every session and never cleaned: passes of earlier rounds would be averaged in)
-find $S -name "r0[0-9]_*" ! -name "r05_*" -delete
+find $S -name "r0[0-9]_*" ! -name "r06_*" -delete
 mkdir -p $D/other_workloads
 for f in bench_default.json bench_driver_style.json pytest_gpu.txt trace_blockout.json phase_blockout.json phase_general.json \
          phase_abc_fine.json phase_cube.json scaling_points.jsonl; do cp $S/$f $D/$f; done

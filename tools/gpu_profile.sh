@@ -10,14 +10,14 @@ OUT=$R/gpurun_out/$1; WL=${2:-blockout}; BINS=${3:-16384}
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
 B="python $R/bench.py --workload $WL --no-cpu-baseline --no-extra --groups 1"     # one launch group: per-launch counters = per-step counters
-rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o r05 -- $B --steps 200 --warmup 20 --min-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
+rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/kt" -o r06 -- $B --steps 200 --warmup 20 --min-seconds 0 > "$OUT/bench_under_rocprof.json" 2> "$OUT/kt.err"
 python $R/tools/kernel_trace_summary.py "$OUT/kt" 200 --rm > "$OUT/kernel_trace_timed_region.json"
 f=$(find "$OUT/kt" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats.csv"
 P="$B --bins $BINS --steps 60 --warmup 10 --prefill 150 --min-seconds 0"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r05 -- $P > "$OUT/bench_pmc_fetch.json" 2> "$OUT/fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o r05 -- $P > /dev/null 2> "$OUT/write.err"
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/sq" -o r05 -- $P > /dev/null 2> "$OUT/sq.err"
-rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d "$OUT/sq2" -o r05 -- $P > /dev/null 2> "$OUT/sq2.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch" -o r06 -- $P > "$OUT/bench_pmc_fetch.json" 2> "$OUT/fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o r06 -- $P > /dev/null 2> "$OUT/write.err"
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_VALU --output-format csv -d "$OUT/sq" -o r06 -- $P > /dev/null 2> "$OUT/sq.err"
+rocprofv3 --pmc SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES --output-format csv -d "$OUT/sq2" -o r06 -- $P > /dev/null 2> "$OUT/sq2.err"
 # the raw per-dispatch CSVs are large: keep per-kernel averages only
 python - "$OUT" <<'PY'
 import csv, collections, glob, json, os, sys
