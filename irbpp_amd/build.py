@@ -8,7 +8,7 @@ import subprocess
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libirbpp_hip.so")
-SOURCES = ["irbpp_capi.hip", "irbpp_kernels.hip", "irbpp_replay.hip", "irbpp_device.h", "contours_device.h", "irbpp_itemgen.h",
+SOURCES = ["irbpp_capi.hip", "irbpp_kernels.hip", "irbpp_wide.hip", "irbpp_replay.hip", "irbpp_device.h", "contours_device.h", "irbpp_itemgen.h",
            os.path.join("..", "..", "include", "irbpp.h")]
 # -ffp-contract=off: the float64 results must equal numpy's, so no FMA contraction anywhere
 # -fno-honor-nans: no NaN ever enters the path, so fmax needs no canonicalising v_max(x,x) per use

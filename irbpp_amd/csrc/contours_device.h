@@ -476,19 +476,22 @@ __device__ inline int trace_border_walk(const uint32_t* fr, int x0, int y0, uint
     return w.result;
 }
 
-#define IRBPP_PX(p) ((int)((p) & 15))
-#define IRBPP_PY(p) ((int)((p) >> 4))
+// a contour point is x | y << SHIFT in a PT: a byte with SHIFT = 4 on action grids of up to 16 x 16 cells, 16 bits with
+// SHIFT = 5 on the wide grids (up to 32 x 32, round 6)
+#define IRBPP_PX(p) ((int)((p) & ((1 << SHIFT) - 1)))
+#define IRBPP_PY(p) ((int)((p) >> SHIFT))
 
 // approxPolyDP_<int>(closed, eps=1) (OpenCV approx.cpp) followed by find_convex_vetex.
 // pts[0..count) -> vertex bits ORed into vrows[y] (bit x).  Returns false on stack overflow.
-__device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t* dst, uint32_t* stk,
-                                         int cap_stk, uint32_t* vrows) {
+template <typename PT, int SHIFT>
+__device__ inline bool approx_and_convex_t(const PT* pts, int count, PT* dst, uint32_t* stk,
+                                           int cap_stk, uint32_t* vrows) {
     int new_count = 0;
     int top = 0;
     // 1. three farthest-point hops
     int pos = 0, right_start = 0;
     bool le_eps = false;
-    uint8_t start_pt = 0;
+    PT start_pt = 0;
     for (int it = 0; it < 3; ++it) {
         int max_dist = 0;
         pos += right_start;
@@ -497,7 +500,7 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
         if (++pos >= count) pos = 0;
         const int sx = IRBPP_PX(start_pt), sy = IRBPP_PY(start_pt);
         for (int j = 1; j < count; ++j) {
-            const uint8_t pt = pts[pos];
+            const PT pt = pts[pos];
             if (++pos >= count) pos = 0;
             const int dx = IRBPP_PX(pt) - sx, dy = IRBPP_PY(pt) - sy;
             const int dist = dx * dx + dy * dy;
@@ -533,7 +536,7 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
                     dst[new_count++] = start_pt;
                     continue;
                 }
-                const uint8_t end_pt = pts[s_end];
+                const PT end_pt = pts[s_end];
                 sx = IRBPP_PX(start_pt);
                 sy = IRBPP_PY(start_pt);
                 dx = IRBPP_PX(end_pt) - sx;
@@ -541,7 +544,7 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
                 max_dist = 0;
                 in_slice = true;
             }
-            const uint8_t pt = pts[pos];
+            const PT pt = pts[pos];
             int dist = (IRBPP_PY(pt) - sy) * dx - (IRBPP_PX(pt) - sx) * dy;
             dist = dist < 0 ? -dist : dist;
             if (dist > max_dist) { max_dist = dist; split = pos; }
@@ -565,10 +568,10 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
         start_pt = dst[pos];
         if (++pos >= cnt) pos = 0;
         int wpos = pos;
-        uint8_t pt = dst[pos];
+        PT pt = dst[pos];
         if (++pos >= cnt) pos = 0;
         for (int i = 0; i < cnt && new_count > 2; ++i) {
-            const uint8_t end_pt = dst[pos];
+            const PT end_pt = dst[pos];
             if (++pos >= cnt) pos = 0;
             const int dx = IRBPP_PX(end_pt) - IRBPP_PX(start_pt), dy = IRBPP_PY(end_pt) - IRBPP_PY(start_pt);
             const int ux = IRBPP_PX(pt) - IRBPP_PX(start_pt), uy = IRBPP_PY(pt) - IRBPP_PY(start_pt);
@@ -594,9 +597,9 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
     if (m <= 3) {
         for (int i = 0; i < m; ++i) atomicOr(&vrows[IRBPP_PY(dst[i])], 1u << IRBPP_PX(dst[i]));
     } else {
-        uint8_t a = dst[m - 1], b = dst[0];
+        PT a = dst[m - 1], b = dst[0];
         for (int i = 0; i < m; ++i) {
-            const uint8_t c = dst[i == m - 1 ? 0 : i + 1];
+            const PT c = dst[i == m - 1 ? 0 : i + 1];
             const int cross = (IRBPP_PX(b) - IRBPP_PX(a)) * (IRBPP_PY(c) - IRBPP_PY(a)) -
                               (IRBPP_PY(b) - IRBPP_PY(a)) * (IRBPP_PX(c) - IRBPP_PX(a));
             if (cross < 0) atomicOr(&vrows[IRBPP_PY(b)], 1u << IRBPP_PX(b));
@@ -605,6 +608,78 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
         }
     }
     return true;
+}
+
+#undef IRBPP_PX
+#undef IRBPP_PY
+#define IRBPP_PX(p) ((int)((p) & 15))
+#define IRBPP_PY(p) ((int)((p) >> 4))
+__device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t* dst, uint32_t* stk,
+                                         int cap_stk, uint32_t* vrows) {
+    return approx_and_convex_t<uint8_t, 4>(pts, count, dst, stk, cap_stk, vrows);
+}
+
+// ---------------------------------------------------------------------------------------
+// WIDE action grids (17 .. 32 cells a side: resolutionA = 0.01 on the 0.32 m bin, space.py:19-24; round 6): level images of up
+// to 32 rows of 32 bits, contour points of 16 bits (x | y << 5).  Plain statements of the same routines -- candidate starts,
+// icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border that starts at a component's first pixel in raster order,
+// approxPolyDP + find_convex_vetex (the template above) -- with no run jumps, tables or frames: a capacity path, lane-serial,
+// one border per lane (irbpp_kernels.hip: wide_observe).  tests/host/ runs them against the oracle on 32 x 32 images.
+// ---------------------------------------------------------------------------------------
+// first pixels of runs with nothing above the run (see start_candidates): `row`, `up` = the row and the one above, `wmask` = the
+// image's columns
+__device__ __forceinline__ uint32_t start_candidates_wide(uint32_t row, uint32_t up, uint32_t wmask) {
+    const uint32_t upm = (up | (up << 1) | (up >> 1)) & wmask;
+    const uint32_t first = row & ~(row << 1) & ~upm;
+    uint32_t t = upm & row;                                             // pixels touched from above, spread to the first pixel of their run
+    const uint32_t p2 = row & (row >> 1), p4 = p2 & (p2 >> 2), p8 = p4 & (p4 >> 4), p16 = p8 & (p8 >> 8);
+    t |= (t >> 1) & row;
+    t |= (t >> 2) & p2;
+    t |= (t >> 4) & p4;
+    t |= (t >> 8) & p8;
+    t |= (t >> 16) & p16;
+    return first & ~t;
+}
+__device__ __forceinline__ bool wide_fg(const uint32_t* rows, int W, int H, int x, int y) {
+    return x >= 0 && y >= 0 && x < W && y < H && ((rows[y] >> x) & 1u) != 0u;
+}
+// Returns the number of points (all counted, the first `cap` stored), 0 if (x0, y0) is not the first pixel of its component,
+// -1 if the iteration guard tripped.
+template <int SHIFT>
+__device__ inline int trace_border_wide(const uint32_t* rows, int W, int H, int x0, int y0, uint16_t* pts, int cap) {
+    int s = 4, x1 = 0, y1 = 0;
+    do {                                                                // first non-zero neighbour, clockwise from west (background)
+        s = (s - 1) & 7;
+        x1 = x0 + dir_dx(s);
+        y1 = y0 + dir_dy(s);
+    } while (!wide_fg(rows, W, H, x1, y1) && s != 4);
+    if (s == 4) {                                                       // isolated pixel
+        if (cap > 0) pts[0] = (uint16_t)(x0 | (y0 << SHIFT));
+        return 1;
+    }
+    int x3 = x0, y3 = y0, prev_s = s ^ 4, n = 0;
+    for (int guard = 0; guard < 8192; ++guard) {
+        IRBPP_TRACE_ITER();
+        int x4 = x3, y4 = y3;
+        while (s < 15) {                                                // counter-clockwise search, at most 15 probes
+            ++s;
+            x4 = x3 + dir_dx(s & 7);
+            y4 = y3 + dir_dy(s & 7);
+            if (wide_fg(rows, W, H, x4, y4)) break;
+        }
+        s &= 7;
+        if (s != prev_s) {                                              // CHAIN_APPROX_SIMPLE
+            if (n < cap) pts[n] = (uint16_t)(x3 | (y3 << SHIFT));
+            ++n;
+        }
+        prev_s = s;
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
+        if (y4 * W + x4 < y0 * W + x0) return 0;                        // an earlier pixel of the component: some other start's border
+        x3 = x4;
+        y3 = y4;
+        s = (s + 4) & 7;
+    }
+    return -1;
 }
 
 // One outer border, serially: trace, approximate, mark convex vertices.  Returns 0 ok,

@@ -17,6 +17,7 @@
 #include "../../include/irbpp.h"
 #include "irbpp_device.h"
 #include "irbpp_kernels.hip"      // single translation unit: kernels + host ABI
+#include "irbpp_wide.hip"         // action grids of 17 .. 32 cells a side: the capacity path
 #include "irbpp_replay.hip"
 #include "irbpp_itemgen.h"
 
@@ -95,7 +96,7 @@ int raise_lds_limits() {
     const void* kernels[] = {(const void*)irbpp_env_kernel_wide, (const void*)irbpp_env_kernel, (const void*)irbpp_env_kernel_box,
                              (const void*)irbpp_env_kernel_box8, (const void*)irbpp_env_kernel_generic,
                              (const void*)irbpp_env_kernel_generic8, (const void*)irbpp_env_kernel_mixed8, (const void*)irbpp_hull_kernel,
-                             (const void*)irbpp_env_kernel_chain,
+                             (const void*)irbpp_env_kernel_chain, (const void*)irbpp_wide_kernel,
 #if !defined(IRBPP_NO_SPEC)
                              (const void*)irbpp_env_kernel_s1, (const void*)irbpp_env_kernel_s2, (const void*)irbpp_env_kernel_s3,
                              (const void*)irbpp_env_kernel_s4, (const void*)irbpp_env_kernel_s5, (const void*)irbpp_emit_kernel_s5,
@@ -182,7 +183,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.res_h = cfg->resolution_h;
     P.res_z = cfg->resolution_z;
     P.inv_res_z = 1.0 / cfg->resolution_z;
-    for (int k = 0; k < 16; ++k) P.txs[k] = round6_host((double)k * cfg->resolution_a);
+    for (int k = 0; k < 32; ++k) P.txs[k] = round6_host((double)k * cfg->resolution_a);
     P.bin_x = cfg->bin[0];
     P.bin_y = cfg->bin[1];
     P.bin_z = cfg->bin[2];
@@ -198,7 +199,13 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.Ay = (int)ceil(cfg->bin[1] / cfg->resolution_a);
     P.Hc = P.Hx * P.Hy;
     P.AC = P.Ax * P.Ay;
-    if (P.Ax > 16 || P.Ay > 16 || P.Ax < 1 || P.Ay < 1 || P.Hc > 128 * 128) { delete env; return IRBPP_ERR_ARG; }
+    if (P.Ax > 32 || P.Ay > 32 || P.Ax < 1 || P.Ay < 1 || P.Hc > 128 * 128) { delete env; return IRBPP_ERR_ARG; }
+    // 17 .. 32 action cells a side (resolutionA = 0.01): the capacity path of irbpp_wide.hip -- one kernel per observation, every
+    // stage in the bin's workgroup; no stability proxy, no item streams' extras are affected, the stage-level tooling entry points
+    // (possible_position, heuristic_action, convex_hull_actions) answer IRBPP_ERR_ARG
+    P.wide = (P.Ax > 16 || P.Ay > 16) ? 1 : 0;
+    P.vrow = P.wide ? WIDE_VROW : 16;
+    if (P.wide && (P.Hc > 64 * 64 || cfg->stability != 0)) { delete env; return IRBPP_ERR_ARG; }
     if (P.Hx != P.Ax * P.step || P.Hy != P.Ay * P.step) { delete env; return IRBPP_ERR_ARG; }   // phase-plane tile layout
     // height levels are coded in 6 bits (level + 32): a placement height never exceeds bin_z, so 31 levels must cover it
     if (floor(cfg->bin[2] / cfg->resolution_z + 1e-9) > 31.0) { delete env; return IRBPP_ERR_ARG; }
@@ -213,10 +220,10 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
     P.wimg = P.R * 64;
-    P.seg_cap = 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;
-    P.round_cap = (P.N / NXCD + 64) * 16;
+    P.seg_cap = P.wide ? 64 : 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;      // (the wide path hands nothing over between kernels)
+    P.round_cap = P.wide ? 16 : (P.N / NXCD + 64) * 16;
     layout_lds_host(P);                 // redone by irbpp_load_shapes if the block path applies
-    if (P.lds_bytes_full > 160 * 1024) { delete env; return IRBPP_ERR_ARG; }
+    if (P.lds_bytes_full > 160 * 1024 || (P.wide && wide_layout(P).bytes > 160 * 1024)) { delete env; return IRBPP_ERR_ARG; }
 
     if (hipSetDevice(cfg->device) != hipSuccess) { delete env; return IRBPP_ERR_HIP; }
     if (raise_lds_limits() != IRBPP_OK) { delete env; return IRBPP_ERR_HIP; }
@@ -232,13 +239,13 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(order, N);
     ALLOC(err, 1);
     ALLOC(w_posz, N * P.R * P.AC);
-    ALLOC(w_valid, N * P.R * 16);
+    ALLOC(w_valid, N * P.R * P.vrow);
     ALLOC(w_vmask, N * P.R * 16);
     ALLOC(w_meta, N * WMETA);
-    ALLOC(w_img, N * P.wimg * 16);
-    ALLOC(w_imgrot, N * P.wimg);
+    ALLOC(w_img, P.wide ? 16 : N * P.wimg * 16);
+    ALLOC(w_imgrot, P.wide ? 16 : N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
-    ALLOC(w_big, (size_t)trace_grid_cap(P.N) * TRACE_WAVE_BYTES);   // one scratch per wave of the trace grid
+    ALLOC(w_big, P.wide ? N * WIDE_BIG_BYTES : (size_t)trace_grid_cap(P.N) * TRACE_WAVE_BYTES);   // one scratch per wave of the trace grid (wide: per bin)
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);
@@ -291,7 +298,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     // README's eight rotations: the four lattice rotations, not the 45-degree ones) those take the block loop and the
     // others their cell lists, in one kernel (PATH_MIXED); b = the largest size with the most rotations.
     int block_b = 0, block_rots = 0;
-    if (!(env->cfg.tuning & IRBPP_TUNE_NO_BLOCK_PATH)) {
+    if (!(env->cfg.tuning & IRBPP_TUNE_NO_BLOCK_PATH) && !P.wide) {
         int best_count = 0;
         for (int b = 8; b >= 2; --b) {
             if (b % P.step != 0 || (P.Hx - b) % P.step != 0 || (P.Hy - b) % P.step != 0) continue;
@@ -327,7 +334,7 @@ int irbpp_load_shapes(irbpp_env* env, int32_t n_shapes, const double* extents, c
     // Box path: every footprint of the dataset is a solid box -- maskB the rectangle [0,bx) x [0,by), one bottom height
     // over it (the Cube dataset: bottom 0, the ceil-fuzz row of space.py:105 masked out).  max over the window of (H - c)
     // is (max H) - c exactly, and the max over a rectangle is separable: row maxima first, then column maxima.
-    bool box = block_b == 0 && !(env->cfg.tuning & IRBPP_TUNE_NO_BOX_PATH);
+    bool box = block_b == 0 && !(env->cfg.tuning & IRBPP_TUNE_NO_BOX_PATH) && !P.wide;
     for (int64_t i = 0; i < (int64_t)n_shapes * R && box; ++i) {
         const int fx = dims[i * 2], fy = dims[i * 2 + 1];
         const double* mb = mask_bottom + offsets[i];
@@ -645,6 +652,17 @@ static void launch_group(irbpp_env* env, StepIO io, int mode, hipStream_t st, in
         }
     // split pipeline: a location observation is finished by the trace kernel (one wave per 64 candidate starts of
     // the launch's flat list) and the emit kernel (one workgroup per bin), on the same stream
+    if (env->P.wide) {                     // irbpp_wide.hip: [the geometry-free apply kernel,] then ONE kernel per observation
+        int wmode = mode;
+        if (mode == MODE_STEP) {
+            if (env->P.K > 1 && n < 2048) hipLaunchKernelGGL(irbpp_apply_wg_kernel, dim3(n), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+            else hipLaunchKernelGGL(irbpp_apply_kernel, dim3((n + 3) / 4), dim3(256), 0, st, env->P, env->T, env->S, io, mode);
+            if (env->P.K > 1) return;
+            wmode = MODE_OBSERVE;
+        }
+        hipLaunchKernelGGL(irbpp_wide_kernel, dim3(n), dim3(256), wide_layout(env->P).bytes, st, env->P, env->T, env->S, io, wmode);
+        return;
+    }
     const bool chain = observes && mode != MODE_POSSIBLE && chain_launch(env, n);
     const bool split = env->P.split && observes && !chain;
     // expensive bins first in the emit kernel: free-form level images only (lattice and box data never get there), not for a
@@ -960,7 +978,7 @@ int irbpp_invalidate_obs_buffer(irbpp_env* env, float* obs_dev, void* stream) {
 }
 
 int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double* posz_dev, uint8_t* mask_dev, void* stream) {
-    if (!env || !item_ids_dev || !posz_dev || !mask_dev) return IRBPP_ERR_ARG;
+    if (!env || !item_ids_dev || !posz_dev || !mask_dev || env->P.wide) return IRBPP_ERR_ARG;
     if (!env->shapes_loaded) return IRBPP_ERR_STATE;
     StepIO io;
     memset(&io, 0, sizeof(io));
@@ -971,7 +989,7 @@ int irbpp_possible_position(irbpp_env* env, const int32_t* item_ids_dev, double*
 }
 
 int irbpp_heuristic_action(irbpp_env* env, int32_t method, int32_t dir_idx, int32_t* out_dev, void* stream) {
-    if (!env || !out_dev || method < 1 || method > 4 || dir_idx < 0 || dir_idx > 3) return IRBPP_ERR_ARG;
+    if (!env || !out_dev || method < 1 || method > 4 || dir_idx < 0 || dir_idx > 3 || env->P.wide) return IRBPP_ERR_ARG;
     if (!env->was_reset) return IRBPP_ERR_STATE;
     StepIO io;
     memset(&io, 0, sizeof(io));
@@ -1001,7 +1019,7 @@ int irbpp_shot_item(const double* verts_dev, const int32_t* faces_dev, int32_t n
 
 int irbpp_convex_hull_actions(irbpp_env* env, int32_t n_grids, const double* posz_valid_dev, const uint8_t* mask_dev,
                               uint32_t* vertex_rows_dev, void* stream) {
-    if (!env || n_grids < 1 || !posz_valid_dev || !mask_dev || !vertex_rows_dev) return IRBPP_ERR_ARG;
+    if (!env || n_grids < 1 || !posz_valid_dev || !mask_dev || !vertex_rows_dev || env->P.wide) return IRBPP_ERR_ARG;
     hipLaunchKernelGGL(irbpp_hull_kernel, dim3(n_grids), dim3(256), env->P.lds_bytes, (hipStream_t)stream, env->P,
                        env->S, posz_valid_dev, mask_dev, vertex_rows_dev);
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
@@ -1020,7 +1038,7 @@ int irbpp_set_heightmaps(irbpp_env* env, const double* hm_dev, void* stream) {
                            (hipStream_t)stream));
     // the drop heights of the last observation (w_posz, marked by w_valid) belong to the OLD maps: a step that follows
     // without a new observation recomputes its drop height from the footprint's bottom cells instead
-    HIP_TRY(hipMemsetAsync(env->S.w_valid, 0, (size_t)env->P.N * env->P.R * 16 * sizeof(uint32_t), (hipStream_t)stream));
+    HIP_TRY(hipMemsetAsync(env->S.w_valid, 0, (size_t)env->P.N * env->P.R * env->P.vrow * sizeof(uint32_t), (hipStream_t)stream));
     return IRBPP_OK;
 }
 
@@ -1116,7 +1134,10 @@ int irbpp_debug_kernel_info(const irbpp_env* env, int32_t* lds_bytes, const char
              pick_env_kernel(env).name, cpw > 64 ? "_refill" : cpw == 64 ? "" : (cpw == 32 ? "_c32" : "_c16"), emit,
              !split_apply(env, n) ? "" : (env->P.K > 1 ? (n < 2048 ? " (step: irbpp_apply_wg_kernel alone)" : " (step: irbpp_apply_kernel alone)")
                                                        : " (step: irbpp_apply_kernel in front, transition kernel in MODE_OBSERVE)"));
-    if (chain_launch(env, n)) {
+    if (env->P.wide)
+        snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "irbpp_wide_kernel alone (action grid of %d x %d cells)%s", env->P.Ax, env->P.Ay,
+                 env->P.K > 1 ? " (step: the apply kernel alone)" : " (step: irbpp_apply_kernel in front)");
+    else if (chain_launch(env, n)) {
         const bool s1 = spec == 1;
         snprintf(const_cast<irbpp_env*>(env)->kernel_names, sizeof env->kernel_names, "%s alone (observation finished in the bin's workgroup)%s",
                  s1 ? "irbpp_env_kernel_chain_s1" : "irbpp_env_kernel_chain", env->P.K > 1 ? " (step: irbpp_apply_wg_kernel alone)" : "");

@@ -126,7 +126,7 @@ struct State {
 struct Params {
     int32_t N, Hx, Hy, Hc, Ax, Ay, AC, step, R, S, K;
     double res_a, res_h, res_z, inv_res_z;
-    double txs[16];                // np.round(k * resolutionA, 6) for k = 0..15 (binPhy.py:236)
+    double txs[32];                // np.round(k * resolutionA, 6) for k = 0..31 (binPhy.py:236)
     double bin_x, bin_y, bin_z, bin_vol;
     double scale_z, ibin_z;        // Interface scale and round(bin_z*scale, 6)
     int32_t traj_start, goff, gbins;
@@ -167,6 +167,8 @@ struct Params {
     int32_t round_cap;     // round records of one XCD's list (a full list makes the trace kernel approximate in place)
     int32_t heavy_cap, heavy_thr;   // bins the emit kernel can serve first (0: off); border starts + isolated pixels that make a bin one of them
     int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
+    int32_t wide;          // action grid of 17 .. 32 cells a side: the capacity path of irbpp_wide.hip (one kernel per observation)
+    int32_t vrow;          // words per rotation of w_valid (naiveMask bit rows): 16, or 32 on a wide grid
 };
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -274,6 +276,8 @@ constexpr Params spec_params(const SpecKey& k) {
     P.mb_w = k.block_b ? (P.Hy - k.block_b) / k.step + 1 : 0;
     P.split = 1;
     P.stability = 0;
+    P.wide = 0;
+    P.vrow = 16;
     P.dbg_repeat = 0;
     P.wimg = k.R * 64;
     P.heavy_thr = (k.S * 3) / 5;
@@ -289,7 +293,7 @@ constexpr Params spec_params(const SpecKey& k) {
     X(o_img) X(o_clist) X(o_vmask) X(o_scratch) X(o_red) X(o_dps) X(nslot) X(slot_cap) X(slot_bytes) X(scratch_bytes)  \
     X(lds_bytes) X(lds_bytes_full) X(e_vmask) X(e_red) X(e_hist) X(e_keys) X(emit_lds_bytes) X(ew_bytes) X(e_need) X(big_slot_bytes)         \
     X(block_b) X(block_rots) X(mb_w) X(mb_h) X(o_mb) X(o_c2) X(mg_hy) X(mg_step) X(mg_ay) X(mg_ax) X(mg_ac) X(mg_mbw) X(dbg_repeat)  \
-    X(split) X(wimg) X(heavy_thr) X(stability) X(obs_len1)
+    X(split) X(wimg) X(heavy_thr) X(stability) X(obs_len1) X(wide) X(vrow)
 constexpr bool spec_matches(const Params& P, const Params& C) {
 #define IRBPP_X(f) if (P.f != C.f) return false;
     IRBPP_PINNED_FIELDS(IRBPP_X)

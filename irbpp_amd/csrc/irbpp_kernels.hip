@@ -2820,7 +2820,7 @@ __device__ __forceinline__ void env_transition(const Params& P_run, const Tables
         const bool pref_ok = st_next >= 0 && st_next < T.n_shapes;
         if (pref_ok && tid < P.R * SRW_) sr_pref = ((const int*)(T.sr + (size_t)st_next * P.R))[tid];
         if (ok) {
-            const double tx = P_run.txs[lx & 15], ty = P_run.txs[ly & 15];   // np.round(lx*resA, 6), precomputed (indexed in the kernarg segment: the local copy must stay in registers)
+            const double tx = P_run.txs[lx & 31], ty = P_run.txs[ly & 31];   // np.round(lx*resA, 6), precomputed (indexed in the kernarg segment: the local copy must stay in registers)
             if (round6_scaled(tx + sr.ext_x - P.bin_x) > 0.0 || round6_scaled(ty + sr.ext_y - P.bin_y) > 0.0) ok = false;
         }
         double z = 1e3;                                              // posZmap[rot, lx, ly] (:266)
@@ -3063,7 +3063,7 @@ __device__ __forceinline__ void apply_body(const Params& P, const Tables& T, con
     const double ext_x = IRBPP_SRD(ext_x), ext_y = IRBPP_SRD(ext_y), ext_z = IRBPP_SRD(ext_z);
     bool ok = item0 >= 0 && nvalid0 > 0 && rot < P.R;                // prejudge (:238-245)
     if (ok) {
-        const double tx = P.txs[lx & 15], ty = P.txs[ly & 15];       // np.round(lx*resA, 6), precomputed
+        const double tx = P.txs[lx & 31], ty = P.txs[ly & 31];       // np.round(lx*resA, 6), precomputed
         if (round6_scaled(tx + ext_x - P.bin_x) > 0.0 || round6_scaled(ty + ext_y - P.bin_y) > 0.0) ok = false;
     }
     const int s_nt = ok ? IRBPP_SRI(nt) : 0;
@@ -3078,7 +3078,7 @@ __device__ __forceinline__ void apply_body(const Params& P, const Tables& T, con
     uint32_t vword = 0u;
     double zc = 1e3;
     if (want_z) {
-        vword = S.w_valid[((size_t)b * P.R + rot) * 16 + lx];
+        vword = S.w_valid[((size_t)b * P.R + rot) * P.vrow + lx];
         zc = S.w_posz[((size_t)b * P.R + rot) * P.AC + lx * P.Ay + ly];
     }
     const Cell* const tcells = T.tcell + s_ot;

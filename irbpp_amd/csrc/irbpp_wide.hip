@@ -1,0 +1,447 @@
+// irbpp_wide.hip -- WIDE action grids: 17 .. 32 cells a side (resolutionA = 0.01 on the 0.32 m bin: space.py:19-24 takes any
+// resolutionA with an integral stepSize; every README command of the reference uses 0.02 = 16 x 16).
+//
+// The step's tuned kernels hold a contour point in ONE byte (x | y << 4), a level image in sixteen 16-bit row words and an
+// action cell per thread: all of that is the 16 x 16 grid's.  This file is the CAPACITY path for larger grids -- correct first,
+// simple on purpose: ONE kernel per observation, one 256-thread workgroup per bin, everything in LDS:
+//
+//   [irbpp_apply_kernel in front for a step: it is geometry-free]
+//   irbpp_wide_kernel: reset / get_action_candidates / observe bookkeeping (env_transition's), overlap test over the footprint's
+//   cell lists (space.py:98-129), level codes (cvTools.py:78-79), one level image after the other as 32 rows of 32 bits,
+//   candidate starts, the plain border walk and approxPolyDP + convexity lane-serially (contours_device.h:
+//   trace_border_wide, approx_and_convex_t<uint16_t, 5>: host-tested against the oracle), candidate rows in np.unique order,
+//   the > S selection / the no-candidate fallback by a radix select over keys in LDS, rows, candidate keys, fused MINZ policy.
+//
+// Same arithmetic, same order of operations as the 16 x 16 pipeline; parity against both oracles in tests/test_gpu_wide.py.
+#pragma once
+
+namespace irbpp {
+
+constexpr int WIDE_VROW = 32;                     // words per rotation of w_valid / vertex bits on a wide grid
+constexpr int WIDE_TL = 16;                       // lanes of a workgroup that follow borders (four per wave)
+constexpr int WIDE_LCAP = 192;                    // contour points a tracing lane holds in LDS; longer borders: thread 0, global scratch
+constexpr int WIDE_BIG = 4096;                    // ... of this many points
+constexpr int WIDE_BIG_BYTES = WIDE_BIG * (2 + 2 + 4);
+constexpr int WIDE_CLIST = 1024;
+
+struct WideLayout {
+    int o_sr, o_present, o_vmask, o_vbits, o_red, o_keys, o_hist, o_rows, o_cnt, o_clist, o_redo, o_over, o_hm, o_lev, o_trace, o_skl, bytes;
+};
+__host__ __device__ inline WideLayout wide_layout(const Params& P) {
+    WideLayout w{};
+    int off = 0;
+    w.o_sr = off;       off += align16(P.R * (int)sizeof(ShapeRot));
+    w.o_present = off;  off += align16(P.R * 8);
+    w.o_vmask = off;    off += align16(P.R * WIDE_VROW * 4);
+    w.o_vbits = off;    off += align16(P.R * WIDE_VROW * 4);
+    w.o_red = off;      off += 512;
+    w.o_keys = off;     off += align16((P.R * P.AC + P.S) * 4 + 64);          // candidate keys [R*AC], selected keys [S]
+    int npad = 64;
+    while (npad < P.S) npad <<= 1;
+    w.o_hist = off;     off += align16(10 * npad > 1024 ? 10 * npad : 1024);  // radix counters, then the sort keys
+    w.o_rows = off;     off += 32 * 4;
+    w.o_cnt = off;      off += 16;
+    w.o_clist = off;    off += WIDE_CLIST * 2;
+    w.o_redo = off;     off += 64 * 2;
+    w.o_over = off;                                                            // two phases share the bytes from here on
+    // phase 1 / 2: heightmap tile, level codes, the tracing lanes' slots
+    int a = off;
+    w.o_hm = a;         a += align16(P.Hc * 8);
+    w.o_lev = a;        a += align16(P.R * P.AC);
+    w.o_trace = a;      a += WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
+    // phase 3: the sortable images of the keys' values
+    int c = off;
+    w.o_skl = c;        c += align16(P.R * P.AC * 8);
+    w.bytes = a > c ? a : c;
+    return w;
+}
+
+// The `want` smallest of n keys by (value, position) -- np.argsort(...)[:want] with ties by ascending position (binPhy.py:209-212,
+// 217-225) -- keys, their sortable values and the selection all in LDS (select_smallest keeps them in registers: 2048 at most).
+template <typename KEY>
+__device__ inline void wide_select(const Params& P, const double* zsrc, const uint32_t* vbits, int n, int want, const KEY& key,
+                                   uint32_t* out, uint32_t* sel, uint32_t* hist, unsigned long long* skl, int* redi) {
+    const int tid = threadIdx.x;
+    auto value = [&](uint32_t k) {
+        const uint32_t r = k >> 16, x = (k >> 8) & 255u, y = k & 255u;
+        if (vbits != nullptr && !((vbits[r * WIDE_VROW + x] >> y) & 1u)) return 1e3;
+        return zsrc[r * P.AC + x * P.Ay + y];
+    };
+    for (int e = tid; e < n; e += BLOCK) skl[e] = sortable_f64(value(key(e)));
+    __syncthreads();
+    unsigned long long prefix = 0ull;
+    int remaining = want;
+    for (int d = 7; d >= 0; --d) {                                       // the want-th smallest value, a byte per round from the top
+        hist[tid] = 0u;
+        __syncthreads();
+        for (int e = tid; e < n; e += BLOCK) {
+            const unsigned long long v = skl[e];
+            if (d == 7 || (v >> (8 * (d + 1))) == prefix) atomicAdd(&hist[(uint32_t)(v >> (8 * d)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int run = 0;
+            for (int i = 0; i < 256; ++i) {
+                const int c = (int)hist[i];
+                if (run < remaining && remaining <= run + c) { redi[32] = i; redi[33] = remaining - run; break; }
+                run += c;
+            }
+        }
+        __syncthreads();
+        prefix = (prefix << 8) | (unsigned long long)(uint32_t)redi[32];
+        remaining = redi[33];
+        __syncthreads();
+    }
+    // compaction in position order: everything below T, and the first `remaining` elements equal to T (sel may be the array
+    // key() reads: a chunk only writes below the positions it has read)
+    int nsel = 0, neq = 0;
+    for (int e0 = 0; e0 < n; e0 += BLOCK) {
+        const int e = e0 + tid;
+        const unsigned long long v = e < n ? skl[e] : ~0ull;
+        const uint32_t k = e < n ? key(e) : 0u;
+        const bool eq = e < n && v == prefix;
+        int teq;
+        const int eqb = block_scan_flag(eq, redi, teq);
+        const bool take = e < n && (v < prefix || (eq && neq + eqb < remaining));
+        int tsel;
+        const int pos = block_scan_flag(take, redi, tsel);
+        __syncthreads();
+        if (take) sel[nsel + pos] = k;
+        nsel += tsel;
+        neq += teq;
+    }
+    __syncthreads();
+    int npad = 64;
+    while (npad < want) npad <<= 1;
+    uint32_t* const khi = hist;
+    uint32_t* const klo = hist + npad;
+    uint16_t* const kps = (uint16_t*)(hist + 2 * npad);
+    for (int i = tid; i < npad; i += BLOCK) {
+        unsigned long long v = ~0ull;
+        if (i < want) v = sortable_f64(value(sel[i]));
+        khi[i] = (uint32_t)(v >> 32);
+        klo[i] = (uint32_t)v;
+        kps[i] = (uint16_t)(i < want ? i : 0xFFFF);
+    }
+    __syncthreads();
+    for (int k = 2; k <= npad; k <<= 1)
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            const int sh = __ffs(j) - 1;
+            for (int t = tid; t < (npad >> 1); t += BLOCK) {
+                const int i = ((t >> sh) << (sh + 1)) | (t & (j - 1)), l = i | j;
+                const uint32_t ah = khi[i], al = klo[i], bh = khi[l], bl = klo[l];
+                const uint32_t ap = kps[i], bp = kps[l];
+                const bool a_gt_b = ah > bh || (ah == bh && (al > bl || (al == bl && ap > bp)));
+                if (a_gt_b == ((i & k) == 0)) {
+                    khi[i] = bh; klo[i] = bl; kps[i] = (uint16_t)bp;
+                    khi[l] = ah; klo[l] = al; kps[l] = (uint16_t)ap;
+                }
+            }
+            __syncthreads();
+        }
+    for (int r = tid; r < want; r += BLOCK) out[r] = sel[kps[r]];
+    __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(BLOCK)
+irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io, const int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const WideLayout W = wide_layout(P);
+    int* const srw = (int*)(smem + W.o_sr);
+    uint32_t* const present = (uint32_t*)(smem + W.o_present);        // [R][2]: bit `code` of rotation r
+    uint32_t* const vmask = (uint32_t*)(smem + W.o_vmask);            // [R][32] vertex bits: word row, bit col
+    uint32_t* const vbits = (uint32_t*)(smem + W.o_vbits);            // [R][32] naiveMask bit rows
+    double* const redd = (double*)(smem + W.o_red);
+    int* const redi = (int*)(redd + 8);
+    uint32_t* const keys = (uint32_t*)(smem + W.o_keys);
+    uint32_t* const hist = (uint32_t*)(smem + W.o_hist);
+    uint32_t* const rows = (uint32_t*)(smem + W.o_rows);
+    int* const cnt = (int*)(smem + W.o_cnt);
+    uint16_t* const clist = (uint16_t*)(smem + W.o_clist);
+    uint16_t* const redo_list = (uint16_t*)(smem + W.o_redo);       // borders that outgrew a tracing lane's slot
+    double* const hm = (double*)(smem + W.o_hm);
+    uint8_t* const lev = smem + W.o_lev;
+    unsigned long long* const skl = (unsigned long long*)(smem + W.o_skl);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
+    constexpr int VR = WIDE_VROW;
+
+    const bool some = mode == MODE_RESET && io.bin_list != nullptr;
+    const int slot = (int)blockIdx.x + io.block_off;
+    const int b = some ? io.bin_list[slot] : slot;
+    if (b < 0 || b >= P.N) {
+        if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_BIN);
+        return;
+    }
+    double* const ghm = S.hm + (size_t)b * P.Hc;
+    int32_t* const q = S.queue + (size_t)b * P.K;
+    float* const obs = io.obs ? io.obs + (size_t)(some ? slot : b) * io.obs_stride : nullptr;
+
+    // ---- bookkeeping of the transition (env_transition's, binPhy.py:128-147, 161-169)
+    if (mode == MODE_RESET) {
+        for (int i = tid; i < P.Hc; i += BLOCK) { hm[i] = 0.0; ghm[i] = 0.0; }
+        if (tid == 0) {
+            BinState* ps = S.bs + b;
+            const int ep = (some || io.reset_next) ? ps->episode + 1 : 0;
+            const int trow = trajectory_row(P, T, b, ep);
+            const int c0 = T.stream ? ps->cursor : 0;
+            for (int i = 0; i < P.K; ++i) q[i] = fetch_item(T, S, trow, c0 + i);
+            ps->episode = ep;
+            ps->traj_row = trow;
+            ps->cursor = c0 + P.K;
+            ps->cur_item = -1;
+            ps->nvalid = 0;
+            ps->order_action = 0;
+            ps->item_idx = 0;
+            ps->ep_len = 0;
+            ps->ratio_acc = 0.0;
+            ps->ep_reward = 0.0;
+            if (!some) for (int i = 0; i < 4; ++i) S.totals[(size_t)b * 4 + i] = 0.0;
+        }
+    } else {
+        for (int i = tid; i < P.Hc; i += BLOCK) hm[i] = ghm[i];
+    }
+    __syncthreads();
+    int obs_item = -1;
+    if (mode == MODE_CANDS) {
+        int oa = io.fixed_slot ? io.fixed_slot - 1 : io.actions[b];
+        oa += oa < 0 ? P.K : 0;
+        if (oa < 0 || oa >= P.K) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ACTION); oa = oa < 0 ? 0 : P.K - 1; }
+        obs_item = q[oa];
+        if (tid == 0 && !io.fixed_slot) S.bs[b].order_action = oa;
+    } else if (P.K == 1) {                       // MODE_RESET / MODE_OBSERVE of an online environment: the queue's first item
+        obs_item = q[0];
+    } else {                                     // buffer branch of cur_observation (binPhy.py:228-230): [k ids | heightmap]
+        for (int i = tid; i < P.K; i += BLOCK) obs[i] = (float)q[i];
+        for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)hm[i];
+        return;
+    }
+    int item = __builtin_amdgcn_readfirstlane(obs_item);
+    if (item >= T.n_shapes) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ITEM); item = -1; }
+
+    // ---- Space.get_possible_position (space.py:98-129) over the footprint's masked-in bottom cells
+    constexpr int SRW = sizeof(ShapeRot) / 4;
+    if (item >= 0) for (int t = tid; t < R * SRW; t += BLOCK) srw[t] = ((const int*)(T.sr + (size_t)item * R))[t];
+    for (int i = tid; i < R * 2; i += BLOCK) present[i] = 0u;
+    for (int i = tid; i < R * VR; i += BLOCK) { vmask[i] = 0u; vbits[i] = 0u; }
+    for (int i = tid; i < R * AC; i += BLOCK) lev[i] = 255;
+    __syncthreads();
+    double* const zdst = S.w_posz + (size_t)b * R * AC;
+    int my_valid = 0;
+    for (int r = 0; r < R && item >= 0; ++r) {
+        const ShapeRot* sp = (const ShapeRot*)srw + r;
+        const int s_ax = sp->ax, s_ay = sp->ay, nb = sp->nb, has_out = sp->has_out;
+        const double ext_z_r = sp->ext_z_r;
+        const Cell* cells = T.bcell + sp->ob;
+        for (int c0 = 0; c0 < AC; c0 += BLOCK) {                         // (uniform trip count: np_floor_divide_int votes)
+            const int c = c0 + tid;
+            const int X = fdiv(c, Ay, P.mg_ay), Y = c - X * Ay;
+            const bool in_range = c < AC && X <= Ax - s_ax && Y <= Ay - s_ay;
+            double m = has_out ? 0.0 : -1e300;
+            if (in_range) {
+                const double* h0 = hm + (X * P.step) * P.Hy + Y * P.step;
+                for (int e = 0; e < nb; ++e) {
+                    const Cell ce = cells[e];
+                    m = fmax(m, h0[(ce.ij & 0xFFFF) * P.Hy + (ce.ij >> 16)] - ce.v);
+                }
+            }
+            const bool valid = in_range && round6_scaled(m + ext_z_r - P.bin_z) <= 0.0;      // np.round(.,6) <= 0 (space.py:120)
+            const int li = np_floor_divide_int(valid ? m : 0.0, P.res_z, P.inv_res_z);       // cvTools.py:78
+            if (valid) {
+                zdst[r * AC + c] = m;
+                if (li != -1) {                                            // level -1 is skipped (cvTools.py:84)
+                    const int idx = li + 32;
+                    if (idx < 0 || idx > 63) raise_error(S, IRBPP_DEVERR_LEVEL_RANGE);
+                    else {
+                        lev[r * AC + c] = (uint8_t)idx;
+                        atomicOr(&present[r * 2 + (idx >> 5)], 1u << (idx & 31));
+                    }
+                }
+                atomicOr(&vbits[r * VR + X], 1u << Y);
+                ++my_valid;
+            }
+        }
+    }
+    const int nvalid = block_sum_int(my_valid, redi);
+    // the tile is done with after its float32 copy: item vector and heightmap of the observation (binPhy.py:196-203)
+    if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
+    for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)hm[i];
+    {   // naiveMask's bit rows: what the next apply looks its drop height up with
+        uint32_t* gb = S.w_valid + (size_t)b * R * VR;
+        for (int i = tid; i < R * VR; i += BLOCK) gb[i] = vbits[i];
+    }
+    __syncthreads();
+
+    // ---- getConvexHullActions (cvTools.py:61-102): one level image after the other
+    const uint32_t wmask = Ay >= 32 ? 0xFFFFFFFFu : ((1u << Ay) - 1u);
+    const int tl = (lane < WIDE_TL / WAVES) ? (tid >> 6) * (WIDE_TL / WAVES) + lane : -1;      // tracing lanes: four per wave
+    uint8_t* const tbase = smem + W.o_trace + (tl >= 0 ? tl : 0) * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
+    uint16_t* const tpts = (uint16_t*)tbase;
+    uint16_t* const tdst = tpts + WIDE_LCAP;
+    uint32_t* const tstk = (uint32_t*)(tdst + WIDE_LCAP);
+    uint8_t* const big = S.w_big + (size_t)b * WIDE_BIG_BYTES;
+    for (int r = 0; r < R; ++r) {
+        for (int half = 0; half < 2; ++half) {
+            uint32_t pm = present[r * 2 + half];
+            pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm);
+            while (pm != 0u) {
+                const int code = half * 32 + __ffs((int)pm) - 1;
+                pm &= pm - 1u;
+                if (tid < 32) rows[tid] = 0u;
+                if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+                __syncthreads();
+                for (int c = tid; c < AC; c += BLOCK)
+                    if (lev[r * AC + c] == code) {
+                        const int X = fdiv(c, Ay, P.mg_ay), Y = c - X * Ay;
+                        atomicOr(&rows[X], 1u << Y);
+                    }
+                __syncthreads();
+                if (tid < Ax) {                                            // candidate starts of row tid
+                    uint32_t cand = start_candidates_wide(rows[tid], tid > 0 ? rows[tid - 1] : 0u, wmask);
+                    while (cand != 0u) {
+                        const int x = __ffs((int)cand) - 1;
+                        cand &= cand - 1u;
+                        const int at = atomicAdd(&cnt[0], 1);
+                        if (at < WIDE_CLIST) clist[at] = (uint16_t)(x | (tid << 5));
+                    }
+                }
+                __syncthreads();
+                const int total = cnt[0] < WIDE_CLIST ? cnt[0] : WIDE_CLIST;
+                if (cnt[0] > WIDE_CLIST && tid == 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
+                if (tl >= 0)
+                    for (int ci = tl; ci < total; ci += WIDE_TL) {
+                        const int e = clist[ci], x0 = e & 31, y0 = e >> 5;
+                        const int n = trace_border_wide<5>(rows, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
+                        bool redo = false;
+                        if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+                        else if (n > WIDE_LCAP) redo = true;
+                        else if (n > 0) redo = !approx_and_convex_t<uint16_t, 5>(tpts, n, tdst, tstk, WIDE_LCAP, vmask + r * VR);
+                        if (redo) {                                        // outgrew the slot: thread 0, in global scratch, below
+                            const int at = atomicAdd(&cnt[1], 1);
+                            if (at < 64) redo_list[at] = (uint16_t)e;
+                        }
+                    }
+                __syncthreads();
+                if (cnt[1] > 0 && tid == 0) {
+                    uint16_t* bp = (uint16_t*)big;
+                    uint16_t* bd = bp + WIDE_BIG;
+                    uint32_t* bs = (uint32_t*)(bd + WIDE_BIG);
+                    const int nredo = cnt[1] < 64 ? cnt[1] : 64;
+                    if (cnt[1] > 64) raise_error(S, IRBPP_DEVERR_CAPACITY);
+                    for (int k = 0; k < nredo; ++k) {
+                        const int e = redo_list[k];
+                        const int n = trace_border_wide<5>(rows, Ay, Ax, e & 31, e >> 5, bp, WIDE_BIG);
+                        if (n < 0 || n > WIDE_BIG || !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR))
+                            raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+                    }
+                }
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- cur_observation's candidate block (binPhy.py:204-227): rows per rotation ordered by (col, row) (np.unique, cvTools.py:101)
+    if (tid == 0) ((unsigned long long*)redd)[7] = ~0ull;
+    const int prev_rows = io.obs_rows != nullptr ? io.obs_rows[b] : -1;
+    uint32_t* const okey = keys + R * AC;
+    int n = 0;
+    if (tid < 64) {
+        const int cx = lane & 31;
+        for (int r0 = 0; r0 < R; r0 += 2) {
+            const int r = r0 + (lane >> 5);
+            uint32_t col = 0u;
+            if (r < R && cx < Ay)
+                for (int cy = 0; cy < Ax; ++cy) col |= ((vmask[r * VR + cy] >> cx) & 1u) << cy;
+            const int c = __popc(col), incl = wave_inclusive_sum(c);
+            int at = n + incl - c;
+            while (col != 0u) {
+                const int cy = __ffs((int)col) - 1;
+                col &= col - 1u;
+                keys[at++] = ((uint32_t)r << 16) | ((uint32_t)cy << 8) | (uint32_t)cx;
+            }
+            n += __builtin_amdgcn_readlane(incl, 63);
+        }
+        if (tid == 0) redi[34] = n;
+    }
+    __syncthreads();
+    n = redi[34];
+    int nrows;
+    bool fallback = false;
+    const uint32_t* rws;
+    const uint32_t* const gvalid = vbits;
+    if (n > 0 && n <= P.S) {
+        nrows = n;
+        rws = keys;
+    } else if (n > P.S) {
+        wide_select(P, zdst, nullptr, n, P.S, [&](int e) { return keys[e]; }, okey, keys, hist, skl, redi);
+        nrows = P.S;
+        rws = okey;
+    } else {
+        fallback = true;
+        const int total_cells = R * AC;
+        const int want = total_cells < P.S ? total_cells : P.S;
+        auto cell_key = [&](int e) {
+            const int r = fdiv(e, AC, P.mg_ac), c = e - r * AC, x = fdiv(c, Ay, P.mg_ay);
+            return ((uint32_t)r << 16) | ((uint32_t)x << 8) | (uint32_t)(c - x * Ay);
+        };
+        if (nvalid == 0) {
+            for (int e = tid; e < want; e += BLOCK) okey[e] = cell_key(e);
+            __syncthreads();
+        } else {
+            wide_select(P, zdst, gvalid, total_cells, want, cell_key, okey, keys, hist, skl, redi);
+        }
+        nrows = want;
+        rws = okey;
+    }
+    __syncthreads();
+    int write_rows = P.S;
+    if (io.obs_rows != nullptr) {
+        if (prev_rows >= 0) write_rows = prev_rows > nrows ? prev_rows : nrows;
+        if (tid == 0) io.obs_rows[b] = nrows;
+    }
+    float best = INFINITY;
+    int bi = 0x7fffffff;
+    for (int row = tid; row < write_rows; row += BLOCK) {
+        float v0 = 0.0f, v1 = 0.0f, v2 = 0.0f, v3 = 0.0f, v4 = 0.0f;
+        if (row < nrows) {
+            const uint32_t k = rws[row];
+            float rv;
+            if (fallback) rv = (float)((gvalid[(k >> 16) * VR + ((k >> 8) & 255u)] >> (k & 255u)) & 1u);
+            else rv = (float)zdst[(k >> 16) * AC + ((k >> 8) & 255u) * Ay + (k & 255u)];
+            v0 = (float)(k >> 16);
+            v1 = (float)((k >> 8) & 255u);
+            v2 = (float)(k & 255u);
+            v3 = fallback ? (float)P.bin_z : rv;
+            v4 = fallback ? rv : 1.0f;
+            S.cand[(size_t)b * P.S + row] = k;
+            if (!fallback && rv < best) { best = rv; bi = row; }
+        }
+        float* const o = obs + 5 * row;
+        o[0] = v0; o[1] = v1; o[2] = v2; o[3] = v3; o[4] = v4;
+    }
+    if (tid == 0) {
+        S.bs[b].cur_item = item;
+        S.bs[b].nvalid = nvalid;
+        S.bs[b].nrows = nrows;
+    }
+    if (io.auto_action != nullptr) {                                     // the scripted MINZ policy on the rows just written
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o);
+            const int oi = __shfl_xor(bi, o);
+            if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        if (lane == 0) {
+            const uint32_t fb = (uint32_t)__float_as_int(best + 0.0f);
+            const uint32_t su = fb ^ ((fb >> 31) != 0u ? 0xFFFFFFFFu : 0x80000000u);
+            atomicMin((unsigned long long*)redd + 7, ((unsigned long long)su << 32) | (uint32_t)bi);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int won = (int)(uint32_t)(((const unsigned long long*)redd)[7] & 0xFFFFFFFFull);
+            io.auto_action[b] = won == 0x7fffffff ? 0 : won;
+        }
+    }
+    if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) atomicOr(io.err_out, *S.err);
+}
+
+}  // namespace irbpp

@@ -22,7 +22,7 @@
 #include <string.h>
 
 #define MAXR 8
-#define MAXA 16
+#define MAXA 32                              /* action cells a side: 16 at resolutionA 0.02, 32 at 0.01 (space.py:24) */
 #define MAXK 16
 
 typedef struct {
@@ -110,10 +110,10 @@ static void get_possible_position(orc_env *e, int item) {
 /* ---------------------------------------------------------------- OpenCV restatement */
 static const int DX[8] = {1, 1, 0, -1, -1, -1, 0, 1}, DY[8] = {0, -1, -1, -1, 0, 1, 1, 1};
 
-typedef struct { int n; int x[1024], y[1024]; } contour_t;
+typedef struct { int n; int x[4096], y[4096]; } contour_t;
 
-/* icvFetchContourEx, CHAIN_APPROX_SIMPLE, on the padded label image (18 x 18) */
-static void fetch_contour(int img[18][18], int x0, int y0, int is_hole, int nbd, contour_t *c) {
+/* icvFetchContourEx, CHAIN_APPROX_SIMPLE, on the padded label image */
+static void fetch_contour(int img[MAXA + 2][MAXA + 2], int x0, int y0, int is_hole, int nbd, contour_t *c) {
     int s_end = is_hole ? 0 : 4, s = s_end, x1, y1;
     c->n = 0;
     do { s = (s - 1) & 7; x1 = x0 + DX[s]; y1 = y0 + DY[s]; } while (img[y1][x1] == 0 && s != s_end);
@@ -125,7 +125,7 @@ static void fetch_contour(int img[18][18], int x0, int y0, int is_hole, int nbd,
         s &= 7;
         if ((unsigned)(s - 1) < (unsigned)s_end) img[y3][x3] = -nbd;
         else if (img[y3][x3] == 1) img[y3][x3] = nbd;
-        if (s != prev_s) { if (c->n < 1024) { c->x[c->n] = px; c->y[c->n] = py; } c->n++; }
+        if (s != prev_s) { if (c->n < 4096) { c->x[c->n] = px; c->y[c->n] = py; } c->n++; }
         prev_s = s;
         px += DX[s]; py += DY[s];
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) break;
@@ -136,7 +136,7 @@ static void fetch_contour(int img[18][18], int x0, int y0, int is_hole, int nbd,
 /* approxPolyDP_<int>(closed, eps = 1); returns the polygon in (ox, oy) */
 static int approx_poly_dp(const contour_t *c, int *ox, int *oy) {
     const int count0 = c->n;
-    static __thread int sx_[2048], se_[2048];
+    static __thread int sx_[8192], se_[8192];
     int count = count0, new_count = 0, top = 0, pos = 0, right_start = 0, le_eps = 0, spx = 0, spy = 0;
     if (count == 0) return 0;
     for (int it = 0; it < 3; ++it) {
@@ -208,7 +208,7 @@ static int approx_poly_dp(const contour_t *c, int *ox, int *oy) {
 static void convex_hulls(orc_env *e, int r, unsigned char hit[MAXA][MAXA]) {
     int mapInt[MAXA][MAXA], levels[MAXA * MAXA], nlev = 0;
     static __thread contour_t c;
-    static __thread int ox[1024], oy[1024];
+    static __thread int ox[4096], oy[4096];
     for (int X = 0; X < e->Ax; ++X)
         for (int Y = 0; Y < e->Ay; ++Y) {
             mapInt[X][Y] = e->mask[r][X][Y] == 0.0 ? -1 : (int)np_floor_divide(e->poszv[r][X][Y], e->resZ);
@@ -219,7 +219,7 @@ static void convex_hulls(orc_env *e, int r, unsigned char hit[MAXA][MAXA]) {
     for (int li = 0; li < nlev; ++li) {
         const int h = levels[li];
         if (h == -1) continue;
-        int img[18][18];
+        int img[MAXA + 2][MAXA + 2];
         memset(img, 0, sizeof(img));
         for (int X = 0; X < e->Ax; ++X)
             for (int Y = 0; Y < e->Ay; ++Y) img[X + 1][Y + 1] = mapInt[X][Y] == h;

@@ -266,19 +266,19 @@ class _CandidateTap(object):
         ref_binphy.getConvexHullActions = self.real
 
 
-def run_online(shapes, sequences, steps, S=500, res_h=0.01, tap=False):
+def run_online(shapes, sequences, steps, S=500, res_h=0.01, tap=False, res_a=0.02):
     """``tap``: also record the candidate row count in front of every observation (``ncand``) and END the recording in
     front of the first observation whose > S selection had ties among its S + 1 lowest heights (see _CandidateTap)."""
     ct = _CandidateTap().install(S) if tap else None
     try:
-        return _run_online(shapes, sequences, steps, S, res_h, ct)
+        return _run_online(shapes, sequences, steps, S, res_h, ct, res_a)
     finally:
         if ct is not None:
             ct.remove()
 
 
-def _run_online(shapes, sequences, steps, S, res_h, ct):
-    env = make_reference_env(shapes, sequences, 1, S, res_h=res_h)
+def _run_online(shapes, sequences, steps, S, res_h, ct, res_a=0.02):
+    env = make_reference_env(shapes, sequences, 1, S, res_a=res_a, res_h=res_h)
     obs = env.reset()
     ncand = [ct.n] if ct else None
     rec = dict(obs=[obs.copy()], act=[], rew=[], done=[], counter=[], ratio=[], ep_r=[],
@@ -311,8 +311,8 @@ def _run_online(shapes, sequences, steps, S, res_h, ct):
     return out
 
 
-def run_hier(shapes, sequences, steps, k, S=500):
-    env = make_reference_env(shapes, sequences, k, S)
+def run_hier(shapes, sequences, steps, k, S=500, res_a=0.02):
+    env = make_reference_env(shapes, sequences, k, S, res_a=res_a)
     order_obs = env.reset()
     rec = dict(order_obs=[order_obs.copy()], loc_obs=[], order_act=[], act=[], rew=[], done=[],
                counter=[], ratio=[])
@@ -654,6 +654,12 @@ def main():
     np.savez_compressed(os.path.join(OUT, "tools_test_hier.npz"), **tools_test_hier_golden())
     np.savez_compressed(os.path.join(OUT, "random_creators.npz"), **random_creator_golden())
     np.savez_compressed(os.path.join(OUT, "heuristic_cases.npz"), **heuristic_cases())
+    # resolutionA = 0.01: a 32 x 32 action grid (space.py:19-24), online on free-form solids (recorded up to its first tied > S
+    # selection, if any) and hierarchical on the small BlockOut set; S = 1000 keeps most selections below S
+    wide = synthetic.general_shapes(n_shapes=16, n_rot=4, fmin=4, fmax=14, seed=3)
+    seq_w = synthetic.make_sequences(wide.n_shapes, 16, 80, seed=2)
+    np.savez_compressed(os.path.join(OUT, "online_wide32.npz"), seq=seq_w, **run_online(wide, seq_w, 60, S=1000, tap=True, res_a=0.01))
+    np.savez_compressed(os.path.join(OUT, "hier_wide32_k3.npz"), seq=seq_b, **run_hier(blk, seq_b, 40, 3, S=1000, res_a=0.01))
     if "--skip-baseline-configs" not in sys.argv:
         for name, rec in baseline_config_goldens().items():
             np.savez_compressed(os.path.join(OUT, name + ".npz"), **rec)

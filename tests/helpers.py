@@ -71,6 +71,13 @@ ONLINE_GOLDENS = ["online_cube", "online_blockout", "online_general", "bench_blo
 HIER_GOLDENS = [("hier_blockout_k3", 3), ("bench_blockout_k10", 10)]
 
 
+def wide_scenario(name):
+    """Shape sets of the resolutionA = 0.01 goldens (make_golden.py: online_wide32, hier_wide32_k3)."""
+    if name == "online_wide32":
+        return synthetic.general_shapes(n_shapes=16, n_rot=4, fmin=4, fmax=14, seed=3)
+    return synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+
+
 def _bench_workload(name):
     from bench import make_workload
     return make_workload(name)

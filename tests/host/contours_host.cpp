@@ -113,6 +113,31 @@ int host_trace_border_walk_spill(const uint16_t* rows, int x0, int y0, uint8_t* 
     return n;
 }
 
+// WIDE action grids (up to 32 x 32): candidate starts of every row, and the convex vertices of every component's outer border
+// through trace_border_wide + approx_and_convex_t<uint16_t, 5> -- what irbpp_kernels.hip's wide_observe does per level image.
+// rows[H]: bit x of word y = pixel (x, y); out_cand[H]: candidate start bits; vrows[H]: vertex bits.  Returns the number of borders
+// (candidates that turned out first pixels), negative on a guard / stack failure.
+int host_wide_image_vertices(const uint32_t* rows, int W, int H, int cap, int cap_stk, uint32_t* out_cand, uint32_t* vrows, int* longest) {
+    static uint16_t pts[4096], dst[4096];
+    static uint32_t stk[4096];
+    const uint32_t wmask = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+    int borders = 0;
+    *longest = 0;
+    for (int y = 0; y < H; ++y) { vrows[y] = 0; out_cand[y] = start_candidates_wide(rows[y], y ? rows[y - 1] : 0u, wmask); }
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            if (!((out_cand[y] >> x) & 1u)) continue;
+            const int n = trace_border_wide<5>(rows, W, H, x, y, pts, cap);
+            if (n < 0) return -1;
+            if (n == 0) continue;
+            if (n > cap) return -2;
+            if (n > *longest) *longest = n;
+            if (!approx_and_convex_t<uint16_t, 5>(pts, n, dst, stk, cap_stk, vrows)) return -3;
+            ++borders;
+        }
+    return borders;
+}
+
 // approx_and_convex on a point list: vrows[16] gets the vertex bits; returns 1 ok, 0 stack overflow.
 int host_approx_and_convex(const uint8_t* pts, int count, int cap_stk, uint32_t* vrows) {
     static uint8_t dst[4096];

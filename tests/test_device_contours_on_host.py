@@ -54,6 +54,8 @@ def host():
     lib.host_trace_border_fast.restype = C.c_int
     lib.host_trace_border_fast_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
     lib.host_trace_border_fast_spill.restype = C.c_int
+    lib.host_wide_image_vertices.argtypes = [u32p, C.c_int, C.c_int, C.c_int, C.c_int, u32p, u32p, C.POINTER(C.c_int)]
+    lib.host_wide_image_vertices.restype = C.c_int
     lib.host_trace_border_walk.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
     lib.host_trace_border_walk.restype = C.c_int
     lib.host_trace_border_walk_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
@@ -364,3 +366,61 @@ def test_register_transpose_of_a_level_image(host):
         host.host_transpose16(rows.ctypes.data_as(u16p), cols.ctypes.data_as(u16p))
         want = np.array([sum(int(img[y, x]) << y for y in range(16)) for x in range(16)], dtype=np.uint16)
         assert np.array_equal(cols, want)
+
+
+def _wide_images(seed, n, W, H):
+    rng = np.random.RandomState(seed)
+    for k in range(n):
+        kind = k % 5
+        if kind == 0:
+            img = rng.rand(H, W) < rng.uniform(0.15, 0.85)
+        elif kind == 1:
+            img = ndimage.binary_dilation(rng.rand(H, W) < 0.08, structure=np.ones((3, 3))) & ~(rng.rand(H, W) < 0.1)
+        elif kind == 2:                                   # unions of rectangles: level sets of box stacks
+            img = np.zeros((H, W), dtype=bool)
+            for _ in range(rng.randint(1, 9)):
+                y, x = rng.randint(0, H), rng.randint(0, W)
+                img[y:y + rng.randint(1, 17), x:x + rng.randint(1, 17)] ^= True
+        elif kind == 3:                                   # rings, full frame included
+            img = np.zeros((H, W), dtype=bool)
+            for m in range(rng.randint(0, 2), min(H, W) // 2, rng.randint(2, 4)):
+                img[m:H - m, m:W - m] = True
+                img[m + 1:H - 1 - m, m + 1:W - 1 - m] = False
+        else:                                             # diagonals, staircases, combs
+            img = np.zeros((H, W), dtype=bool)
+            for _ in range(rng.randint(1, 8)):
+                y, x, d = rng.randint(0, H), rng.randint(0, W), rng.choice([-1, 1])
+                for s in range(rng.randint(2, 24)):
+                    yy, xx = y + s, x + d * s
+                    if 0 <= yy < H and 0 <= xx < W:
+                        img[yy, max(xx, 0):xx + rng.randint(1, 4)] = True
+            if k % 10 == 9:
+                img[::2, :] = True                        # a comb: the longest borders a grid can hold
+                img[:, 0] = True
+        yield img.astype(np.uint8)
+
+
+@pytest.mark.parametrize("W,H,seed", [(32, 32, 0), (32, 32, 1), (32, 32, 2), (24, 32, 3), (32, 17, 4), (20, 27, 5)])
+def test_wide_grid_routines_equal_the_oracle(host, W, H, seed):
+    """Action grids of 17 .. 32 cells a side (resolutionA = 0.01): candidate starts, the plain border walk with 16-bit points
+    and approxPolyDP + convexity (contours_device.h: start_candidates_wide, trace_border_wide, approx_and_convex_t<uint16_t, 5>)
+    on whole level images against the oracle's findContours / approxPolyDP / find_convex_vetex."""
+    cand = (C.c_uint32 * H)()
+    vrows = (C.c_uint32 * H)()
+    longest = C.c_int(0)
+    seen_long = 0
+    for img in _wide_images(seed, 120, W, H):
+        rows = (C.c_uint32 * H)(*[int(sum(int(img[y, x]) << x for x in range(W))) for y in range(H)])
+        outer, _, _ = _oracle_outer(img)
+        n = host.host_wide_image_vertices(rows, W, H, 4096, 4096, cand, vrows, C.byref(longest))
+        assert n == len(outer)                                             # one border per component
+        starts = {(x, y) for y in range(H) for x in range(W) if (cand[y] >> x) & 1}
+        assert {c[0] for c in outer} <= starts                              # every first pixel is listed
+        want = set()
+        for c in outer:
+            want |= _oracle_vertices(c)
+        got = {(x, y) for y in range(H) for x in range(W) if (vrows[y] >> x) & 1}
+        assert got == want
+        assert longest.value == max([len(c) for c in outer], default=0)
+        seen_long = max(seen_long, longest.value)
+    assert seen_long > 64                                                   # borders beyond the 16 x 16 grid's slot were covered

@@ -217,3 +217,55 @@ def test_heuristic_actions_match_reference(golden_dir, tag):
         if done:
             obs = env.reset()
     assert bool(g[tag + "_random_raises"])       # the reference's RANDOM branch raises for every input: nothing to match
+
+
+@pytest.mark.parametrize("which", ["numpy", "c"])
+def test_wide_action_grid_matches_reference(golden_dir, which):
+    """resolutionA = 0.01: a 32 x 32 action grid (space.py:19-24), as the reference's own PackingGame played it
+    (tests/golden/make_golden.py: online_wide32 on free-form solids, hier_wide32_k3 on the small BlockOut set, S = 1000) --
+    both oracles; the GPU's capacity path for such grids meets the same files in tests/test_gpu_wide.py."""
+    from helpers import wide_scenario
+    from oracle.c_oracle import CPackingGame
+    SW = 1000
+    g = _load(golden_dir, "online_wide32")
+    sh = wide_scenario("online_wide32")
+    kw = dict(selectedAction=SW, resolutionA=0.01)
+    env = PackingGame(sh, g["seq"], bufferSize=1, **kw) if which == "numpy" else CPackingGame(sh, g["seq"], **kw)
+    obs = env.reset()
+    np.testing.assert_array_equal(obs, g["obs"][0])
+    fallbacks = 0
+    for t in range(len(g["act"])):
+        if which == "numpy":
+            np.testing.assert_array_equal(env.space.naiveMask, g["mask"][t])
+            np.testing.assert_array_equal(env.space.posZmap, g["posz"][t])
+        a = minz_action(obs, SW)
+        assert a == g["act"][t]
+        obs, r, d, info = env.step(a)
+        assert r == g["rew"][t] and d == g["done"][t]
+        if d:
+            assert info["counter"] == g["counter"][t] and info["ratio"] == g["ratio"][t]
+            obs = env.reset()
+        np.testing.assert_array_equal(obs[5 * SW:], g["obs"][t + 1][5 * SW:])
+        if (obs[:5 * SW].reshape(SW, 5)[:, 4] == 1).any():
+            np.testing.assert_array_equal(obs, g["obs"][t + 1])
+        else:
+            assert_fallback_rows_legal(obs[:5 * SW].reshape(SW, 5), sh.n_rot, ax=32, ay=32)
+            fallbacks += 1
+    assert g["done"].sum() >= 2 and fallbacks >= 1 and g["ncand"].max() > 500
+    g = _load(golden_dir, "hier_wide32_k3")
+    kw = dict(selectedAction=SW, resolutionA=0.01, bufferSize=3)
+    sh = wide_scenario("hier_wide32_k3")
+    env = PackingGame(sh, g["seq"], **kw) if which == "numpy" else CPackingGame(sh, g["seq"], **kw)
+    np.testing.assert_array_equal(env.reset(), g["order_obs"][0])
+    for t in range(len(g["act"])):
+        loc = env.get_action_candidates(int(g["order_act"][t]))
+        np.testing.assert_array_equal(loc[5 * SW:], g["loc_obs"][t][5 * SW:])
+        if (loc[:5 * SW].reshape(SW, 5)[:, 4] == 1).any():
+            np.testing.assert_array_equal(loc, g["loc_obs"][t])
+        a = minz_action(loc, SW)
+        assert a == g["act"][t]
+        order, r, d, info = env.step(a)
+        assert r == g["rew"][t] and d == g["done"][t]
+        if d:
+            order = env.reset()
+        np.testing.assert_array_equal(order, g["order_obs"][t + 1])

@@ -1,0 +1,216 @@
+"""Action grids of 17 .. 32 cells a side -- resolutionA = 0.01 on the 0.32 m bin (space.py:19-24 takes any resolutionA with an
+integral stepSize) -- through irbpp_wide.hip's capacity path (one kernel per observation: overlap test, level images of 32 x 32
+bits, 16-bit contour points, > S selection over up to 8192 cells) against BOTH oracles: every observation, reward, done flag,
+info and heightmap, online and hierarchical, through auto-resets, > S selections and the no-candidate fallback."""
+import numpy as np
+import pytest
+import torch
+
+import irbpp_amd  # noqa: F401
+from irbpp_amd import _lib, synthetic
+from irbpp_amd.vec_env import GpuPackingEnv, GpuVecEnv
+from oracle.c_oracle import COracleVecEnv
+from oracle.packing import OracleVecEnv
+from helpers import minz_action
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+S = 500
+
+
+def _f32(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+def _play(shapes, seqs, n, steps, numpy_steps, **kw):
+    """GPU against the C oracle for `steps` steps, the numpy oracle beside them for the first `numpy_steps`."""
+    genv = GpuVecEnv(shapes, seqs, n, device=DEV, **kw)
+    genv.candidates_on_device = True
+    assert "irbpp_wide_kernel alone" in genv.env.kernel_info()[1]
+    cenv = COracleVecEnv(n, shapes, seqs, **kw)
+    oenv = OracleVecEnv(n, shapes, seqs, **kw)
+    gobs = genv.reset()
+    cobs = _f32(cenv.reset())
+    np.testing.assert_array_equal(gobs.cpu().numpy(), cobs)
+    np.testing.assert_array_equal(_f32(oenv.reset()), cobs)
+    s_sel = kw.get("selectedAction", S)
+    done_total, full, fallbacks = 0, 0, 0
+    for t in range(steps):
+        act = genv.env.policy_minz(gobs).cpu().numpy()
+        np.testing.assert_array_equal(act, np.array([minz_action(o, s_sel) for o in cobs]))
+        gobs, grew, gdone, ginfo = genv.step(act)
+        cobs, crew, cdone, cinfo = cenv.step(act)
+        cobs = _f32(cobs)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), cobs, err_msg=f"step {t}")
+        np.testing.assert_array_equal(gdone, cdone)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], crew.astype(np.float32))
+        for i in range(n):
+            if cdone[i]:
+                assert ginfo[i]["counter"] == cinfo[i]["counter"] and ginfo[i]["ratio"] == cinfo[i]["ratio"]
+                assert ginfo[i]["episode"]["r"] == cinfo[i]["episode"]["r"]
+        if t < numpy_steps:
+            oobs, orew, odone, _ = oenv.step(act)
+            np.testing.assert_array_equal(_f32(oobs), cobs, err_msg=f"numpy oracle, step {t}")
+            np.testing.assert_array_equal(odone, cdone)
+        hm = genv.env.get_heightmaps().cpu().numpy()
+        for i in range(n):
+            np.testing.assert_array_equal(hm[i], cenv.envs[i].heightmap())
+        rows = cobs[:, :5 * s_sel].reshape(n, s_sel, 5)
+        full += int((rows[:, :, 4] == 1).all(axis=1).sum())                  # all S rows are candidates: the > S selection ran (or n == S)
+        fallbacks += int(((rows[:, :, 4] == 0).all(axis=1) & (rows[:, 0, 3] == np.float32(0.30))).sum())
+        done_total += int(cdone.sum())
+    genv.env.check_device_error()
+    genv.close()
+    return done_total, full, fallbacks
+
+
+def test_wide_online_free_form_matches_both_oracles():
+    sh = synthetic.general_shapes(n_shapes=16, n_rot=4, fmin=4, fmax=14, seed=3)
+    seqs = synthetic.make_sequences(sh.n_shapes, 32, 80, seed=2)
+    done, full, fallbacks = _play(sh, seqs, 4, 70, 10, resolutionA=0.01, resolutionH=0.01)
+    assert done >= 2 and full >= 10 and fallbacks >= 1, (done, full, fallbacks)
+
+
+def test_wide_online_eight_rotations_and_cubes():
+    sh = synthetic.general_shapes(n_shapes=12, n_rot=8, fmin=4, fmax=10, seed=5)
+    seqs = synthetic.make_sequences(sh.n_shapes, 32, 80, seed=4)
+    done, full, _ = _play(sh, seqs, 3, 40, 4, resolutionA=0.01, resolutionH=0.01)
+    assert full >= 5, (done, full)
+    cube = synthetic.cube_shapes()
+    done, _, _ = _play(cube, synthetic.make_sequences(cube.n_shapes, 32, 80, seed=6), 3, 45, 4, resolutionA=0.01, resolutionH=0.01)
+    assert done >= 1
+
+
+def test_wide_odd_grid_and_fine_heightmap():
+    """30 x 26 action cells (a 0.30 x 0.26 m bin), and resolutionA = 0.01 over resolutionH = 0.005 (stepSize 2, a 64 x 64 heightmap)."""
+    sh = synthetic.general_shapes(n_shapes=12, n_rot=4, fmin=4, fmax=12, seed=7)
+    seqs = synthetic.make_sequences(sh.n_shapes, 32, 80, seed=8)
+    done, _, _ = _play(sh, seqs, 3, 40, 4, resolutionA=0.01, resolutionH=0.01, bin_dimension=(0.30, 0.26, 0.30), selectedAction=300)
+    assert done >= 1
+    fine = synthetic.general_shapes(n_shapes=10, n_rot=4, fmin=8, fmax=24, res_h=0.005, seed=9)
+    _play(fine, synthetic.make_sequences(fine.n_shapes, 16, 60, seed=10), 2, 16, 2, resolutionA=0.01, resolutionH=0.005)
+
+
+def test_wide_hierarchical_matches_the_oracles():
+    sh = synthetic.blockout_shapes(n_shapes=24, n_rot=4, cube=0.06, seed=0)
+    seqs = synthetic.make_sequences(sh.n_shapes, 64, 150, seed=5)
+    n, k = 3, 4
+    kw = dict(resolutionA=0.01, resolutionH=0.01, bufferSize=k)
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, **kw)
+    genv.candidates_on_device = True
+    cenv = COracleVecEnv(n, sh, seqs, **kw)
+    oenv = OracleVecEnv(n, sh, seqs, **kw)
+    gord = genv.reset()
+    np.testing.assert_array_equal(gord.cpu().numpy(), _f32(cenv.reset()))
+    oenv.reset()
+    done_total = 0
+    for t in range(60):
+        oa = np.array([(t * 5 + 1 + i) % k for i in range(n)])
+        gloc = genv.get_action_candidates(oa)
+        cloc = _f32(cenv.get_action_candidates(oa))
+        np.testing.assert_array_equal(gloc.cpu().numpy(), cloc, err_msg=f"location observation, placement {t}")
+        if t < 5:
+            np.testing.assert_array_equal(_f32(oenv.get_action_candidates(oa)), cloc)
+        if t % 9 == 4:                                                       # every buffer slot at once (binPhy.py:171-180)
+            every = genv.get_all_possible_observation().reshape(n, k, -1)
+            for j in range(k):
+                np.testing.assert_array_equal(every[:, j].cpu().numpy(), _f32(cenv.get_action_candidates(np.full(n, j))))
+            gloc = genv.get_action_candidates(oa)
+            cenv.get_action_candidates(oa)
+        act = genv.env.policy_minz(gloc).cpu().numpy()
+        gord, grew, gdone, _ = genv.step(act)
+        cord, crew, cdone, _ = cenv.step(act)
+        np.testing.assert_array_equal(gord.cpu().numpy(), _f32(cord))
+        np.testing.assert_array_equal(gdone, cdone)
+        np.testing.assert_array_equal(grew.numpy()[:, 0], crew.astype(np.float32))
+        if t < 5:
+            oenv.step(act)
+        done_total += int(cdone.sum())
+    genv.env.check_device_error()
+    genv.close()
+    assert done_total >= 1
+
+
+def test_wide_reset_specific_errors_and_refused_entry_points():
+    sh = synthetic.general_shapes(n_shapes=12, n_rot=4, fmin=4, fmax=12, seed=3)
+    seqs = synthetic.make_sequences(sh.n_shapes, 32, 80, seed=2)
+    kw = dict(resolutionA=0.01, resolutionH=0.01)
+    env = GpuPackingEnv(sh, seqs, 4, device=DEV, **kw)
+    cenv = COracleVecEnv(4, sh, seqs, **kw)
+    obs = env.reset()
+    cobs = cenv.reset()
+    for t in range(6):
+        act = env.policy_minz(obs)
+        obs = env.step(act)[0]
+        cobs = cenv.step(act.cpu().numpy())[0]
+    sub = env.reset_bins(torch.tensor([2, 0], dtype=torch.int32, device=DEV))
+    np.testing.assert_array_equal(sub.cpu().numpy(), _f32(cenv.reset_specific([2, 0])))
+    env.check_device_error()
+    bad = env.policy_minz(obs)
+    bad[1] = S                                                               # outside the candidate rows
+    env.step(bad)
+    with pytest.raises(_lib.IrbppError, match="BAD_ACTION"):
+        env.step_info_host()
+    ids = torch.zeros(4, dtype=torch.int32, device=DEV)
+    with pytest.raises(_lib.IrbppError):
+        env.possible_position(ids)
+    with pytest.raises(_lib.IrbppError):
+        env.heuristic_action("MINZ")
+    env.close()
+    with pytest.raises(_lib.IrbppError):                                     # 33 cells a side: beyond the wide path too
+        GpuPackingEnv(sh, seqs, 2, device=DEV, resolutionA=0.01, resolutionH=0.01, bin_dimension=(0.33, 0.32, 0.30))
+
+
+@pytest.mark.parametrize("n", [1, 96])
+def test_wide_matches_the_reference_goldens(golden_dir, n):
+    """The reference's own PackingGame at resolutionA = 0.01 (tests/golden/make_golden.py: online_wide32, hier_wide32_k3; S = 1000):
+    the recorded episodes replayed by one bin and by every bin of a 96-bin launch."""
+    import os
+    from helpers import wide_scenario
+    from test_gpu_large_forms import _replay_table
+    SW = 1000
+    g = np.load(os.path.join(golden_dir, "online_wide32.npz"))
+    sh = wide_scenario("online_wide32")
+    env = GpuPackingEnv(sh, _replay_table(g["seq"], n, int(g["done"].sum())), n, device=DEV, selectedAction=SW, resolutionA=0.01)
+    ref = torch.from_numpy(_f32(g["obs"])).to(DEV)
+    obs = env.reset()
+    assert torch.equal(obs, ref[0].expand(n, -1))
+    fb = torch.from_numpy(np.array([[c // 1024, (c % 1024) // 32, c % 32, 0.30, 0.0] for c in range(SW)]).astype(np.float32).reshape(-1)).to(DEV)
+    act = torch.empty((n,), dtype=torch.int32, device=DEV)
+    fallbacks = 0
+    for t in range(len(g["act"])):
+        act.fill_(int(g["act"][t]))
+        obs, rew, done = env.step(act)
+        h = env.step_info_host()
+        assert (h["done"] == bool(g["done"][t])).all() and (h["reward"].astype(np.float32) == np.float32(g["rew"][t])).all(), t
+        if g["done"][t]:
+            assert (h["counter"] == g["counter"][t]).all() and (h["ratio"] == g["ratio"][t]).all()
+        r = ref[t + 1]
+        if bool((r[:5 * SW].reshape(SW, 5)[:, 4] == 1).any()):
+            assert torch.equal(obs, r.expand(n, -1)), f"step {t}"
+        else:                                                # fallback rows: the reference's order is its numpy build's (binPhy.py:217-225)
+            assert torch.equal(obs[:, 5 * SW:], r[5 * SW:].expand(n, -1)) and torch.equal(obs[:, :5 * SW], fb.expand(n, -1))
+            fallbacks += 1
+    assert fallbacks >= 1
+    env.check_device_error()
+    env.close()
+    g = np.load(os.path.join(golden_dir, "hier_wide32_k3.npz"))
+    env = GpuPackingEnv(wide_scenario("hier_wide32_k3"), _replay_table(g["seq"], n, int(g["done"].sum())), n, device=DEV, selectedAction=SW,
+                        resolutionA=0.01, bufferSize=3)
+    order_ref = torch.from_numpy(_f32(g["order_obs"])).to(DEV)
+    loc_ref = torch.from_numpy(_f32(g["loc_obs"])).to(DEV)
+    assert torch.equal(env.reset(), order_ref[0].expand(n, -1))
+    oa = torch.empty((n,), dtype=torch.int32, device=DEV)
+    for t in range(len(g["act"])):
+        oa.fill_(int(g["order_act"][t]))
+        loc = env.get_action_candidates(oa)
+        r = loc_ref[t]
+        assert torch.equal(loc[:, 5 * SW:], r[5 * SW:].expand(n, -1)), t
+        if bool((r[:5 * SW].reshape(SW, 5)[:, 4] == 1).any()):
+            assert torch.equal(loc, r.expand(n, -1)), f"placement {t}"
+        act.fill_(int(g["act"][t]))
+        order, rew, done = env.step(act)
+        assert bool((done.bool() == bool(g["done"][t])).all())
+        assert torch.equal(order, order_ref[t + 1].expand(n, -1)), t
+    env.check_device_error()
+    env.close()
