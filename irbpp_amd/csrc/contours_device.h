@@ -640,43 +640,45 @@ __device__ __forceinline__ uint32_t start_candidates_wide(uint32_t row, uint32_t
     t |= (t >> 16) & p16;
     return first & ~t;
 }
-__device__ __forceinline__ bool wide_fg(const uint32_t* rows, int W, int H, int x, int y) {
-    return x >= 0 && y >= 0 && x < W && y < H && ((rows[y] >> x) & 1u) != 0u;
+// 8-bit neighbour mask of pixel (x, y): bit s = the neighbour in direction s (0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE; y down)
+__device__ __forceinline__ uint32_t nb_mask_wide(const uint32_t* rows, int H, int x, int y) {
+    const unsigned long long ra = y > 0 ? rows[y - 1] : 0u, rb = rows[y], rc = y + 1 < H ? rows[y + 1] : 0u;
+    const uint32_t ta = (uint32_t)(((ra << 1) >> x) & 7ull), tb = (uint32_t)(((rb << 1) >> x) & 7ull), tc = (uint32_t)(((rc << 1) >> x) & 7ull);
+    // bit 0 of a triple = column x - 1, bit 1 = x, bit 2 = x + 1
+    return (tb >> 2) | ((ta >> 2) << 1) | (((ta >> 1) & 1u) << 2) | ((ta & 1u) << 3) | ((tb & 1u) << 4) | ((tc & 1u) << 5) |
+           (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
 }
 // Returns the number of points (all counted, the first `cap` stored), 0 if (x0, y0) is not the first pixel of its component,
-// -1 if the iteration guard tripped.
+// -1 if the iteration guard tripped.  (`rows` holds no bit beyond column W - 1 or row H - 1.)
 template <int SHIFT>
 __device__ inline int trace_border_wide(const uint32_t* rows, int W, int H, int x0, int y0, uint16_t* pts, int cap) {
-    int s = 4, x1 = 0, y1 = 0;
-    do {                                                                // first non-zero neighbour, clockwise from west (background)
-        s = (s - 1) & 7;
-        x1 = x0 + dir_dx(s);
-        y1 = y0 + dir_dy(s);
-    } while (!wide_fg(rows, W, H, x1, y1) && s != 4);
-    if (s == 4) {                                                       // isolated pixel
+    uint32_t nb = nb_mask_wide(rows, H, x0, y0);
+    // first non-zero neighbour, clockwise from west (background): 3, 2, 1, 0, 7, 6, 5
+    const uint32_t rot = ((nb << 4) | (nb >> 4)) & 0xFFu;                  // direction 3 -> bit 7
+    if (rot == 0u) {                                                       // isolated pixel
         if (cap > 0) pts[0] = (uint16_t)(x0 | (y0 << SHIFT));
         return 1;
     }
+    int s = (3 - (7 - (31 - __builtin_clz(rot)))) & 7;
+    const int x1 = x0 + dir_dx(s), y1 = y0 + dir_dy(s);
     int x3 = x0, y3 = y0, prev_s = s ^ 4, n = 0;
     for (int guard = 0; guard < 8192; ++guard) {
         IRBPP_TRACE_ITER();
-        int x4 = x3, y4 = y3;
-        while (s < 15) {                                                // counter-clockwise search, at most 15 probes
-            ++s;
-            x4 = x3 + dir_dx(s & 7);
-            y4 = y3 + dir_dy(s & 7);
-            if (wide_fg(rows, W, H, x4, y4)) break;
-        }
-        s &= 7;
-        if (s != prev_s) {                                              // CHAIN_APPROX_SIMPLE
+        // counter-clockwise search s + 1, s + 2, ... for the next border pixel (the one we came from is set: found within eight)
+        const int k2 = (s + 1) & 7;
+        const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;       // direction k2 -> bit 0
+        s = (k2 + __builtin_ctz(r2)) & 7;
+        const int x4 = x3 + dir_dx(s), y4 = y3 + dir_dy(s);
+        if (s != prev_s) {                                                 // CHAIN_APPROX_SIMPLE
             if (n < cap) pts[n] = (uint16_t)(x3 | (y3 << SHIFT));
             ++n;
         }
         prev_s = s;
         if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
-        if (y4 * W + x4 < y0 * W + x0) return 0;                        // an earlier pixel of the component: some other start's border
+        if (y4 * W + x4 < y0 * W + x0) return 0;                           // an earlier pixel of the component: some other start's border
         x3 = x4;
         y3 = y4;
+        nb = nb_mask_wide(rows, H, x3, y3);
         s = (s + 4) & 7;
     }
     return -1;

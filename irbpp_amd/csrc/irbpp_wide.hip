@@ -18,14 +18,15 @@
 namespace irbpp {
 
 constexpr int WIDE_VROW = 32;                     // words per rotation of w_valid / vertex bits on a wide grid
-constexpr int WIDE_TL = 16;                       // lanes of a workgroup that follow borders (four per wave)
-constexpr int WIDE_LCAP = 192;                    // contour points a tracing lane holds in LDS; longer borders: thread 0, global scratch
+constexpr int WIDE_TL = 64;                       // lanes of a workgroup that follow borders (sixteen per wave)
+constexpr int WIDE_LCAP = 128;                    // contour points a tracing lane holds in LDS; longer borders: thread 0, global scratch
+constexpr int WIDE_IB = 64;                       // level images built and followed at a time
 constexpr int WIDE_BIG = 4096;                    // ... of this many points
 constexpr int WIDE_BIG_BYTES = WIDE_BIG * (2 + 2 + 4);
-constexpr int WIDE_CLIST = 1024;
+constexpr int WIDE_CLIST = 2048;                  // candidate starts of a batch of images: image in batch << 10 | y0 << 5 | x0
 
 struct WideLayout {
-    int o_sr, o_present, o_vmask, o_vbits, o_red, o_keys, o_hist, o_rows, o_cnt, o_clist, o_redo, o_over, o_hm, o_lev, o_trace, o_skl, bytes;
+    int o_sr, o_present, o_vmask, o_vbits, o_red, o_keys, o_hist, o_rows, o_cnt, o_clist, o_redo, o_lut, o_imglist, o_lev, o_over, o_hm, o_trace, o_skl, bytes;
 };
 __host__ __device__ inline WideLayout wide_layout(const Params& P) {
     WideLayout w{};
@@ -39,20 +40,20 @@ __host__ __device__ inline WideLayout wide_layout(const Params& P) {
     int npad = 64;
     while (npad < P.S) npad <<= 1;
     w.o_hist = off;     off += align16(10 * npad > 1024 ? 10 * npad : 1024);  // radix counters, then the sort keys
-    w.o_rows = off;     off += 32 * 4;
+    w.o_rows = off;     off += WIDE_IB * 32 * 4;                               // a batch of level images: 32 rows of 32 bits each
     w.o_cnt = off;      off += 16;
     w.o_clist = off;    off += WIDE_CLIST * 2;
     w.o_redo = off;     off += 64 * 2;
-    w.o_over = off;                                                            // two phases share the bytes from here on
-    // phase 1 / 2: heightmap tile, level codes, the tracing lanes' slots
-    int a = off;
-    w.o_hm = a;         a += align16(P.Hc * 8);
-    w.o_lev = a;        a += align16(P.R * P.AC);
-    w.o_trace = a;      a += WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
-    // phase 3: the sortable images of the keys' values
-    int c = off;
-    w.o_skl = c;        c += align16(P.R * P.AC * 8);
-    w.bytes = a > c ? a : c;
+    w.o_lut = off;      off += align16(P.R * 64 * 2);                          // (rotation, level code) -> image number
+    w.o_imglist = off;  off += align16(P.R * 64 * 2);                          // image number -> rotation << 8 | level code
+    w.o_lev = off;      off += align16(P.R * P.AC);
+    w.o_over = off;                                                            // three phases share the bytes from here on
+    // phase 1: the heightmap tile; phase 2: the tracing lanes' slots; phase 3: the sortable images of the keys' values
+    const int a = off + align16(P.Hc * 8);
+    const int t = off + WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
+    const int c = off + align16(P.R * P.AC * 8);
+    w.o_hm = w.o_trace = w.o_skl = off;
+    w.bytes = a > c ? (a > t ? a : t) : (c > t ? c : t);
     return w;
 }
 
@@ -74,17 +75,36 @@ __device__ inline void wide_select(const Params& P, const double* zsrc, const ui
     for (int d = 7; d >= 0; --d) {                                       // the want-th smallest value, a byte per round from the top
         hist[tid] = 0u;
         __syncthreads();
-        for (int e = tid; e < n; e += BLOCK) {
-            const unsigned long long v = skl[e];
-            if (d == 7 || (v >> (8 * (d + 1))) == prefix) atomicAdd(&hist[(uint32_t)(v >> (8 * d)) & 255u], 1u);
+        // (the heights of one bin share their high bytes: a wave whose lanes agree on the digit adds its count once instead of 64
+        // serialised LDS atomics on one word -- select_smallest's trick)
+        for (int e0 = 0; e0 < n; e0 += BLOCK) {
+            const int e = e0 + tid;
+            const unsigned long long v = e < n ? skl[e] : 0ull;
+            const bool in = e < n && (d == 7 || (v >> (8 * (d + 1))) == prefix);
+            const int digit = (int)((uint32_t)(v >> (8 * d)) & 255u);
+            const unsigned long long act = __ballot(in);
+            if (act == 0ull) continue;
+            const int first = __ffsll((long long)act) - 1;
+            const int c0 = __builtin_amdgcn_readlane(digit, first);
+            if (__ballot(in && digit != c0) == 0ull) {
+                if ((tid & 63) == first) atomicAdd(&hist[c0], (uint32_t)__popcll(act));
+            } else if (in) {
+                atomicAdd(&hist[digit], 1u);
+            }
         }
         __syncthreads();
-        if (tid == 0) {
-            int run = 0;
-            for (int i = 0; i < 256; ++i) {
-                const int c = (int)hist[i];
-                if (run < remaining && remaining <= run + c) { redi[32] = i; redi[33] = remaining - run; break; }
-                run += c;
+        if (tid < 64) {                                                   // one wave scans the 256 counts
+            int c[4], sum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c[i] = (int)hist[tid * 4 + i]; sum += c[i]; }
+            const int incl = wave_inclusive_sum(sum);
+            int run = incl - sum;
+            if (run < remaining && remaining <= incl) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    if (run < remaining && remaining <= run + c[i]) { redi[32] = tid * 4 + i; redi[33] = remaining - run; }
+                    run += c[i];
+                }
             }
         }
         __syncthreads();
@@ -159,6 +179,8 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     int* const cnt = (int*)(smem + W.o_cnt);
     uint16_t* const clist = (uint16_t*)(smem + W.o_clist);
     uint16_t* const redo_list = (uint16_t*)(smem + W.o_redo);       // borders that outgrew a tracing lane's slot
+    uint16_t* const lut = (uint16_t*)(smem + W.o_lut);
+    uint16_t* const imglist = (uint16_t*)(smem + W.o_imglist);
     double* const hm = (double*)(smem + W.o_hm);
     uint8_t* const lev = smem + W.o_lev;
     unsigned long long* const skl = (unsigned long long*)(smem + W.o_skl);
@@ -232,7 +254,22 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
         const ShapeRot* sp = (const ShapeRot*)srw + r;
         const int s_ax = sp->ax, s_ay = sp->ay, nb = sp->nb, has_out = sp->has_out;
         const double ext_z_r = sp->ext_z_r;
+        // the rotation's masked-in bottom cells, staged in LDS (the candidate keys' bytes, idle until the observation is emitted)
+        // as (bottom height, offset of the cell in the row-major tile): every thread walks the same list
         const Cell* cells = T.bcell + sp->ob;
+        typedef double cell_pair __attribute__((ext_vector_type(2)));
+        cell_pair* const lc = (cell_pair*)keys;
+        const int lcap = ((R * AC + P.S) * 4) / 16;
+        __syncthreads();
+        for (int e = tid; e < nb && e < lcap; e += BLOCK) {
+            const Cell ce = cells[e];
+            cell_pair v;
+            v.x = ce.v;
+            v.y = __hiloint2double(0, (ce.ij & 0xFFFF) * P.Hy + (ce.ij >> 16));
+            lc[e] = v;
+        }
+        __syncthreads();
+        const int nl = nb < lcap ? nb : lcap;
         for (int c0 = 0; c0 < AC; c0 += BLOCK) {                         // (uniform trip count: np_floor_divide_int votes)
             const int c = c0 + tid;
             const int X = fdiv(c, Ay, P.mg_ay), Y = c - X * Ay;
@@ -240,7 +277,22 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
             double m = has_out ? 0.0 : -1e300;
             if (in_range) {
                 const double* h0 = hm + (X * P.step) * P.Hy + Y * P.step;
-                for (int e = 0; e < nb; ++e) {
+                int e = 0;
+                for (; e + 4 <= nl; e += 4) {
+                    cell_pair q[4];
+                    double hv[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[k] = lc[e + k];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) hv[k] = h0[__double2loint(q[k].y)];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m = fmax(m, hv[k] - q[k].x);
+                }
+                for (; e < nl; ++e) {
+                    const cell_pair q = lc[e];
+                    m = fmax(m, h0[__double2loint(q.y)] - q.x);
+                }
+                for (e = nl; e < nb; ++e) {                                // (a list beyond the staging bytes: from global memory)
                     const Cell ce = cells[e];
                     m = fmax(m, h0[(ce.ij & 0xFFFF) * P.Hy + (ce.ij >> 16)] - ce.v);
                 }
@@ -272,72 +324,92 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     }
     __syncthreads();
 
-    // ---- getConvexHullActions (cvTools.py:61-102): one level image after the other
+    // ---- getConvexHullActions (cvTools.py:61-102): the level images of all rotations, WIDE_IB at a time -- built as 32 rows of 32
+    // bits, their candidate starts listed together, one candidate per tracing lane (sixteen lanes per wave)
     const uint32_t wmask = Ay >= 32 ? 0xFFFFFFFFu : ((1u << Ay) - 1u);
-    const int tl = (lane < WIDE_TL / WAVES) ? (tid >> 6) * (WIDE_TL / WAVES) + lane : -1;      // tracing lanes: four per wave
-    uint8_t* const tbase = smem + W.o_trace + (tl >= 0 ? tl : 0) * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
+    const int tl = (lane < WIDE_TL / WAVES) ? (tid >> 6) * (WIDE_TL / WAVES) + lane : -1;
+    uint8_t* const tbase = smem + W.o_trace + (tl >= 0 ? tl : 0) * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);   // (the tile is done with)
     uint16_t* const tpts = (uint16_t*)tbase;
     uint16_t* const tdst = tpts + WIDE_LCAP;
     uint32_t* const tstk = (uint32_t*)(tdst + WIDE_LCAP);
     uint8_t* const big = S.w_big + (size_t)b * WIDE_BIG_BYTES;
-    for (int r = 0; r < R; ++r) {
-        for (int half = 0; half < 2; ++half) {
-            uint32_t pm = present[r * 2 + half];
-            pm = (uint32_t)__builtin_amdgcn_readfirstlane((int)pm);
-            while (pm != 0u) {
-                const int code = half * 32 + __ffs((int)pm) - 1;
-                pm &= pm - 1u;
-                if (tid < 32) rows[tid] = 0u;
-                if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
-                __syncthreads();
-                for (int c = tid; c < AC; c += BLOCK)
-                    if (lev[r * AC + c] == code) {
+    for (int i = tid; i < R * 64; i += BLOCK) lut[i] = 0xFFFF;
+    __syncthreads();
+    if (tid == 0) {                                  // images in (rotation, level) order
+        int ni = 0;
+        for (int r = 0; r < R; ++r)
+            for (int half = 0; half < 2; ++half)
+                for (uint32_t pm = present[r * 2 + half]; pm != 0u; pm &= pm - 1u) {
+                    const int code = half * 32 + __ffs((int)pm) - 1;
+                    imglist[ni] = (uint16_t)((r << 8) | code);
+                    lut[r * 64 + code] = (uint16_t)ni;
+                    ++ni;
+                }
+        cnt[2] = ni;
+    }
+    __syncthreads();
+    const int nimg = cnt[2];
+    for (int base = 0; base < nimg; base += WIDE_IB) {
+        const int nbi = nimg - base < WIDE_IB ? nimg - base : WIDE_IB;
+        for (int i = tid; i < nbi * 32; i += BLOCK) rows[i] = 0u;
+        if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
+        __syncthreads();
+        for (int r = 0; r < R; ++r)
+            for (int c = tid; c < AC; c += BLOCK) {
+                const int code = lev[r * AC + c];
+                if (code != 255) {
+                    const int slot = (int)lut[r * 64 + code] - base;
+                    if (slot >= 0 && slot < nbi) {
                         const int X = fdiv(c, Ay, P.mg_ay), Y = c - X * Ay;
-                        atomicOr(&rows[X], 1u << Y);
-                    }
-                __syncthreads();
-                if (tid < Ax) {                                            // candidate starts of row tid
-                    uint32_t cand = start_candidates_wide(rows[tid], tid > 0 ? rows[tid - 1] : 0u, wmask);
-                    while (cand != 0u) {
-                        const int x = __ffs((int)cand) - 1;
-                        cand &= cand - 1u;
-                        const int at = atomicAdd(&cnt[0], 1);
-                        if (at < WIDE_CLIST) clist[at] = (uint16_t)(x | (tid << 5));
+                        atomicOr(&rows[slot * 32 + X], 1u << Y);
                     }
                 }
-                __syncthreads();
-                const int total = cnt[0] < WIDE_CLIST ? cnt[0] : WIDE_CLIST;
-                if (cnt[0] > WIDE_CLIST && tid == 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
-                if (tl >= 0)
-                    for (int ci = tl; ci < total; ci += WIDE_TL) {
-                        const int e = clist[ci], x0 = e & 31, y0 = e >> 5;
-                        const int n = trace_border_wide<5>(rows, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
-                        bool redo = false;
-                        if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
-                        else if (n > WIDE_LCAP) redo = true;
-                        else if (n > 0) redo = !approx_and_convex_t<uint16_t, 5>(tpts, n, tdst, tstk, WIDE_LCAP, vmask + r * VR);
-                        if (redo) {                                        // outgrew the slot: thread 0, in global scratch, below
-                            const int at = atomicAdd(&cnt[1], 1);
-                            if (at < 64) redo_list[at] = (uint16_t)e;
-                        }
-                    }
-                __syncthreads();
-                if (cnt[1] > 0 && tid == 0) {
-                    uint16_t* bp = (uint16_t*)big;
-                    uint16_t* bd = bp + WIDE_BIG;
-                    uint32_t* bs = (uint32_t*)(bd + WIDE_BIG);
-                    const int nredo = cnt[1] < 64 ? cnt[1] : 64;
-                    if (cnt[1] > 64) raise_error(S, IRBPP_DEVERR_CAPACITY);
-                    for (int k = 0; k < nredo; ++k) {
-                        const int e = redo_list[k];
-                        const int n = trace_border_wide<5>(rows, Ay, Ax, e & 31, e >> 5, bp, WIDE_BIG);
-                        if (n < 0 || n > WIDE_BIG || !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR))
-                            raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
-                    }
-                }
-                __syncthreads();
+            }
+        __syncthreads();
+        for (int i = tid; i < nbi * 32; i += BLOCK) {                      // candidate starts of row y of image `slot`
+            const int slot = i >> 5, y = i & 31;
+            if (y >= Ax) continue;
+            uint32_t cand = start_candidates_wide(rows[i], y > 0 ? rows[i - 1] : 0u, wmask);
+            while (cand != 0u) {
+                const int x = __ffs((int)cand) - 1;
+                cand &= cand - 1u;
+                const int at = atomicAdd(&cnt[0], 1);
+                if (at < WIDE_CLIST) clist[at] = (uint16_t)(x | (y << 5) | (slot << 10));
             }
         }
+        __syncthreads();
+        const int total = cnt[0] < WIDE_CLIST ? cnt[0] : WIDE_CLIST;
+        if (cnt[0] > WIDE_CLIST && tid == 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
+        if (tl >= 0)
+            for (int ci = tl; ci < total; ci += WIDE_TL) {
+                const int e = clist[ci], x0 = e & 31, y0 = (e >> 5) & 31, slot = e >> 10;
+                const int r = imglist[base + slot] >> 8;
+                const int n = trace_border_wide<5>(rows + slot * 32, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
+                bool redo = false;
+                if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+                else if (n > WIDE_LCAP) redo = true;
+                else if (n > 0) redo = !approx_and_convex_t<uint16_t, 5>(tpts, n, tdst, tstk, WIDE_LCAP, vmask + r * VR);
+                if (redo) {                                                // outgrew the slot: thread 0, in global scratch, below
+                    const int at = atomicAdd(&cnt[1], 1);
+                    if (at < 64) redo_list[at] = (uint16_t)e;
+                }
+            }
+        __syncthreads();
+        if (cnt[1] > 0 && tid == 0) {
+            uint16_t* bp = (uint16_t*)big;
+            uint16_t* bd = bp + WIDE_BIG;
+            uint32_t* bs = (uint32_t*)(bd + WIDE_BIG);
+            const int nredo = cnt[1] < 64 ? cnt[1] : 64;
+            if (cnt[1] > 64) raise_error(S, IRBPP_DEVERR_CAPACITY);
+            for (int k = 0; k < nredo; ++k) {
+                const int e = redo_list[k], slot = e >> 10;
+                const int r = imglist[base + slot] >> 8;
+                const int n = trace_border_wide<5>(rows + slot * 32, Ay, Ax, e & 31, (e >> 5) & 31, bp, WIDE_BIG);
+                if (n < 0 || n > WIDE_BIG || !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR))
+                    raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+            }
+        }
+        __syncthreads();
     }
 
     // ---- cur_observation's candidate block (binPhy.py:204-227): rows per rotation ordered by (col, row) (np.unique, cvTools.py:101)
