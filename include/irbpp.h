@@ -19,9 +19,10 @@
  *     handed over with irbpp_register_obs_buffer is kept complete by the library instead
  *     (same contents, fewer stores).
  *
- * Limits (irbpp_create returns IRBPP_ERR_ARG beyond them): action grid <= 16 x 16 cells,
- * heightmap <= 128 x 128 cells with resolutionA an integer multiple of resolutionH and the bin an
- * integer number of action cells; n_rot <= 8; selected <= 1024; buffer_size <= 16;
+ * Limits (irbpp_create returns IRBPP_ERR_ARG beyond them): action grid <= 32 x 32 cells (up to 16 x 16: the tuned pipeline;
+ * 17 .. 32 a side, e.g. resolutionA = 0.01: the capacity path of csrc/irbpp_wide.hip, one kernel per observation, heightmap
+ * <= 64 x 64 cells, no stability proxy, no stage-level tooling entry points), heightmap <= 128 x 128 cells with resolutionA an
+ * integer multiple of resolutionH and the bin an integer number of action cells; n_rot <= 8; selected <= 1024; buffer_size <= 16;
  * bin[2] / resolution_z <= 31 height levels (cvTools.py:78 codes a level in 6 bits: level + 32);
  * num_bins <= 1048576 per device.  Item ids are < 65536 in the placement log.
  */
