@@ -220,7 +220,7 @@ static void convex_hulls(orc_env *e, int r, unsigned char hit[MAXA][MAXA]) {
         const int h = levels[li];
         if (h == -1) continue;
         int img[MAXA + 2][MAXA + 2];
-        memset(img, 0, sizeof(img));
+        memset(img, 0, sizeof(img[0]) * (size_t)(e->Ax + 2));      /* rows 0 .. Ax + 1 of the padded image */
         for (int X = 0; X < e->Ax; ++X)
             for (int Y = 0; Y < e->Ay; ++Y) img[X + 1][Y + 1] = mapInt[X][Y] == h;
         int nbd = 1;
@@ -273,7 +273,7 @@ static void cur_observation(orc_env *e, int gen_item, double *obs) {
         int n = 0;
         for (int r = 0; r < e->R; ++r) {                          /* getConvexHullActions */
             unsigned char hit[MAXA][MAXA];
-            memset(hit, 0, sizeof(hit));
+            memset(hit, 0, sizeof(hit[0]) * (size_t)e->Ax);
             convex_hulls(e, r, hit);
             for (int col = 0; col < e->Ay; ++col)                 /* np.unique: sorted by (x = col, y = row) */
                 for (int row = 0; row < e->Ax; ++row)

@@ -18,15 +18,12 @@ for spec in sys.argv[1:]:
     shapes, seqs, kw = make_workload(wl)
     k = int(kw.get("bufferSize", 1))
     seqs = seqs[:2000]
-    # every C-oracle environment holds its own copy of the shape tables and the trajectories: bound what this asks of the
-    # host (session 39 took 4096 environments of the 64 x 64 data set, ~60 MB each, and with them the box)
-    per_env = 4 * 8 * sum(np.asarray(t[r][0]).size for t in shapes.tables for r in range(len(t))) + np.asarray(seqs).nbytes
-    if n * per_env > 32 << 30:
-        print(json.dumps({"spec": spec, "skipped": f"{n} oracle environments x {per_env >> 20} MB exceed the 32 GB this tool allows itself"}), flush=True)
-        continue
+    # (the C-oracle environments of one COracleVecEnv share ONE copy of the tables and trajectories since round 6 -- session 39 of
+    # round 5 took 4096 private copies of the 64 x 64 data set's 54 MB, and with them the box -- and step on host threads;
+    # tests/test_gpu_large_forms.py runs this comparison as -m gpu tests)
     genv = GpuVecEnv(shapes, seqs, n, device="cuda:0", num_groups=groups, **kw)
     genv.candidates_on_device = True
-    cenv = COracleVecEnv(n, shapes, seqs, **kw)
+    cenv = COracleVecEnv(n, shapes, seqs, threads=min(16, os.cpu_count() or 1), **kw)
     t0 = time.time()
     gobs = genv.reset()
     ok = np.array_equal(gobs.cpu().numpy(), cenv.reset().astype(np.float32))
