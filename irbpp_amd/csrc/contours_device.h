@@ -684,6 +684,73 @@ __device__ inline int trace_border_wide(const uint32_t* rows, int W, int H, int 
     return -1;
 }
 
+// The wide walk with RUN JUMPS (trace_step's logic on 32-bit lines): after a step in an axis direction the walk keeps going straight
+// while the three neighbours probed before that direction are background and the next pixel is foreground -- one bit scan on the
+// line walked and the line beside it (rows for E / W, the transposed copy `cols` for N / S; bit y of cols[x] = pixel (x, y)).
+// Same points as trace_border_wide (tests/host/: both against the oracle, and against each other).
+__device__ __forceinline__ uint32_t nb_mask3_wide(uint32_t a, uint32_t b, uint32_t c, int x) {
+    const unsigned long long ra = a, rb = b, rc = c;
+    const uint32_t ta = (uint32_t)(((ra << 1) >> x) & 7ull), tb = (uint32_t)(((rb << 1) >> x) & 7ull), tc = (uint32_t)(((rc << 1) >> x) & 7ull);
+    return (tb >> 2) | ((ta >> 2) << 1) | (((ta >> 1) & 1u) << 2) | ((ta & 1u) << 3) | ((tb & 1u) << 4) | ((tc & 1u) << 5) |
+           (((tc >> 1) & 1u) << 6) | ((tc >> 2) << 7);
+}
+__device__ __forceinline__ int run_forward_wide(uint32_t line, uint32_t side, int p) {      // towards higher bits
+    const uint32_t clear = ~(side | (side << 1) | (side >> 1));
+    const uint32_t m = (clear & (line >> 1)) >> p;
+    return __builtin_ctz(~m);                                                               // consecutive ones from bit p (bit 31 of line >> 1 is clear)
+}
+__device__ __forceinline__ int run_backward_wide(uint32_t line, uint32_t side, int p) {     // towards lower bits
+    const uint32_t clear = ~(side | (side << 1) | (side >> 1));
+    const uint32_t m = clear & (line << 1);
+    const uint32_t z = ~m & ((2u << p) - 1u);                                               // zero bits at or below p
+    return z ? p - (31 - __builtin_clz(z)) : p + 1;
+}
+template <int SHIFT>
+__device__ inline int trace_border_wide_runs(const uint32_t* rows, const uint32_t* cols, int W, int H, int x0, int y0, uint16_t* pts, int cap) {
+    uint32_t nb = nb_mask3_wide(y0 > 0 ? rows[y0 - 1] : 0u, rows[y0], y0 + 1 < H ? rows[y0 + 1] : 0u, x0);
+    const uint32_t rot = ((nb << 4) | (nb >> 4)) & 0xFFu;                  // clockwise from west: direction 3 -> bit 7
+    if (rot == 0u) {                                                       // isolated pixel
+        if (cap > 0) pts[0] = (uint16_t)(x0 | (y0 << SHIFT));
+        return 1;
+    }
+    const int s_first = (3 - (7 - (31 - __builtin_clz(rot)))) & 7;
+    const int x1 = x0 + dir_dx(s_first), y1 = y0 + dir_dy(s_first);
+    int x3 = x0, y3 = y0, cur_s = s_first, prev_s = s_first ^ 4, n = 0;
+    for (int guard = 0; guard < 8192; ++guard) {
+        IRBPP_TRACE_ITER();
+        const int k2 = (cur_s + 1) & 7;
+        const uint32_t r2 = ((nb >> k2) | (nb << (8 - k2))) & 0xFFu;       // direction k2 -> bit 0
+        const int s2 = (k2 + __builtin_ctz(r2)) & 7;
+        int x4 = x3 + dir_dx(s2), y4 = y3 + dir_dy(s2);
+        if (s2 != prev_s) {                                                // CHAIN_APPROX_SIMPLE
+            if (n < cap) pts[n] = (uint16_t)(x3 | (y3 << SHIFT));
+            ++n;
+        }
+        prev_s = s2;
+        if (x4 == x0 && y4 == y0 && x3 == x1 && y3 == y1) return n;
+        const bool vert = (s2 & 3) == 2, axis = (s2 & 1) == 0, fwd = s2 == 0 || s2 == 6;
+        const uint32_t* base = vert ? cols : rows;
+        const int nl = vert ? W : H;                                       // lines of that frame
+        const int li = vert ? x4 : y4;
+        int p = vert ? y4 : x4;
+        const uint32_t wm = base[li], wa = li > 0 ? base[li - 1] : 0u, wb = li + 1 < nl ? base[li + 1] : 0u;
+        if (axis) {
+            const uint32_t side = (vert != fwd) ? wb : wa;
+            p += fwd ? run_forward_wide(wm, side, p) : -run_backward_wide(wm, side, p);
+        }
+        x4 = vert ? x4 : p;
+        y4 = vert ? p : y4;
+        if (x4 == x0 && y4 == y0 && s2 == (s_first ^ 4)) return n;         // a run that ends on the start, against the first step
+        if (y4 * W + x4 < y0 * W + x0) return 0;                           // an earlier pixel of the component
+        const uint32_t nbl = nb_mask3_wide(wa, wm, wb, p);
+        x3 = x4;
+        y3 = y4;
+        cur_s = (s2 + 4) & 7;
+        nb = vert ? nb_untranspose(nbl) : nbl;
+    }
+    return -1;
+}
+
 // One outer border, serially: trace, approximate, mark convex vertices.  Returns 0 ok,
 // 1 capacity overflow (caller retries with a bigger slot), 2 iteration guard.
 __device__ inline int contour_vertices(const uint16_t* img, const uint16_t* imgT, int x0, int y0, const SlotMem& m,

@@ -40,7 +40,7 @@ __host__ __device__ inline WideLayout wide_layout(const Params& P) {
     int npad = 64;
     while (npad < P.S) npad <<= 1;
     w.o_hist = off;     off += align16(10 * npad > 1024 ? 10 * npad : 1024);  // radix counters, then the sort keys
-    w.o_rows = off;     off += WIDE_IB * 32 * 4;                               // a batch of level images: 32 rows of 32 bits each
+    w.o_rows = off;     off += 2 * WIDE_IB * 32 * 4;                           // a batch of level images: 32 rows of 32 bits each, then their transposed copies
     w.o_cnt = off;      off += 16;
     w.o_clist = off;    off += WIDE_CLIST * 2;
     w.o_redo = off;     off += 64 * 2;
@@ -176,6 +176,7 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     uint32_t* const keys = (uint32_t*)(smem + W.o_keys);
     uint32_t* const hist = (uint32_t*)(smem + W.o_hist);
     uint32_t* const rows = (uint32_t*)(smem + W.o_rows);
+    uint32_t* const cols = rows + WIDE_IB * 32;                       // [image][x]: bit y = pixel (x, y) (the vertical run jumps)
     int* const cnt = (int*)(smem + W.o_cnt);
     uint16_t* const clist = (uint16_t*)(smem + W.o_clist);
     uint16_t* const redo_list = (uint16_t*)(smem + W.o_redo);       // borders that outgrew a tracing lane's slot
@@ -198,6 +199,9 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     double* const ghm = S.hm + (size_t)b * P.Hc;
     int32_t* const q = S.queue + (size_t)b * P.K;
     float* const obs = io.obs ? io.obs + (size_t)(some ? slot : b) * io.obs_stride : nullptr;
+    stamp(io, b, 0);                                 // tooling (irbpp_debug_phase_cycles): 0 start, 1 tile staged, 2 overlap test done,
+                                                     // 3 contours done, 4 observation written; 5 / 6: cycles of image building / border following
+    long long t_img = 0, t_trace = 0;
 
     // ---- bookkeeping of the transition (env_transition's, binPhy.py:128-147, 161-169)
     if (mode == MODE_RESET) {
@@ -238,6 +242,7 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
         for (int i = tid; i < P.Hc; i += BLOCK) obs[P.K + i] = (float)hm[i];
         return;
     }
+    stamp(io, b, 1);
     int item = __builtin_amdgcn_readfirstlane(obs_item);
     if (item >= T.n_shapes) { if (tid == 0) raise_error(S, IRBPP_DEVERR_BAD_ITEM); item = -1; }
 
@@ -315,6 +320,7 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
         }
     }
     const int nvalid = block_sum_int(my_valid, redi);
+    stamp(io, b, 2);
     // the tile is done with after its float32 copy: item vector and heightmap of the observation (binPhy.py:196-203)
     if (tid < 9) obs[5 * P.S + tid] = tid == 0 ? (float)item : 0.0f;
     for (int i = tid; i < P.Hc; i += BLOCK) obs[5 * P.S + 9 + i] = (float)hm[i];
@@ -351,6 +357,7 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     const int nimg = cnt[2];
     for (int base = 0; base < nimg; base += WIDE_IB) {
         const int nbi = nimg - base < WIDE_IB ? nimg - base : WIDE_IB;
+        const long long t0 = io.phase_cycles ? (long long)clock64() : 0;
         for (int i = tid; i < nbi * 32; i += BLOCK) rows[i] = 0u;
         if (tid == 0) { cnt[0] = 0; cnt[1] = 0; }
         __syncthreads();
@@ -366,6 +373,13 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
                 }
             }
         __syncthreads();
+        for (int i = tid; i < nbi * 32; i += BLOCK) {                      // column word x of image `slot`
+            const uint32_t* im = rows + (i & ~31);
+            const int x = i & 31;
+            uint32_t cw = 0u;
+            for (int y = 0; y < Ax; ++y) cw |= ((im[y] >> x) & 1u) << y;
+            cols[i] = cw;
+        }
         for (int i = tid; i < nbi * 32; i += BLOCK) {                      // candidate starts of row y of image `slot`
             const int slot = i >> 5, y = i & 31;
             if (y >= Ax) continue;
@@ -380,11 +394,13 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
         __syncthreads();
         const int total = cnt[0] < WIDE_CLIST ? cnt[0] : WIDE_CLIST;
         if (cnt[0] > WIDE_CLIST && tid == 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
+        const long long t1 = io.phase_cycles ? (long long)clock64() : 0;
+        t_img += t1 - t0;
         if (tl >= 0)
             for (int ci = tl; ci < total; ci += WIDE_TL) {
                 const int e = clist[ci], x0 = e & 31, y0 = (e >> 5) & 31, slot = e >> 10;
                 const int r = imglist[base + slot] >> 8;
-                const int n = trace_border_wide<5>(rows + slot * 32, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
+                const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
                 bool redo = false;
                 if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
                 else if (n > WIDE_LCAP) redo = true;
@@ -404,12 +420,19 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
             for (int k = 0; k < nredo; ++k) {
                 const int e = redo_list[k], slot = e >> 10;
                 const int r = imglist[base + slot] >> 8;
-                const int n = trace_border_wide<5>(rows + slot * 32, Ay, Ax, e & 31, (e >> 5) & 31, bp, WIDE_BIG);
+                const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, e & 31, (e >> 5) & 31, bp, WIDE_BIG);
                 if (n < 0 || n > WIDE_BIG || !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR))
                     raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
             }
         }
         __syncthreads();
+        if (io.phase_cycles) t_trace += (long long)clock64() - t1;
+    }
+    stamp(io, b, 3);
+    if (io.phase_cycles && tid == 0) {
+        io.phase_cycles[(size_t)b * PHASE_ROW + 5] = t_img;
+        io.phase_cycles[(size_t)b * PHASE_ROW + 6] = t_trace;
+        io.phase_cycles[(size_t)b * PHASE_ROW + 7] = nimg;
     }
 
     // ---- cur_observation's candidate block (binPhy.py:204-227): rows per rotation ordered by (col, row) (np.unique, cvTools.py:101)
@@ -513,6 +536,7 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
             io.auto_action[b] = won == 0x7fffffff ? 0 : won;
         }
     }
+    stamp(io, b, 4);
     if (blockIdx.x == 0 && tid == 0 && io.err_out != nullptr) atomicOr(io.err_out, *S.err);
 }
 

@@ -138,6 +138,28 @@ int host_wide_image_vertices(const uint32_t* rows, int W, int H, int cap, int ca
     return borders;
 }
 
+// the wide walk with run jumps against the plain wide walk: every candidate start of the image, same return value and points.
+// Returns the number of starts compared, negative at the first difference.
+int host_wide_runs_equal_plain(const uint32_t* rows, int W, int H) {
+    static uint16_t pa[4096], pb[4096];
+    uint32_t cols[32];
+    for (int x = 0; x < 32; ++x) { cols[x] = 0; for (int y = 0; y < H; ++y) cols[x] |= ((rows[y] >> x) & 1u) << y; }
+    const uint32_t wmask = W >= 32 ? 0xFFFFFFFFu : ((1u << W) - 1u);
+    int compared = 0;
+    for (int y = 0; y < H; ++y) {
+        const uint32_t cand = start_candidates_wide(rows[y], y ? rows[y - 1] : 0u, wmask);
+        for (int x = 0; x < W; ++x) {
+            if (!((cand >> x) & 1u)) continue;
+            const int na = trace_border_wide<5>(rows, W, H, x, y, pa, 4096);
+            const int nb = trace_border_wide_runs<5>(rows, cols, W, H, x, y, pb, 4096);
+            if (na != nb) return -1 - compared;
+            for (int i = 0; i < na; ++i) if (pa[i] != pb[i]) return -100000 - compared;
+            ++compared;
+        }
+    }
+    return compared;
+}
+
 // approx_and_convex on a point list: vrows[16] gets the vertex bits; returns 1 ok, 0 stack overflow.
 int host_approx_and_convex(const uint8_t* pts, int count, int cap_stk, uint32_t* vrows) {
     static uint8_t dst[4096];

@@ -56,6 +56,8 @@ def host():
     lib.host_trace_border_fast_spill.restype = C.c_int
     lib.host_wide_image_vertices.argtypes = [u32p, C.c_int, C.c_int, C.c_int, C.c_int, u32p, u32p, C.POINTER(C.c_int)]
     lib.host_wide_image_vertices.restype = C.c_int
+    lib.host_wide_runs_equal_plain.argtypes = [u32p, C.c_int, C.c_int]
+    lib.host_wide_runs_equal_plain.restype = C.c_int
     lib.host_trace_border_walk.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
     lib.host_trace_border_walk.restype = C.c_int
     lib.host_trace_border_walk_spill.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int, C.c_int]
@@ -414,6 +416,7 @@ def test_wide_grid_routines_equal_the_oracle(host, W, H, seed):
         outer, _, _ = _oracle_outer(img)
         n = host.host_wide_image_vertices(rows, W, H, 4096, 4096, cand, vrows, C.byref(longest))
         assert n == len(outer)                                             # one border per component
+        assert host.host_wide_runs_equal_plain(rows, W, H) >= n            # the walk with run jumps: same points from every start
         starts = {(x, y) for y in range(H) for x in range(W) if (cand[y] >> x) & 1}
         assert {c[0] for c in outer} <= starts                              # every first pixel is listed
         want = set()
