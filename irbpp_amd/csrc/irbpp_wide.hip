@@ -380,52 +380,63 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
             for (int y = 0; y < Ax; ++y) cw |= ((im[y] >> x) & 1u) << y;
             cols[i] = cw;
         }
-        for (int i = tid; i < nbi * 32; i += BLOCK) {                      // candidate starts of row y of image `slot`
-            const int slot = i >> 5, y = i & 31;
-            if (y >= Ax) continue;
-            uint32_t cand = start_candidates_wide(rows[i], y > 0 ? rows[i - 1] : 0u, wmask);
-            while (cand != 0u) {
-                const int x = __ffs((int)cand) - 1;
-                cand &= cand - 1u;
-                const int at = atomicAdd(&cnt[0], 1);
-                if (at < WIDE_CLIST) clist[at] = (uint16_t)(x | (y << 5) | (slot << 10));
-            }
-        }
-        __syncthreads();
-        const int total = cnt[0] < WIDE_CLIST ? cnt[0] : WIDE_CLIST;
-        if (cnt[0] > WIDE_CLIST && tid == 0) raise_error(S, IRBPP_DEVERR_CAPACITY);
-        const long long t1 = io.phase_cycles ? (long long)clock64() : 0;
-        t_img += t1 - t0;
-        if (tl >= 0)
-            for (int ci = tl; ci < total; ci += WIDE_TL) {
-                const int e = clist[ci], x0 = e & 31, y0 = (e >> 5) & 31, slot = e >> 10;
-                const int r = imglist[base + slot] >> 8;
-                const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
-                bool redo = false;
-                if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
-                else if (n > WIDE_LCAP) redo = true;
-                else if (n > 0) redo = !approx_and_convex_t<uint16_t, 5>(tpts, n, tdst, tstk, WIDE_LCAP, vmask + r * VR);
-                if (redo) {                                                // outgrew the slot: thread 0, in global scratch, below
-                    const int at = atomicAdd(&cnt[1], 1);
-                    if (at < 64) redo_list[at] = (uint16_t)e;
+        // candidate starts, one list for the whole batch -- or, should a batch of speckle have more starts than the list holds, one
+        // image at a time (an image has at most 16 x 32 of them: every other pixel of a row)
+        long long t1 = 0;
+        int nsub = 1;
+        for (int sub = 0; sub < nsub; ++sub) {
+            if (sub > 0 || nsub > 1) { __syncthreads(); if (tid == 0) { cnt[0] = 0; cnt[1] = 0; } __syncthreads(); }
+            for (int i = tid; i < nbi * 32; i += BLOCK) {                  // candidate starts of row y of image `slot`
+                const int slot = i >> 5, y = i & 31;
+                if (y >= Ax || (nsub > 1 && slot != sub)) continue;
+                uint32_t cand = start_candidates_wide(rows[i], y > 0 ? rows[i - 1] : 0u, wmask);
+                while (cand != 0u) {
+                    const int x = __ffs((int)cand) - 1;
+                    cand &= cand - 1u;
+                    const int at = atomicAdd(&cnt[0], 1);
+                    if (at < WIDE_CLIST) clist[at] = (uint16_t)(x | (y << 5) | (slot << 10));
                 }
             }
-        __syncthreads();
-        if (cnt[1] > 0 && tid == 0) {
-            uint16_t* bp = (uint16_t*)big;
-            uint16_t* bd = bp + WIDE_BIG;
-            uint32_t* bs = (uint32_t*)(bd + WIDE_BIG);
-            const int nredo = cnt[1] < 64 ? cnt[1] : 64;
-            if (cnt[1] > 64) raise_error(S, IRBPP_DEVERR_CAPACITY);
-            for (int k = 0; k < nredo; ++k) {
-                const int e = redo_list[k], slot = e >> 10;
-                const int r = imglist[base + slot] >> 8;
-                const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, e & 31, (e >> 5) & 31, bp, WIDE_BIG);
-                if (n < 0 || n > WIDE_BIG || !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR))
-                    raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+            __syncthreads();
+            if (nsub == 1 && cnt[0] > WIDE_CLIST) {                        // (uniform) too many for one list: image by image
+                nsub = nbi;
+                sub = -1;
+                continue;
             }
+            const int total = cnt[0];
+            if (sub <= 0) { t1 = io.phase_cycles ? (long long)clock64() : 0; t_img += t1 - t0; }
+            if (tl >= 0)
+                for (int ci = tl; ci < total; ci += WIDE_TL) {
+                    const int e = clist[ci], x0 = e & 31, y0 = (e >> 5) & 31, slot = e >> 10;
+                    const int r = imglist[base + slot] >> 8;
+                    const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, x0, y0, tpts, WIDE_LCAP);
+                    bool redo = false;
+                    if (n < 0) raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+                    else if (n > WIDE_LCAP) redo = true;
+                    else if (n > 0) redo = !approx_and_convex_t<uint16_t, 5>(tpts, n, tdst, tstk, WIDE_LCAP, vmask + r * VR);
+                    if (redo) {                                            // outgrew the slot: thread 0, in global scratch, below
+                        const int at = atomicAdd(&cnt[1], 1);
+                        if (at < 64) redo_list[at] = (uint16_t)e;
+                    }
+                }
+            __syncthreads();
+            if (cnt[1] > 0 && tid == 0) {
+                uint16_t* bp = (uint16_t*)big;
+                uint16_t* bd = bp + WIDE_BIG;
+                uint32_t* bs = (uint32_t*)(bd + WIDE_BIG);
+                // (more long borders than the redo list holds: every candidate of the list once more -- marking a vertex twice is harmless)
+                const bool all = cnt[1] > 64;
+                const int nredo = all ? total : cnt[1];
+                for (int k = 0; k < nredo; ++k) {
+                    const int e = all ? clist[k] : redo_list[k], slot = e >> 10;
+                    const int r = imglist[base + slot] >> 8;
+                    const int n = trace_border_wide_runs<5>(rows + slot * 32, cols + slot * 32, Ay, Ax, e & 31, (e >> 5) & 31, bp, WIDE_BIG);
+                    if (n < 0 || n > WIDE_BIG || (n > 0 && !approx_and_convex_t<uint16_t, 5>(bp, n, bd, bs, WIDE_BIG, vmask + r * VR)))
+                        raise_error(S, IRBPP_DEVERR_TRACE_GUARD);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
         if (io.phase_cycles) t_trace += (long long)clock64() - t1;
     }
     stamp(io, b, 3);

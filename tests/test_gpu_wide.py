@@ -214,3 +214,66 @@ def test_wide_matches_the_reference_goldens(golden_dir, n):
         assert torch.equal(order, order_ref[t + 1].expand(n, -1)), t
     env.check_device_error()
     env.close()
+
+
+def test_wide_adversarial_level_images():
+    """Level images chosen at will on the 32 x 32 grid, dialled in through the heightmap of bins that observe a one-cell item:
+    checkerboard speckle over several levels (more candidate starts than the batch list holds: image by image), snakes whose borders
+    have 125 .. 629 points (beyond 128: the redo in global scratch), rings, random rectangles -- every location observation against the
+    C oracle (S = 1000: up to the > S selection over thousands of candidates)."""
+    from irbpp_amd.shapes import ShapeSet
+    from irbpp_amd.synthetic import _box_tables
+    ext = np.array([0.01, 0.01, 0.01])
+    sh = ShapeSet(np.array([[ext] * 2]), np.array([1e-6]), [[_box_tables(ext, 0.01) for _ in range(2)]], name="unit1")
+    seqs = np.zeros((8, 40), dtype=np.int32)
+    n, k, SW = 6, 2, 1000
+    kw = dict(resolutionA=0.01, resolutionH=0.01, bufferSize=k, selectedAction=SW)
+    genv = GpuVecEnv(sh, seqs, n, device=DEV, **kw)
+    genv.candidates_on_device = True
+    cenv = COracleVecEnv(n, sh, seqs, **kw)
+    np.testing.assert_array_equal(genv.reset().cpu().numpy(), _f32(cenv.reset()))
+    rng = np.random.RandomState(5)
+
+    def snake(zigzags):                                                      # one component whose border turns at every pixel: 62 points per zigzag row
+        img = np.zeros((32, 32), dtype=bool)
+        for j, y0 in enumerate((0, 3, 6, 9, 12, 15, 18, 21, 24, 27)[:zigzags]):
+            for x in range(32):
+                img[y0 + (x & 1), x] = True
+            if j < zigzags - 1:
+                xe = 31 if j % 2 == 0 else 0
+                img[y0 + 1:y0 + 4, xe] = True
+        return img
+    many = 0
+    for t in range(10):
+        hm = np.zeros((n, 32, 32))
+        for i in range(n):
+            kind = (t + i) % 5
+            if kind == 0:                                                    # speckle over five levels: thousands of starts
+                lv = rng.randint(0, 5, size=(32, 32)) * 0.02 + ((np.add.outer(np.arange(32), np.arange(32)) & 1) * 0.1)
+                many += 1
+            elif kind == 1:
+                z = (2, 3, 6, 10)[(t // 2) % 4]                               # 125 (in the lane's slot), 188, 377, 629 points (redone in global scratch)
+                lv = np.where(snake(z) if t % 2 else snake(z).T, 0.05, 0.12)
+            elif kind == 2:
+                g = np.maximum(np.abs(np.arange(32)[:, None] - 15.5), np.abs(np.arange(32)[None, :] - 15.5))
+                lv = np.where((np.floor(g) % 2 == 0) ^ (rng.rand(32, 32) < 0.02), 0.03, 0.09)
+            elif kind == 3:
+                lv = np.kron(rng.randint(0, 6, size=(8, 8)), np.ones((4, 4))) * 0.03
+            else:
+                lv = np.where(rng.rand(32, 32) < rng.uniform(0.3, 0.7), 0.04, 0.10)
+            hm[i] = lv
+        genv.env.set_heightmaps(torch.from_numpy(hm).to(DEV))
+        for i in range(n):
+            cenv.envs[i].set_heightmap(hm[i])
+        oa = np.array([t % k] * n)
+        gloc = genv.get_action_candidates(oa).cpu().numpy()
+        cloc = _f32(cenv.get_action_candidates(oa))
+        np.testing.assert_array_equal(gloc, cloc, err_msg=f"round {t}")
+        act = np.array([minz_action(c, SW) for c in cloc])
+        gord, _, gdone, _ = genv.step(act)
+        cord, _, cdone, _ = cenv.step(act)
+        np.testing.assert_array_equal(gord.cpu().numpy(), _f32(cord))
+        np.testing.assert_array_equal(gdone, cdone)
+    assert many >= 8
+    genv.env.check_device_error()
+    genv.close()
