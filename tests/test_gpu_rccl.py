@@ -34,8 +34,12 @@ dist.destroy_process_group()
 
 
 def _env():
+    import socket
+    with socket.socket() as sk:                      # a port nobody holds right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     env = dict(os.environ)
-    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    env.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return env
 
@@ -54,7 +58,6 @@ def test_collectives_run_through_a_single_rank_rccl_communicator():
 
 def test_bench_timed_loop_under_a_forced_rccl_process_group():
     env = _env()
-    env["MASTER_PORT"] = "29542"
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-process-group", "--no-extra", "--no-cpu-baseline",
                           "--bins", "2048", "--prefill", "20", "--warmup", "5", "--steps", "10", "--min-seconds", "0.2"],
                          env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
