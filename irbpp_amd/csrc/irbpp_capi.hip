@@ -245,7 +245,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
     ALLOC(w_img, P.wide ? 16 : N * P.wimg * 16);
     ALLOC(w_imgrot, P.wide ? 16 : N * P.wimg);
     ALLOC(w_cand, (size_t)NXCD * P.seg_cap);
-    ALLOC(w_big, P.wide ? N * WIDE_BIG_BYTES : (size_t)trace_grid_cap(P.N) * TRACE_WAVE_BYTES);   // one scratch per wave of the trace grid (wide: per bin)
+    ALLOC(w_big, P.wide ? N * wide_scratch_bytes(P) : (size_t)trace_grid_cap(P.N) * TRACE_WAVE_BYTES);   // one scratch per wave of the trace grid (wide: per bin)
     ALLOC(w_total, NXCD * XCD_STRIDE);
     ALLOC(w_nround, NXCD * XCD_STRIDE);
     ALLOC(w_round, (size_t)NXCD * P.round_cap * ROUND_BYTES);

@@ -18,12 +18,19 @@
 namespace irbpp {
 
 constexpr int WIDE_VROW = 32;                     // words per rotation of w_valid / vertex bits on a wide grid
-constexpr int WIDE_TL = 64;                       // lanes of a workgroup that follow borders (sixteen per wave)
-constexpr int WIDE_LCAP = 128;                    // contour points a tracing lane holds in LDS; longer borders: thread 0, global scratch
-constexpr int WIDE_IB = 64;                       // level images built and followed at a time
+// (sized so that TWO workgroups share a CU's LDS at four rotations -- two waves per SIMD instead of one: the whole kernel is a chain
+// of dependent latencies -- profiles/r06/LOG.md s16)
+constexpr int WIDE_TL = 32;                       // lanes of a workgroup that follow borders (eight per wave)
+constexpr int WIDE_LCAP = 96;                     // contour points a tracing lane holds in LDS; longer borders: thread 0, global scratch
+constexpr int WIDE_IB = 32;                       // level images built and followed at a time
 constexpr int WIDE_BIG = 4096;                    // ... of this many points
 constexpr int WIDE_BIG_BYTES = WIDE_BIG * (2 + 2 + 4);
-constexpr int WIDE_CLIST = 2048;                  // candidate starts of a batch of images: image in batch << 10 | y0 << 5 | x0
+// global scratch of a bin: the redo's points / polygon / stack, later the sortable images of the > S selection's values (8 bytes per cell)
+__host__ __device__ inline size_t wide_scratch_bytes(const Params& P) {
+    const size_t sel = (size_t)P.R * P.AC * 8;
+    return sel > (size_t)WIDE_BIG_BYTES ? sel : (size_t)WIDE_BIG_BYTES;
+}
+constexpr int WIDE_CLIST = 1024;                  // candidate starts of a batch of images: image in batch << 10 | y0 << 5 | x0
 
 struct WideLayout {
     int o_sr, o_present, o_vmask, o_vbits, o_red, o_keys, o_hist, o_rows, o_cnt, o_clist, o_redo, o_lut, o_imglist, o_lev, o_over, o_hm, o_trace, o_skl, bytes;
@@ -48,12 +55,12 @@ __host__ __device__ inline WideLayout wide_layout(const Params& P) {
     w.o_imglist = off;  off += align16(P.R * 64 * 2);                          // image number -> rotation << 8 | level code
     w.o_lev = off;      off += align16(P.R * P.AC);
     w.o_over = off;                                                            // three phases share the bytes from here on
-    // phase 1: the heightmap tile; phase 2: the tracing lanes' slots; phase 3: the sortable images of the keys' values
+    // phase 1: the heightmap tile; phase 2: the tracing lanes' slots (phase 3's sortable images of the keys' values: global scratch)
     const int a = off + align16(P.Hc * 8);
     const int t = off + WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
-    const int c = off + align16(P.R * P.AC * 8);
-    w.o_hm = w.o_trace = w.o_skl = off;
-    w.bytes = a > c ? (a > t ? a : t) : (c > t ? c : t);
+    w.o_hm = w.o_trace = off;
+    w.o_skl = 0;
+    w.bytes = a > t ? a : t;
     return w;
 }
 
@@ -69,7 +76,9 @@ __device__ inline void wide_select(const Params& P, const double* zsrc, const ui
         return zsrc[r * P.AC + x * P.Ay + y];
     };
     for (int e = tid; e < n; e += BLOCK) skl[e] = sortable_f64(value(key(e)));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                // (skl lies in global scratch: stored by one thread, read by others)
     __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     unsigned long long prefix = 0ull;
     int remaining = want;
     for (int d = 7; d >= 0; --d) {                                       // the want-th smallest value, a byte per round from the top
@@ -184,7 +193,6 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     uint16_t* const imglist = (uint16_t*)(smem + W.o_imglist);
     double* const hm = (double*)(smem + W.o_hm);
     uint8_t* const lev = smem + W.o_lev;
-    unsigned long long* const skl = (unsigned long long*)(smem + W.o_skl);
     const int tid = threadIdx.x, lane = tid & 63;
     const int R = P.R, AC = P.AC, Ax = P.Ax, Ay = P.Ay;
     constexpr int VR = WIDE_VROW;
@@ -338,7 +346,8 @@ irbpp_wide_kernel(const Params P, const Tables T, const State S, const StepIO io
     uint16_t* const tpts = (uint16_t*)tbase;
     uint16_t* const tdst = tpts + WIDE_LCAP;
     uint32_t* const tstk = (uint32_t*)(tdst + WIDE_LCAP);
-    uint8_t* const big = S.w_big + (size_t)b * WIDE_BIG_BYTES;
+    uint8_t* const big = S.w_big + (size_t)b * wide_scratch_bytes(P);
+    unsigned long long* const skl = (unsigned long long*)big;       // (the > S selection's sortable values: the same global scratch, later)
     for (int i = tid; i < R * 64; i += BLOCK) lut[i] = 0xFFFF;
     __syncthreads();
     if (tid == 0) {                                  // images in (rotation, level) order
