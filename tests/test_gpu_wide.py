@@ -277,3 +277,44 @@ def test_wide_adversarial_level_images():
     assert many >= 8
     genv.env.check_device_error()
     genv.close()
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_wide_make_vec_envs_with_item_streams(k):
+    """make_vec_envs(args) with args.resolutionA = 0.01 and nothing but the reference's namespace: the wide kernel's reset /
+    observe bookkeeping on per-bin item rings (IRcreator.py:26-72 streams, a ring of 32 items that the feeder refills), against the
+    numpy oracle on numpy's own RandomState."""
+    import types
+    from irbpp_amd.vec_env import make_vec_envs
+    from oracle.packing import RandomStreamItemCreator
+    sh = synthetic.blockout_shapes(n_shapes=20, n_rot=4, cube=0.06, seed=7)
+    dic = {i: "%s_%d.obj" % (["tee", "ell", "bar", "zig"][i % 4], i // 4) for i in range(20)}
+    n, seed = 4, 99
+    args = types.SimpleNamespace(
+        num_processes=n, device=0, seed=seed, shapes=sh, dicPath=dic, dataSample="instance", resolutionA=0.01,
+        resolutionH=0.01, resolutionZ=0.01, bin_dimension=np.round([0.32, 0.32, 0.30], 6), selectedAction=S,
+        bufferSize=k, scale=[100, 100, 100], evaluate=False, item_ring=32)
+    envs, spaces, obs_len = make_vec_envs(args, "./logs/runinfo", True)
+    assert "irbpp_wide_kernel alone" in envs.env.kernel_info()[1]
+    envs.candidates_on_device = True
+    creators = [RandomStreamItemCreator(seed + i, dic, "instance", n_items=20) for i in range(n)]
+    oenv = OracleVecEnv(n, sh, None, item_creators=creators, bufferSize=k, resolutionA=0.01)
+    gobs, oobs = envs.reset(), _f32(oenv.reset())
+    np.testing.assert_array_equal(gobs.cpu().numpy(), oobs)
+    written0 = envs.feeder.written.copy()
+    for t in range(45):
+        if k > 1:
+            order = (np.arange(n) + t) % k
+            oloc = _f32(oenv.get_action_candidates(order))
+            np.testing.assert_array_equal(envs.get_action_candidates(order).cpu().numpy(), oloc)
+        else:
+            oloc = oobs
+        act = np.array([minz_action(o, S) for o in oloc])
+        gobs, grew, gdone, _ = envs.step(act)
+        oobs, orew, odone, _ = oenv.step(act)
+        oobs = _f32(oobs)
+        np.testing.assert_array_equal(gobs.cpu().numpy(), oobs, err_msg=f"step {t}")
+        np.testing.assert_array_equal(gdone, odone)
+    assert int((envs.feeder.written - written0).min()) > 0                  # the rings were refilled
+    envs.env.check_device_error()
+    envs.close()
