@@ -36,6 +36,10 @@ struct WideLayout {
     int o_sr, o_present, o_vmask, o_vbits, o_red, o_keys, o_hist, o_rows, o_cnt, o_clist, o_redo, o_lut, o_imglist, o_lev, o_over, o_hm, o_trace, o_skl, bytes;
 };
 __host__ __device__ inline WideLayout wide_layout(const Params& P) {
+    // Three phases share most of the bytes (a workgroup of four rotations needs 49 KB: three per CU):
+    //   region K: phase 1 the footprint's staged cells, phase 2 the batch of level images + their transposed copies, the candidate
+    //             list and the image tables, phase 3 the candidate keys [R*AC] and the selected keys [S]
+    //   region T: phase 1 the heightmap tile, phase 2 the tracing lanes' slots, phase 3 the radix counters / sort keys
     WideLayout w{};
     int off = 0;
     w.o_sr = off;       off += align16(P.R * (int)sizeof(ShapeRot));
@@ -43,24 +47,28 @@ __host__ __device__ inline WideLayout wide_layout(const Params& P) {
     w.o_vmask = off;    off += align16(P.R * WIDE_VROW * 4);
     w.o_vbits = off;    off += align16(P.R * WIDE_VROW * 4);
     w.o_red = off;      off += 512;
-    w.o_keys = off;     off += align16((P.R * P.AC + P.S) * 4 + 64);          // candidate keys [R*AC], selected keys [S]
+    w.o_cnt = off;      off += 16;
+    w.o_redo = off;     off += 64 * 2;
+    w.o_lev = off;      off += align16(P.R * P.AC);
+    // region K
+    const int k0 = off;
+    w.o_keys = k0;
+    int k2 = k0;
+    w.o_rows = k2;      k2 += 2 * WIDE_IB * 32 * 4;
+    w.o_clist = k2;     k2 += WIDE_CLIST * 2;
+    w.o_lut = k2;       k2 += align16(P.R * 64 * 2);
+    w.o_imglist = k2;   k2 += align16(P.R * 64 * 2);
+    const int k3 = k0 + align16((P.R * P.AC + P.S) * 4 + 64);
+    off = k2 > k3 ? k2 : k3;
+    // region T
+    w.o_over = off;
+    w.o_hm = w.o_trace = w.o_hist = off;
+    w.o_skl = 0;                                                               // (global scratch)
     int npad = 64;
     while (npad < P.S) npad <<= 1;
-    w.o_hist = off;     off += align16(10 * npad > 1024 ? 10 * npad : 1024);  // radix counters, then the sort keys
-    w.o_rows = off;     off += 2 * WIDE_IB * 32 * 4;                           // a batch of level images: 32 rows of 32 bits each, then their transposed copies
-    w.o_cnt = off;      off += 16;
-    w.o_clist = off;    off += WIDE_CLIST * 2;
-    w.o_redo = off;     off += 64 * 2;
-    w.o_lut = off;      off += align16(P.R * 64 * 2);                          // (rotation, level code) -> image number
-    w.o_imglist = off;  off += align16(P.R * 64 * 2);                          // image number -> rotation << 8 | level code
-    w.o_lev = off;      off += align16(P.R * P.AC);
-    w.o_over = off;                                                            // three phases share the bytes from here on
-    // phase 1: the heightmap tile; phase 2: the tracing lanes' slots (phase 3's sortable images of the keys' values: global scratch)
-    const int a = off + align16(P.Hc * 8);
-    const int t = off + WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4);
-    w.o_hm = w.o_trace = off;
-    w.o_skl = 0;
-    w.bytes = a > t ? a : t;
+    const int t1 = align16(P.Hc * 8), t2 = WIDE_TL * (WIDE_LCAP * 2 * 2 + WIDE_LCAP * 4), t3 = align16(10 * npad > 1024 ? 10 * npad : 1024);
+    off += t1 > t2 ? (t1 > t3 ? t1 : t3) : (t2 > t3 ? t2 : t3);
+    w.bytes = off;
     return w;
 }
 
