@@ -248,7 +248,16 @@ __device__ inline int trace_border(const uint16_t* img, const uint16_t* imgT, in
 //     wave -- which walk different borders in lockstep -- run straight-line code.
 // ~85 instructions per step where trace_step compiles to ~160 (disassembly of the trace kernel).
 // ---------------------------------------------------------------------------------------
+#ifndef IRBPP_COMPACT_FRAMES
+#define IRBPP_COMPACT_FRAMES 0      // 1 (A/B, tools/build_variant.sh): lines as 16-bit halfwords, two per dword -- 76 instead of 140 bytes of LDS per lane
+#endif
+#if IRBPP_COMPACT_FRAMES
+// halfword h of the frame: 0 a zero line, 1 + y row y, 17 a zero line, 18 + x column x, 34 / 35 zero: the three lines around row y are
+// halfwords y .. y + 2, around column x halfwords 17 + x .. 19 + x; raw 16-bit lines (the walk shifts them left by one bit after the read)
+constexpr int FRAME_LINES = 18, FRAME_COLS = 17, FRAME_WORDS = 19;          // 18 dwords of lines + 1: an odd stride between the lanes' frames
+#else
 constexpr int FRAME_LINES = 18, FRAME_COLS = FRAME_LINES - 1, FRAME_WORDS = 2 * FRAME_LINES - 1;   // (the zero line behind the rows is the one before the columns)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t byte_table(uint32_t hi, uint32_t lo, uint32_t sel) { return __builtin_amdgcn_perm(hi, lo, sel); }
 #else
@@ -263,11 +272,49 @@ __device__ inline uint32_t byte_table(uint32_t hi, uint32_t lo, uint32_t sel) { 
 }
 #endif
 // frames of one level image from its row words r[y] (bit x = pixel (x, y)) and column words c[x] (bit y)
+#if IRBPP_COMPACT_FRAMES
+__device__ __forceinline__ void frames_store(uint32_t* fr, const uint32_t (&r)[16], const uint32_t (&c)[16]) {
+    fr[0] = r[0] << 16;                                                        // halfwords 0 (zero), 1 (row 0)
+#pragma unroll
+    for (int k = 1; k < 8; ++k) fr[k] = r[2 * k - 1] | (r[2 * k] << 16);       // halfwords 2k, 2k + 1 = rows 2k - 1, 2k
+    fr[8] = r[15];                                                             // halfwords 16 (row 15), 17 (zero)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) fr[9 + k] = c[2 * k] | (c[2 * k + 1] << 16);   // halfwords 18 + 2k, 19 + 2k = columns 2k, 2k + 1
+    fr[17] = 0u;                                                               // halfwords 34, 35
+}
+// the three lines around line `li` of the frame that starts at halfword `hoff` (0 rows, 17 columns), shifted left by one bit like the
+// stored lines of the wide-frame layout: bit q + 1 = pixel q
+__device__ __forceinline__ void frame_lines(const uint32_t* fr, uint32_t li, uint32_t hoff, uint32_t& wa, uint32_t& wm, uint32_t& wb) {
+    const uint32_t h0 = li + hoff, sh = (h0 & 1u) << 4;
+    const uint32_t* p = fr + (h0 >> 1);
+    const uint32_t d0 = p[0], d1 = p[1];
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t x = __builtin_amdgcn_alignbit(d1, d0, sh);
+#else
+    const uint32_t x = (uint32_t)(((((unsigned long long)d1) << 32) | d0) >> sh);
+#endif
+    wa = (x << 1) & 0x1FFFEu;
+    wm = (x >> 15) & 0x1FFFEu;
+    wb = ((d1 >> sh) << 1) & 0x1FFFEu;
+}
+__device__ __forceinline__ uint32_t frame_raw_row(const uint32_t* fr, int y) { return (fr[(1 + y) >> 1] >> (((1 + y) & 1) * 16)) & 0xFFFFu; }
+__device__ __forceinline__ uint32_t frame_raw_col(const uint32_t* fr, int x) { return (fr[(18 + x) >> 1] >> (((18 + x) & 1) * 16)) & 0xFFFFu; }
+constexpr uint32_t FRAME_COL_OFF = 17u;                                        // what the per-direction table adds to the line index for N / S
+#else
 __device__ __forceinline__ void frames_store(uint32_t* fr, const uint32_t (&r)[16], const uint32_t (&c)[16]) {
     fr[0] = 0u; fr[FRAME_LINES - 1] = 0u; fr[FRAME_COLS] = 0u; fr[FRAME_WORDS - 1] = 0u;
 #pragma unroll
     for (int k = 0; k < 16; ++k) { fr[1 + k] = r[k] << 1; fr[FRAME_COLS + 1 + k] = c[k] << 1; }
 }
+// the three lines around line `li` of the frame at byte offset `boff`
+__device__ __forceinline__ void frame_lines(const uint32_t* fr, uint32_t li, uint32_t boff, uint32_t& wa, uint32_t& wm, uint32_t& wb) {
+    const uint32_t* ln = (const uint32_t*)((const char*)fr + ((li << 2) + boff));
+    wa = ln[0]; wm = ln[1]; wb = ln[2];
+}
+__device__ __forceinline__ uint32_t frame_raw_row(const uint32_t* fr, int y) { return fr[1 + y] >> 1; }
+__device__ __forceinline__ uint32_t frame_raw_col(const uint32_t* fr, int x) { return fr[FRAME_COLS + 1 + x] >> 1; }
+constexpr uint32_t FRAME_COL_OFF = 4u * FRAME_COLS;                            // (a byte offset here)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ uint32_t bit_field(uint32_t v, uint32_t off, uint32_t width) { return __builtin_amdgcn_ubfe(v, off, width); }   // v_bfe_u32
 // bit `bit` of v as a mask, 0 or ~0 (v_bfe_i32; as asm because the compiler otherwise rewrites mask-and-select as and + compare + cndmask)
@@ -309,7 +356,7 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
     uint32_t DELTA_LO = 0x00010212u, DELTA_HI = 0x22212010u;                // E +1, NE -15, N -16, NW -17 | W -1, SW +15, S +16, SE +17
     uint32_t FLAG_LO = 0x000b000du, FLAG_HI = 0x00070001u;                  // E 13, N 11 | W 1, S 7
     uint32_t LSH_LO = 0x04000404u, LSH_HI = LSH_LO;                         // N and S index columns (x = pos & 15), all others rows
-    uint32_t FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16, FOFF_HI = FOFF_LO; // N and S read the column frame (byte offset)
+    uint32_t FOFF_LO = FRAME_COL_OFF << 16, FOFF_HI = FOFF_LO;              // N and S read the column frame (byte / halfword offset)
     NbTables NT = nb_tables();
 #if defined(__HIP_DEVICE_COMPILE__)
     // opaque to the compiler from here on: the table words stay in the scalar registers they are in (see nb_frame)
@@ -322,7 +369,9 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
     constexpr uint32_t SEL = 0x0c0c0c00u;
     const int pos0 = x0 | (y0 << 4);
     // first neighbour: clockwise search 3, 2, 1, 0, 7, 6, 5 (the west pixel is background)
-    const uint32_t nb0 = nb_frame(fr[y0], fr[y0 + 1], fr[y0 + 2], x0);
+    uint32_t wa0, wm0, wb0;
+    frame_lines(fr, (uint32_t)y0, 0u, wa0, wm0, wb0);
+    const uint32_t nb0 = nb_frame(wa0, wm0, wb0, x0);
     const uint32_t rot = ((nb0 << 4) | (nb0 >> 4)) & 0xFFu;                // direction 3 -> bit 7
     const bool isolated = rot == 0u;
     const int s_first = (3 - (7 - (31 - __builtin_clz(rot | (isolated ? 1u : 0u))))) & 7;
@@ -349,8 +398,8 @@ __device__ inline int trace_border_fast(const uint32_t* fr, int x0, int y0, uint
         const uint32_t lsh = byte_table(LSH_HI, LSH_LO, s2), psh = lsh ^ 4u;
         const uint32_t li = bit_field((uint32_t)pos4, lsh, 4);
         int p = (int)bit_field((uint32_t)pos4, psh, 4);
-        const uint32_t* ln = (const uint32_t*)((const char*)fr + ((li << 2) + byte_table(FOFF_HI, FOFF_LO, s2)));
-        const uint32_t wa = ln[0], wm = ln[1], wb = ln[2];
+        uint32_t wa, wm, wb;
+        frame_lines(fr, li, byte_table(FOFF_HI, FOFF_LO, s2), wa, wm, wb);
         {
             // straight run (see run_forward / run_backward): E looks at the row below, W at the row above, S at the
             // column to the left, N at the column to the right.  Stored lines are shifted by one: bit q + 1 = pixel q.
@@ -393,7 +442,7 @@ struct Walk {
 #define IRBPP_WALK_TABLES(WT)                                                                                               \
     WalkTables WT;                                                                                                          \
     WT.DELTA_LO = 0x00010212u; WT.DELTA_HI = 0x22212010u; WT.FLAG_LO = 0x000b000du; WT.FLAG_HI = 0x00070001u;               \
-    WT.LSH_LO = 0x04000404u; WT.FOFF_LO = (uint32_t)(4 * FRAME_COLS) << 16; WT.NT = nb_tables();                            \
+    WT.LSH_LO = 0x04000404u; WT.FOFF_LO = FRAME_COL_OFF << 16; WT.NT = nb_tables();                            \
     IRBPP_WALK_PIN(WT)                                                                                                      \
     WT.LSH_HI = WT.LSH_LO; WT.FOFF_HI = WT.FOFF_LO;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -408,7 +457,9 @@ struct Walk {
 __device__ __forceinline__ void walk_start(Walk& w, const uint32_t* fr, int x0, int y0, uint8_t* pts, int cap, bool active, const WalkTables& T) {
     constexpr uint32_t SEL = 0x0c0c0c00u;
     const int pos0 = x0 | (y0 << 4);
-    const uint32_t nb0 = nb_frame(fr[y0], fr[y0 + 1], fr[y0 + 2], x0, T.NT);
+    uint32_t wa0, wm0, wb0;
+    frame_lines(fr, (uint32_t)y0, 0u, wa0, wm0, wb0);
+    const uint32_t nb0 = nb_frame(wa0, wm0, wb0, x0, T.NT);
     const uint32_t rot = ((nb0 << 4) | (nb0 >> 4)) & 0xFFu;                // direction 3 -> bit 7
     const bool isolated = rot == 0u;
     const int s_first = (3 - (7 - (31 - __builtin_clz(rot | (isolated ? 1u : 0u))))) & 7;
@@ -441,8 +492,8 @@ __device__ __forceinline__ void walk_iter(Walk& w, const uint32_t* fr, uint8_t* 
     const uint32_t lsh = byte_table(T.LSH_HI, T.LSH_LO, s2), psh = lsh ^ 4u;
     const uint32_t li = bit_field((uint32_t)pos4, lsh, 4);
     int p = (int)bit_field((uint32_t)pos4, psh, 4);
-    const uint32_t* ln = (const uint32_t*)((const char*)fr + ((li << 2) + byte_table(T.FOFF_HI, T.FOFF_LO, s2)));
-    const uint32_t wa = ln[0], wm = ln[1], wb = ln[2];
+    uint32_t wa, wm, wb;
+    frame_lines(fr, li, byte_table(T.FOFF_HI, T.FOFF_LO, s2), wa, wm, wb);
     {
         const uint32_t side = bit_select(bit_flag<3>(flags), wb, wa);
         const uint32_t blocked = side | (side << 1) | (side >> 1);

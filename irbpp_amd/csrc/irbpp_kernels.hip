@@ -2139,7 +2139,7 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                     SlotMem m;
                     m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
                     uint16_t* im = (uint16_t*)(gsc + 6 * TRACE_BIG);                      // the plain walk reads 16-bit row and column words
-                    for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)(fr[1 + q] >> 1); im[16 + q] = (uint16_t)(fr[FRAME_COLS + 1 + q] >> 1); }
+                    for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)frame_raw_row(fr, q); im[16 + q] = (uint16_t)frame_raw_col(fr, q); }
                     if (contour_vertices(im, im + 16, x0, y0, m, S.w_vmask + (size_t)rk * 16) != 0)
                         atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                     my_n = 0;
@@ -2360,7 +2360,7 @@ __device__ __forceinline__ void trace_refill_body(const Params& P, const State& 
                         SlotMem m;
                         m.pts = gsc; m.dst = gsc + TRACE_BIG; m.stk = (uint32_t*)(gsc + 2 * TRACE_BIG); m.cap = TRACE_BIG; m.cap_stk = TRACE_BIG;
                         uint16_t* im = (uint16_t*)(gsc + 6 * TRACE_BIG);
-                        for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)(fr[1 + q] >> 1); im[16 + q] = (uint16_t)(fr[FRAME_COLS + 1 + q] >> 1); }
+                        for (int q = 0; q < 16; ++q) { im[q] = (uint16_t)frame_raw_row(fr, q); im[16 + q] = (uint16_t)frame_raw_col(fr, q); }
                         if (contour_vertices(im, im + 16, x0, y0, m, S.w_vmask + (size_t)rk * 16) != 0)
                             atomicOr(S.err, IRBPP_DEVERR_TRACE_GUARD);
                         my_n = 0;

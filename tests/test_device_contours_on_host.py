@@ -44,8 +44,9 @@ def host():
     if shutil.which("g++") is None:
         pytest.skip("no host compiler")
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value",
-                    "-I", os.path.join(HERE, "host", "stub"), SRC, "-o", OUT], check=True)
+    subprocess.run(["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
+                   + os.environ.get("IRBPP_HOST_TEST_DEFINES", "").split()        # e.g. -DIRBPP_COMPACT_FRAMES=1: the A/B forms
+                   + ["-I", os.path.join(HERE, "host", "stub"), SRC, "-o", OUT], check=True)
     lib = C.CDLL(OUT)
     lib.host_start_candidates.argtypes = [u16p, u32p]
     lib.host_trace_border.argtypes = [u16p, C.c_int, C.c_int, u8p, C.c_int]
