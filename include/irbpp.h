@@ -349,6 +349,20 @@ typedef struct {
 int irbpp_replay_gather(const irbpp_replay_view* view, int32_t draws, float beta, const int64_t* data_idx_dev,
                         const float* prob_dev, float* state_dev, int64_t* action_dev, float* return_dev,
                         float* next_state_dev, float* nonterminal_dev, float* weight_dev, void* stream);
+/* The writable side of the same tensor set (memory.py:28-36, 111): int32 timesteps [n_env][capacity], float32 max priority,
+ * int32 episode timestep counter [n_env]; the others as in irbpp_replay_view. */
+typedef struct {
+    float* states_dev; int64_t* actions_dev; float* rewards_dev; uint8_t* nonterminals_dev; int32_t* timesteps_dev;
+    float* tree_dev; float* max_dev; int64_t* index_dev; uint8_t* full_dev; int32_t* t_dev;
+    int32_t n_env, capacity, obs_len;
+} irbpp_replay_store;
+/* replaces: ReplayMemory.append (memory.py:117-121) with SegmentTree.append (:60-70) and its _propagate (:47-52), called
+ * per env at trainer.py:184-186 -- for all envs in one launch: state_dev float32 rows `state_stride` floats apart, action
+ * int32 or int64 (action_bytes 4 | 8), reward float32 or float64 (reward_bytes 4 | 8; stored as float32), terminal_dev
+ * uint8[n_env]; valid_dev (may be NULL = every env) uint8[n_env]: envs with 0 are skipped (a sample that is not Valid). */
+int irbpp_replay_append(const irbpp_replay_store* store, const float* state_dev, int64_t state_stride, const void* action_dev,
+                        int32_t action_bytes, const void* reward_dev, int32_t reward_bytes, const uint8_t* terminal_dev,
+                        const uint8_t* valid_dev, void* stream);
 /* replaces: the tail of Agent.act (agent.py:55-58) with get_mask_from_state (tools.py:298-299) fused in:
  * action[e] = argmax_i q[e][i] over the candidates i whose validity flag obs[e][5*i+4] is non-zero (first maximum;
  * 0x7fffffff never occurs: with no valid candidate every q is -inf and index 0 wins, like torch.argmax). */

@@ -35,6 +35,13 @@ class IrbppReplayView(C.Structure):
                 ("n_env", C.c_int32), ("capacity", C.c_int32), ("obs_len", C.c_int32), ("n_step", C.c_int32)]
 
 
+class IrbppReplayStore(C.Structure):
+    _fields_ = [("states_dev", C.c_void_p), ("actions_dev", C.c_void_p), ("rewards_dev", C.c_void_p),
+                ("nonterminals_dev", C.c_void_p), ("timesteps_dev", C.c_void_p), ("tree_dev", C.c_void_p),
+                ("max_dev", C.c_void_p), ("index_dev", C.c_void_p), ("full_dev", C.c_void_p), ("t_dev", C.c_void_p),
+                ("n_env", C.c_int32), ("capacity", C.c_int32), ("obs_len", C.c_int32)]
+
+
 class IrbppStepOut(C.Structure):
     _fields_ = [("reward_dev", C.c_void_p), ("done_dev", C.c_void_p), ("counter_dev", C.c_void_p),
                 ("ratio_dev", C.c_void_p), ("ep_reward_dev", C.c_void_p), ("ep_len_dev", C.c_void_p),
@@ -85,6 +92,8 @@ SIGNATURES = {
                                        C.c_void_p, C.c_void_p]),
     "irbpp_replay_gather": (C.c_int, [C.POINTER(IrbppReplayView), C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "irbpp_replay_append": (C.c_int, [C.POINTER(IrbppReplayStore), C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p,
+                                      C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "irbpp_masked_argmax": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p]),
     "irbpp_debug_phase_cycles": (C.c_int, [C.c_void_p, C.c_void_p]),

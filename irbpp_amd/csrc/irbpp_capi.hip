@@ -1112,6 +1112,21 @@ int irbpp_replay_gather(const irbpp_replay_view* v, int32_t draws, float beta, c
     return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
 }
 
+int irbpp_replay_append(const irbpp_replay_store* m, const float* state_dev, int64_t state_stride, const void* action_dev,
+                        int32_t action_bytes, const void* reward_dev, int32_t reward_bytes, const uint8_t* terminal_dev,
+                        const uint8_t* valid_dev, void* stream) {
+    if (!m || !m->states_dev || !m->actions_dev || !m->rewards_dev || !m->nonterminals_dev || !m->timesteps_dev || !m->tree_dev ||
+        !m->max_dev || !m->index_dev || !m->full_dev || !m->t_dev || m->n_env < 1 || m->capacity < 1 || m->obs_len < 1 ||
+        !state_dev || state_stride < m->obs_len || !action_dev || (action_bytes != 4 && action_bytes != 8) || !reward_dev ||
+        (reward_bytes != 4 && reward_bytes != 8) || !terminal_dev)
+        return IRBPP_ERR_ARG;
+    hipLaunchKernelGGL(irbpp_replay_append_kernel, dim3(m->n_env), dim3(256), 0, (hipStream_t)stream, m->states_dev, m->actions_dev,
+                       m->rewards_dev, m->nonterminals_dev, m->timesteps_dev, m->tree_dev, m->max_dev, m->index_dev, m->full_dev,
+                       m->t_dev, m->capacity, m->obs_len, state_dev, (long long)state_stride, action_dev, action_bytes, reward_dev,
+                       reward_bytes, terminal_dev, valid_dev);
+    return hipGetLastError() == hipSuccess ? IRBPP_OK : IRBPP_ERR_HIP;
+}
+
 int irbpp_debug_phase_cycles(irbpp_env* env, int64_t* cycles_dev) {
     if (!env) return IRBPP_ERR_ARG;
     drop_graphs(env);

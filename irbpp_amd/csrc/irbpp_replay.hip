@@ -121,6 +121,51 @@ irbpp_sumtree_update_kernel(float* __restrict__ tree, float* __restrict__ maxp, 
     for (int i = lane; i < len; i += 64) g[i] = row[i];
 }
 
+// ReplayMemory.append (memory.py:117-121) + SegmentTree.append (:60-70) for every env (or the envs of `valid`) in ONE launch:
+// the transition enters the env's ring at its write index with the env's maximum priority, the leaf's ancestors are
+// recomputed as left + right in float32 (_propagate, :47-52), index / full / the episode's timestep counter move on.
+// One workgroup per env: 256 threads copy the observation row (the launch's bytes: obs_len floats in, obs_len out), thread 0
+// does the scalars and walks the leaf's ancestors -- the sibling comes from memory, the node just written stays in a
+// register, so nothing is read back.  action int32 or int64, reward float32 or float64 (what the environment hands out:
+// no conversion launches in front), terminal / valid one byte per env.
+extern "C" __global__ void __launch_bounds__(256)
+irbpp_replay_append_kernel(float* __restrict__ states, int64_t* __restrict__ actions, float* __restrict__ rewards,
+                           uint8_t* __restrict__ nonterminals, int32_t* __restrict__ timesteps, float* __restrict__ tree,
+                           float* __restrict__ maxp, int64_t* __restrict__ index, uint8_t* __restrict__ full,
+                           int32_t* __restrict__ tcount, int cap, int obs_len, const float* __restrict__ state, long long state_stride,
+                           const void* __restrict__ action, int action_bytes, const void* __restrict__ reward, int reward_bytes,
+                           const uint8_t* __restrict__ terminal, const uint8_t* __restrict__ valid) {
+    const int env = blockIdx.x, tid = threadIdx.x;
+    if (valid && !valid[env]) return;                            // trainer.py:184-186: only Valid samples are stored
+    const int pos = (int)index[env];
+    const float* src = state + (size_t)env * state_stride;
+    float* dst = states + ((size_t)env * cap + pos) * obs_len;
+    for (int i = tid; i < obs_len; i += 256) dst[i] = src[i];
+    __syncthreads();                                             // every wave has read index[env]
+    if (tid != 0) return;
+    const size_t slot = (size_t)env * cap + pos;
+    const bool term = terminal[env] != 0;
+    const int t = tcount[env];
+    timesteps[slot] = t;
+    actions[slot] = action_bytes == 8 ? ((const int64_t*)action)[env] : (int64_t)((const int32_t*)action)[env];
+    rewards[slot] = reward_bytes == 8 ? (float)((const double*)reward)[env] : ((const float*)reward)[env];
+    nonterminals[slot] = term ? 0 : 1;
+    float* row = tree + (size_t)env * (2 * cap - 1);
+    float v = maxp[env];                                         // (self.max = max(value, self.max) leaves it as it is)
+    int i = pos + cap - 1;
+    row[i] = v;
+    while (i > 0) {
+        const int parent = (i - 1) >> 1;
+        v = (i & 1) ? v + row[i + 1] : row[i - 1] + v;           // left + right: i odd is the left child
+        row[parent] = v;
+        i = parent;
+    }
+    const int nxt = pos + 1 == cap ? 0 : pos + 1;
+    index[env] = nxt;
+    if (nxt == 0) full[env] = 1;
+    tcount[env] = term ? 0 : t + 1;
+}
+
 // Agent.act (agent.py:51-58) after the network: sum_q[(1 - mask).bool()] = -inf; argmax(1), with the mask read
 // straight from the observation (get_mask_from_state, tools.py:298-299: column 4 of the [S][5] candidate block).
 // One wave per env; the first maximum wins.

@@ -71,6 +71,7 @@ class VectorReplayMemory(object):
         self._depth = max(1, (2 * cap - 1).bit_length())                 # >= height of the implicit tree
         # HIP kernels for find / update (one launch each) where the tree row fits their LDS buffer
         self._lib = _hip_lib(self.device) if use_hip in (None, True) else None
+        self._append_hip = self._lib is not None              # (irbpp_replay_append walks one leaf's ancestors in global memory: any capacity)
         if use_hip and self._lib is None:
             raise RuntimeError("use_hip=True needs a HIP device")
         if self._lib is not None and 2 * cap - 1 > 16384:
@@ -155,12 +156,42 @@ class VectorReplayMemory(object):
         return self.sum_tree[rows, idx], idx - (self.capacity - 1), idx
 
     # ------------------------------------------------------------------ append --------------
+    def _append_on_device(self, state, action, reward, terminal, valid) -> bool:
+        """One launch of irbpp_replay_append for the whole call when the arguments are what an actor loop on the device
+        hands over (float32 observation rows, int32 / int64 actions, float32 / float64 rewards, one-byte flags, all on
+        this device) -- no conversion launches in front of it; False: the caller takes the torch formulation."""
+        d = self.device
+        if d.type != "cuda" or self.states.dtype != torch.float32:
+            return False
+        def on_dev(x, dtypes, n):        # noqa: E306
+            return isinstance(x, torch.Tensor) and x.device == d and x.dtype in dtypes and x.numel() == n and x.is_contiguous()
+        if not (isinstance(state, torch.Tensor) and state.device == d and state.dtype == torch.float32 and state.dim() == 2 and
+                state.shape == (self.N, self.obs_len) and state.stride(1) == 1 and state.stride(0) >= self.obs_len):
+            return False
+        flags = (torch.bool, torch.uint8)
+        if not (on_dev(action, (torch.int32, torch.int64), self.N) and on_dev(reward, (torch.float32, torch.float64), self.N) and
+                on_dev(terminal, flags, self.N) and (valid is None or on_dev(valid, flags, self.N))):
+            return False
+        from . import _lib
+        lib = self._lib if self._lib is not None else _lib.load()
+        store = _lib.IrbppReplayStore(
+            self.states.data_ptr(), self.actions.data_ptr(), self.rewards.data_ptr(), self.nonterminals.data_ptr(),
+            self.timesteps.data_ptr(), self.sum_tree.data_ptr(), self.max.data_ptr(), self.index.data_ptr(), self.full.data_ptr(),
+            self.t.data_ptr(), self.N, self.capacity, self.obs_len)
+        _lib.check(lib.irbpp_replay_append(C.byref(store), _p(state), state.stride(0), _p(action), action.element_size(),
+                                           _p(reward), reward.element_size(), _p(terminal), _p(valid), _stream(d)),
+                   "irbpp_replay_append")
+        return True
+
     def append(self, state: torch.Tensor, action: torch.Tensor, reward: torch.Tensor, terminal,
                valid: Optional[torch.Tensor] = None) -> None:
         """ReplayMemory.append (memory.py:117-121) for every env whose sample is valid
         (trainer.py:184-186): state/action at time t, reward/terminal at t+1; the new transition
         gets the env's maximum priority."""
         d = self.device
+        if self._lib is not None or self._append_hip:
+            if self._append_on_device(state, action, reward, terminal, valid):
+                return
         terminal = torch.as_tensor(terminal, device=d).reshape(self.N).to(torch.bool)
         everyone = valid is None
         rows = self._rows if everyone else self._rows[torch.as_tensor(valid, device=d).reshape(self.N).to(torch.bool)]
@@ -334,9 +365,10 @@ def actor_step(envs, policy, memory: VectorReplayMemory, state: torch.Tensor, re
     (reward, done) device tensors; episode statistics stay on the device (episode_totals)."""
     mask = mask_from_state(state, envs.S)
     action = policy(state, mask)
-    next_state, reward, done = envs.step(action.to(torch.int32))
-    reward = reward.to(torch.float32)
+    next_state, reward, done = envs.step(action if action.dtype == torch.int32 else action.to(torch.int32))
     if reward_clip > 0:
-        reward = reward.clamp(-reward_clip, reward_clip)                          # trainer.py:181-182
-    memory.append(state, action, reward, done.to(torch.bool))                     # every sample is Valid without physics
+        reward = reward.to(torch.float32).clamp(-reward_clip, reward_clip)           # trainer.py:181-182
+    # every sample is Valid without physics.  (On a HIP device the append is one launch that takes the environment's own
+    # float64 rewards and one-byte done flags: `reward` / `done` are then the step's views, overwritten by the next step.)
+    memory.append(state, action, reward, done)
     return next_state, reward, done

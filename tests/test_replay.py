@@ -198,9 +198,13 @@ def test_hip_sum_tree_kernels_equal_the_torch_formulation(capacity, n_step, seed
         reward = torch.from_numpy(rng.uniform(0, 1, size=n_envs).astype(np.float32)).cuda()
         terminal = torch.from_numpy(rng.rand(n_envs) < 0.2).cuda()
         valid = torch.from_numpy(rng.rand(n_envs) < (1.0 if t % 3 else 0.7)).cuda()
-        for m in (hip, ref):
-            m.append(state, action, reward, terminal, valid)
-        assert torch.equal(hip.sum_tree, ref.sum_tree) and torch.equal(hip.max, ref.max)
+        ref.append(state, action, reward, terminal, valid)
+        if t % 2:            # irbpp_replay_append takes what the environment hands out: int32 actions, float64 rewards, uint8 flags
+            hip.append(state, action.to(torch.int32), reward.to(torch.float64), terminal.to(torch.uint8), valid.to(torch.uint8))
+        else:
+            hip.append(state, action, reward, terminal, None if bool(valid.all()) else valid)
+        for name in ("sum_tree", "max", "states", "actions", "rewards", "nonterminals", "timesteps", "index", "full", "t"):
+            assert torch.equal(getattr(hip, name), getattr(ref, name)), (name, t)
         if t % 5 == 4 and bool(ref.full.all()):
             vals = (torch.rand((n_envs, B), device="cuda:0") * ref.total()[:, None]).clamp(min=1e-6)
             for a, b in zip(hip.find(vals), ref.find(vals)):
