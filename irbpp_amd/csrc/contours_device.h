@@ -671,6 +671,37 @@ __device__ inline bool approx_and_convex(const uint8_t* pts, int count, uint8_t*
 }
 
 // ---------------------------------------------------------------------------------------
+// Isolated solid rectangles (round 6).  Of the ~25 borders per bin that lattice data hands to the trace kernel, 38 % belong to a
+// component that is nothing but a solid w x h rectangle with an empty ring around it (tools/rect_component_study.py).  Its border
+// is its four corners (CHAIN_APPROX_SIMPLE), and what approxPolyDP(eps = 1) + find_convex_vetex leave of them depends on (w, h)
+// alone: the first corner only for the two-pixel components (the second point lies within eps), the first and the opposite corner
+// when the thin side is two pixels (the other two lie within eps of the diagonal), all four otherwise -- which for a one-pixel
+// line are its two ends.  (tests/test_device_contours_on_host.py checks the rule against the routines above and the oracle for
+// every size and position.)  So the transition kernel answers such a candidate start itself, as it does isolated pixels, and
+// the trace kernel's waves carry the borders that need following.
+// rect_component: is the component that starts at candidate (x0, y) of `row` -- a start_candidates bit: nothing above the run
+// touches it -- the solid rectangle [x0, x0 + w) x [y, y + h) with no other pixel next to it?  rows = the image's 16 row words.
+template <typename Rows>
+__device__ __forceinline__ bool rect_component(const Rows rows, uint32_t row, int x0, int y, int& w, int& h) {
+    w = __builtin_ctz(~(row >> x0));                                       // the run that starts at x0
+    const uint32_t m = ((1u << w) - 1u) << x0, mb = (m | (m << 1) | (m >> 1)) & 0xFFFFu;
+    h = 1;
+    uint32_t nx = 0u;
+    for (; y + h < 16; ++h) {
+        nx = (uint32_t)rows[y + h] & mb;
+        if (nx != m) break;
+    }
+    return y + h == 16 || nx == 0u;                                        // the row below the last one: clear over the run and beside it
+}
+// the vertex bits of that rectangle: `top` for row y, `bottom` for row y + h - 1 (the same row when h == 1)
+__device__ __forceinline__ void rect_vertices(int w, int h, int x0, uint32_t& top, uint32_t& bottom) {
+    const uint32_t first = 1u << x0, last = 1u << (x0 + w - 1);
+    if (w * h == 2) { top = first; bottom = 0u; }
+    else if (w == 2 || h == 2) { top = first; bottom = last; }
+    else { top = first | last; bottom = first | last; }
+}
+
+// ---------------------------------------------------------------------------------------
 // WIDE action grids (17 .. 32 cells a side: resolutionA = 0.01 on the 0.32 m bin, space.py:19-24; round 6): level images of up
 // to 32 rows of 32 bits, contour points of 16 bits (x | y << 5).  Plain statements of the same routines -- candidate starts,
 // icvFetchContourEx with CHAIN_APPROX_SIMPLE for the OUTER border that starts at a component's first pixel in raster order,

@@ -488,10 +488,32 @@ __device__ inline int contour_candidates(const Params& P, const Lds& L, const ui
     for (int h = 0; h < IPT; ++h) {
         const int gg = g + h * (BLOCK / 16);
         uint32_t iso;
-        const uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
+        uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
         if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
+        int nrect = 0;
+        if (keep && cand && !P.no_rect) {
+            // isolated solid rectangles (contours_device.h: rect_component): their vertices follow from (w, h) -- marked here like
+            // the isolated pixels, and the start leaves the list.  (Only where the candidate words are kept: the split pipeline.)
+            const uint16_t* const im = rows + gg * 16;
+            const uint32_t row_bits = (uint32_t)im[y];
+            uint32_t* const vm = &L.vmask[(L.tasklist[base + gg] >> 8) * 16];
+            uint32_t todo = cand;
+            while (todo) {
+                const int x0 = __ffs((int)todo) - 1;
+                todo &= todo - 1u;
+                int rw, rh;
+                if (rect_component(im, row_bits, x0, y, rw, rh)) {
+                    uint32_t top, bottom;
+                    rect_vertices(rw, rh, x0, top, bottom);
+                    atomicOr(vm + y, top);
+                    if (bottom) atomicOr(vm + y + rh - 1, bottom);
+                    cand &= ~(1u << x0);
+                    ++nrect;
+                }
+            }
+        }
         if (keep) keep[gg * 16 + y] = (uint16_t)cand;
-        my_count += __popc(cand) + (__popc(iso) << 16);
+        my_count += __popc(cand) + ((__popc(iso) + nrect) << 16);
     }
     return block_sum_int(my_count, L.redi);
 }

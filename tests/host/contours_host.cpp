@@ -179,4 +179,16 @@ int host_contour_vertices(const uint16_t* rows, int x0, int y0, int cap, int cap
     return contour_vertices(rows, cols, x0, y0, m, vrows);
 }
 
+// rect_component + rect_vertices for candidate (x0, y0): 0 not an isolated solid rectangle; else w | h << 8, vertex bits in vrows[16]
+int host_rect_component(const uint16_t* rows, int x0, int y0, uint32_t* vrows) {
+    int w = 0, h = 0;
+    memset(vrows, 0, 16 * sizeof(uint32_t));
+    if (!rect_component(rows, (uint32_t)rows[y0], x0, y0, w, h)) return 0;
+    uint32_t top = 0, bottom = 0;
+    rect_vertices(w, h, x0, top, bottom);
+    vrows[y0] |= top;
+    vrows[y0 + h - 1] |= bottom;
+    return w | (h << 8);
+}
+
 }  // extern "C"

@@ -67,6 +67,8 @@ def host():
     lib.host_approx_and_convex.restype = C.c_int
     lib.host_contour_vertices.argtypes = [u16p, C.c_int, C.c_int, C.c_int, C.c_int, u32p]
     lib.host_contour_vertices.restype = C.c_int
+    lib.host_rect_component.argtypes = [u16p, C.c_int, C.c_int, u32p]
+    lib.host_rect_component.restype = C.c_int
     return lib
 
 
@@ -428,3 +430,75 @@ def test_wide_grid_routines_equal_the_oracle(host, W, H, seed):
         assert longest.value == max([len(c) for c in outer], default=0)
         seen_long = max(seen_long, longest.value)
     assert seen_long > 64                                                   # borders beyond the 16 x 16 grid's slot were covered
+
+
+def _rect_truth(img, x0, y0):
+    """(w, h) if the 8-connected component of pixel (x0, y0) is a solid rectangle whose first pixel that is, else None."""
+    lab, _ = ndimage.label(img, structure=np.ones((3, 3)))
+    comp = lab == lab[y0, x0]
+    ys, xs = np.nonzero(comp)
+    if (xs.min(), ys.min()) != (x0, y0) or not comp[ys.min():ys.max() + 1, xs.min():xs.max() + 1].all():
+        return None
+    return int(xs.max() - xs.min() + 1), int(ys.max() - ys.min() + 1)
+
+
+def test_isolated_rectangles_every_size_and_position(host):
+    """rect_component / rect_vertices (contours_device.h): every w x h rectangle at every position is recognised, and its
+    vertex bits are what trace + approxPolyDP + convexity (the device routines, and the oracle) give for it."""
+    vr, vt = (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
+    for w in range(1, 17):
+        for h in range(1, 17):
+            if w * h == 1:
+                continue                                              # an isolated pixel: never a listed candidate
+            for x0 in sorted({0, 1, (16 - w) // 2, 16 - w}):
+                for y0 in sorted({0, 1, (16 - h) // 2, 16 - h}):
+                    if x0 + w > 16 or y0 + h > 16:
+                        continue
+                    img = np.zeros((16, 16), dtype=np.uint8)
+                    img[y0:y0 + h, x0:x0 + w] = 1
+                    rows = _rows(img)
+                    assert host.host_rect_component(rows, x0, y0, vr) == (w | (h << 8))
+                    vt[:] = [0] * 16
+                    assert host.host_contour_vertices(rows, x0, y0, 1360, 1360, vt) == 0
+                    assert list(vr) == list(vt), (w, h, x0, y0)
+                    outer, _, _ = _oracle_outer(img)
+                    got = {(x, y) for y in range(16) for x in range(16) if (vr[y] >> x) & 1}
+                    assert len(outer) == 1 and got == _oracle_vertices(outer[0]), (w, h, x0, y0)
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_rect_component_says_yes_exactly_for_isolated_solid_rectangles(host, seed):
+    """On unions of rectangles, speckle and near-rectangles (a corner pixel missing, a pixel touching diagonally): for every
+    listed candidate start, rect_component == the definition (8-connected component is its solid bounding box), and where
+    it says yes the vertex bits equal those of the followed border."""
+    rng = np.random.RandomState(500 + seed)
+    cand, vr, vt = (C.c_uint32 * 16)(), (C.c_uint32 * 16)(), (C.c_uint32 * 16)()
+    yes = no = 0
+    for k in range(400):
+        img = np.zeros((16, 16), dtype=bool)
+        for _ in range(rng.randint(1, 9)):
+            y, x = rng.randint(0, 16), rng.randint(0, 16)
+            img[y:y + rng.randint(1, 7), x:x + rng.randint(1, 7)] = True
+        if k % 3 == 1:
+            img ^= rng.rand(16, 16) < 0.02                              # a pixel knocked out of / stuck onto a rectangle
+        if k % 3 == 2:
+            img = rng.rand(16, 16) < rng.uniform(0.05, 0.4)
+        img = img.astype(np.uint8)
+        rows = _rows(img)
+        host.host_start_candidates(rows, cand)
+        for y in range(16):
+            for x in range(16):
+                if not (cand[y] >> x) & 1:
+                    continue
+                truth = _rect_truth(img, x, y)
+                got = host.host_rect_component(rows, x, y, vr)
+                if truth is None or truth == (1, 1):
+                    assert got == 0 or truth == (1, 1), (k, x, y)
+                    no += 1
+                    continue
+                assert got == (truth[0] | (truth[1] << 8)), (k, x, y, truth, got)
+                vt[:] = [0] * 16
+                assert host.host_contour_vertices(rows, x, y, 1360, 1360, vt) == 0
+                assert list(vr) == list(vt), (k, x, y, truth)
+                yes += 1
+    assert yes > 300 and no > 300

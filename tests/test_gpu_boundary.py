@@ -399,3 +399,67 @@ def test_graph_replay_follows_the_placement_log():
     for e in (g, d):
         e.check_device_error()
         e.close()
+
+
+def test_isolated_rectangles_of_every_size_through_the_split_pipeline():
+    """Round 6: the transition kernel answers level-image components that are isolated solid rectangles itself
+    (contours_device.h: rect_component / rect_vertices) instead of handing their borders to the trace kernel.  Level images
+    packed with non-touching rectangles of every width and height up to 16 -- plus near-rectangles (a corner knocked out, a
+    pixel stuck on diagonally) that must still be followed -- through the whole pipeline by way of the heightmap of a bin that
+    observes a one-cell item, default build and IRBPP_TUNE_NO_RECT side by side, every location observation against the oracle."""
+    from irbpp_amd import _lib
+    from oracle.packing import OracleVecEnv
+    sh = _unit_item_shapes()
+    seqs = np.zeros((8, 80), dtype=np.int32)
+    n, k = 8, 2
+    genvs = [GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k, tuning=f) for f in (0, _lib.TUNE_NO_RECT)]
+    for g in genvs:
+        g.candidates_on_device = True
+    oenv = OracleVecEnv(n, sh, seqs, bufferSize=k)
+    ref = _f32(oenv.reset())
+    for g in genvs:
+        np.testing.assert_array_equal(g.reset().cpu().numpy(), ref)
+    rng = np.random.RandomState(77)
+    sizes = [(w, h) for w in range(1, 17) for h in range(1, 17)]
+    rng.shuffle(sizes)
+    seen = set()
+    pos = 0
+    for t in range(40):
+        hm = np.zeros((n, 32, 32))
+        for i in range(n):
+            img = np.zeros((16, 16), dtype=bool)
+            occ = np.zeros((18, 18), dtype=bool)                       # the rectangles dilated by one pixel: no two may touch
+            for _ in range(24):
+                w, h = sizes[pos % len(sizes)] if rng.rand() < 0.6 else (rng.randint(1, 5), rng.randint(1, 5))
+                if w > 16 or h > 16:
+                    continue
+                x0, y0 = rng.randint(0, 17 - w), rng.randint(0, 17 - h)
+                if occ[y0:y0 + h + 2, x0:x0 + w + 2].any():
+                    continue
+                img[y0:y0 + h, x0:x0 + w] = True
+                occ[y0:y0 + h + 2, x0:x0 + w + 2] = True
+                seen.add((w, h))
+                pos += 1
+            if (t + i) % 3 == 1:
+                img ^= rng.rand(16, 16) < 0.015                        # near-rectangles
+            lv = np.where(img, 0.05, 0.11) + rng.randint(0, 2, size=(16, 16)) * np.where(img, 0.0, 0.03)
+            hm[i] = np.kron(lv, np.ones((2, 2)))
+        for g in genvs:
+            g.env.set_heightmaps(torch.from_numpy(hm).to(DEV))
+        for i in range(n):
+            oenv.envs[i].space.heightmapC[:] = hm[i]
+        oa = np.array([t % k] * n)
+        oloc = _f32(oenv.get_action_candidates(oa))
+        for g in genvs:
+            np.testing.assert_array_equal(g.get_action_candidates(oa).cpu().numpy(), oloc, err_msg=f"round {t}")
+        act = np.array([int(np.argmin(np.where(c.reshape(S, 5)[:, 4] == 1, c.reshape(S, 5)[:, 3], np.inf)))
+                        if (c.reshape(S, 5)[:, 4] == 1).any() else 0 for c in oloc[:, :5 * S]])
+        oord, _, odone, _ = oenv.step(act)
+        for g in genvs:
+            gord, _, gdone, _ = g.step(act)
+            np.testing.assert_array_equal(gord.cpu().numpy(), _f32(oord))
+            np.testing.assert_array_equal(gdone, odone)
+    assert len(seen) >= 200, len(seen)                                 # (big ones rarely find room beside others: they come alone)
+    for g in genvs:
+        g.env.check_device_error()
+        g.close()
