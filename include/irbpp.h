@@ -113,8 +113,9 @@ typedef struct {
                                         the launch sizes it was built for (irbpp_capi.hip: chain_launch); identical results, parity-tested  */
 #define IRBPP_TUNE_WG128 2097152     /* BlockOut at R = 4: the transition kernel with 128-thread workgroups (two waves per bin, two action cells
                                         per thread); identical results, for A/B runs and the parity tests                                     */
-#define IRBPP_TUNE_NO_RECT 4194304   /* level-image components that are isolated solid rectangles are followed by the trace kernel like every
-                                      * other border (default: the transition kernel marks their vertices itself, as it does isolated pixels) */
+#define IRBPP_TUNE_RECT 4194304      /* the transition kernel marks the vertices of level-image components that are isolated solid rectangles
+                                      * itself, as it does isolated pixels (default: the trace kernel follows them like every other border --
+                                      * measured: trace -5 us, polygon -2 us, transition +6 us at 8192 BlockOut bins, profiles/r06/LOG.md s21) */
 #define IRBPP_TUNE_NO_SPECIALISED 1024 /* the run-time builds of the transition / emit kernels even where a build with the
                                          geometry as compile-time constants exists (16 x 16 action cells, step 2 or 4, R = 2 / 4 / 8,
                                          S = 500: BASELINE.json's configs); identical results, for A/B runs and the parity tests  */

@@ -25,7 +25,7 @@ TUNE_NO_BLOCK_PATH, TUNE_WIDE_KERNEL, TUNE_NARROW_KERNEL, TUNE_NO_BOX_PATH, TUNE
 TUNE_TRACE_CPW64, TUNE_TRACE_CPW32, TUNE_TRACE_CPW16, TUNE_INLINE_POLYGON, TUNE_NO_HEAVY_FIRST = 32, 64, 128, 256, 512
 TUNE_NO_SPECIALISED, TUNE_FUSED_APPLY, TUNE_SPLIT_APPLY, TUNE_BLOCK_EMIT, TUNE_WAVE_EMIT = 1024, 2048, 4096, 8192, 16384
 TUNE_GRAPH, TUNE_WG512, TUNE_NO_WG512, TUNE_TRACE_REFILL, TUNE_NO_MIXED_PATH = 32768, 65536, 131072, 262144, 524288
-TUNE_CHAIN, TUNE_WG128, TUNE_NO_RECT = 1048576, 2097152, 4194304
+TUNE_CHAIN, TUNE_WG128, TUNE_RECT = 1048576, 2097152, 4194304
 
 
 class IrbppReplayView(C.Structure):

@@ -219,7 +219,7 @@ int irbpp_create(const irbpp_config* cfg, irbpp_env** out) {
 #endif
     P.split = 1;                                            // transition -> trace -> emit kernels
     P.stability = cfg->stability < 0 ? 0 : (cfg->stability > 2 ? 2 : cfg->stability);
-    P.no_rect = (cfg->tuning & IRBPP_TUNE_NO_RECT) ? 1 : 0;
+    P.rect = (cfg->tuning & IRBPP_TUNE_RECT) ? 1 : 0;
     P.wimg = P.R * 64;
     P.seg_cap = P.wide ? 64 : 2 * ((P.N + NXCD - 1) / NXCD) * P.R * P.AC;      // (the wide path hands nothing over between kernels)
     P.round_cap = P.wide ? 16 : (P.N / NXCD + 64) * 16;

@@ -169,7 +169,7 @@ struct Params {
     int32_t stability;     // 0 off, 1 rate accepted placements, 2 refuse unstable ones (irbpp_config::stability)
     int32_t wide;          // action grid of 17 .. 32 cells a side: the capacity path of irbpp_wide.hip (one kernel per observation)
     int32_t vrow;          // words per rotation of w_valid (naiveMask bit rows): 16, or 32 on a wide grid
-    int32_t no_rect;       // IRBPP_TUNE_NO_RECT: isolated solid rectangles go to the trace kernel like every other border (A/B)
+    int32_t rect;          // IRBPP_TUNE_RECT: isolated solid rectangles are answered by the transition kernel instead of the trace kernel (A/B)
 };
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -491,9 +491,10 @@ __device__ inline int contour_candidates(const Params& P, const Lds& L, const ui
         uint32_t cand = row_candidates(rows, gg, y, base + gg < ntasks, iso);
         if (iso) atomicOr(&L.vmask[(L.tasklist[base + gg] >> 8) * 16 + y], iso);
         int nrect = 0;
-        if (keep && cand && !P.no_rect) {
+        if (keep && cand && P.rect) {
             // isolated solid rectangles (contours_device.h: rect_component): their vertices follow from (w, h) -- marked here like
-            // the isolated pixels, and the start leaves the list.  (Only where the candidate words are kept: the split pipeline.)
+            // the isolated pixels, and the start leaves the list.  (Only where the candidate words are kept: the split pipeline; opt-in,
+            // IRBPP_TUNE_RECT: the loop costs the transition kernel what it saves the trace and polygon kernels.)
             const uint16_t* const im = rows + gg * 16;
             const uint32_t row_bits = (uint32_t)im[y];
             uint32_t* const vm = &L.vmask[(L.tasklist[base + gg] >> 8) * 16];

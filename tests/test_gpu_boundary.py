@@ -402,17 +402,17 @@ def test_graph_replay_follows_the_placement_log():
 
 
 def test_isolated_rectangles_of_every_size_through_the_split_pipeline():
-    """Round 6: the transition kernel answers level-image components that are isolated solid rectangles itself
+    """Round 6, IRBPP_TUNE_RECT: the transition kernel answers level-image components that are isolated solid rectangles itself
     (contours_device.h: rect_component / rect_vertices) instead of handing their borders to the trace kernel.  Level images
     packed with non-touching rectangles of every width and height up to 16 -- plus near-rectangles (a corner knocked out, a
     pixel stuck on diagonally) that must still be followed -- through the whole pipeline by way of the heightmap of a bin that
-    observes a one-cell item, default build and IRBPP_TUNE_NO_RECT side by side, every location observation against the oracle."""
+    observes a one-cell item, default build and IRBPP_TUNE_RECT side by side, every location observation against the oracle."""
     from irbpp_amd import _lib
     from oracle.packing import OracleVecEnv
     sh = _unit_item_shapes()
     seqs = np.zeros((8, 80), dtype=np.int32)
     n, k = 8, 2
-    genvs = [GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k, tuning=f) for f in (0, _lib.TUNE_NO_RECT)]
+    genvs = [GpuVecEnv(sh, seqs, n, device=DEV, bufferSize=k, tuning=f) for f in (0, _lib.TUNE_RECT)]
     for g in genvs:
         g.candidates_on_device = True
     oenv = OracleVecEnv(n, sh, seqs, bufferSize=k)

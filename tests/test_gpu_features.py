@@ -252,7 +252,7 @@ def test_specialised_builds_and_split_apply_change_nothing(workload, n, steps, s
              _lib.TUNE_NO_MIXED_PATH,                      # (BlockOut at eight rotations through the cell lists entirely, as until round 5)
              _lib.TUNE_CHAIN,                              # (ONE kernel per observation: contour stage and candidate rows in the bin's workgroup)
              _lib.TUNE_WG128, _lib.TUNE_WG128 | _lib.TUNE_SPLIT_APPLY,     # (two waves per bin: BlockOut at R = 4 only)
-             _lib.TUNE_NO_RECT]                            # (isolated solid rectangles followed by the trace kernel, as until round 6)
+             _lib.TUNE_RECT]                               # (isolated solid rectangles answered by the transition kernel, not followed)
     envs = [GpuPackingEnv(shapes, seqs[:400], n, device=DEV, tuning=f, **kw) for f in flags]
     names = [e.kernel_info()[1].split(" + ")[0] for e in envs]
     assert names[0].endswith(spec) and names[2] == names[3] == names[0], names
