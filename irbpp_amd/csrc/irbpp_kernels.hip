@@ -1741,19 +1741,6 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
         niso += batch_total >> 16;
         batch_total &= 0xFFFF;
         const int nb = ntasks - base < IMGS ? ntasks - base : IMGS;
-        // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
-        // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
-        // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
-        // between the eight L2s with every allocation (measured: +22 us per launch).  The LDS list holds CLIST
-        // entries; a batch with more candidates (speckle) goes image by image (an image has at most 64).
-        const int nsub = batch_total <= CLIST ? 1 : IMGS;
-        // (the usual case, one list for the batch: its size is known from the candidate words, so thread 0 asks for the batch's
-        // place in this die's list NOW and looks at the answer after the list is built -- the atomic's round trip to L2, 1 - 2 k
-        // cycles with the other waves at the barrier behind it, runs beside contour_list and the image stores)
-        int early = 0;
-#ifndef IRBPP_AB_LATE_RESERVE
-        if (nsub == 1 && batch_total > 0 && tid == 0) early = atomicAdd(ka->S.w_total + xcd * XCD_STRIDE, batch_total);
-#endif
         // rows [IMGS][16] in LDS -> [image][16 row words] in global, as dwords
         const uint32_t* lr = (const uint32_t*)rows;
         for (int rep = 0; rep < IRBPP_REPS(14); ++rep) {
@@ -1762,6 +1749,12 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
 #pragma unroll 1
         for (int i = tid; i < nb; i += BLOCK) gr[base + i] = (uint8_t)(L.tasklist[base + i] >> 8);
         }
+        // The candidates join a flat list of (bin, image<<8 | y0<<4 | x0) pairs, in whatever order the bins arrive -- the
+        // trace kernel's results do not depend on it.  One list per XCD: the line of a counter that only the
+        // workgroups of one XCD touch stays in that XCD's L2, whereas the line of one device-wide counter travels
+        // between the eight L2s with every allocation (measured: +22 us per launch).  The LDS list holds CLIST
+        // entries; a batch with more candidates (speckle) goes image by image (an image has at most 64).
+        const int nsub = batch_total <= CLIST ? 1 : IMGS;
         for (int sub = 0; sub < nsub; ++sub) {
             int total = 0;
             for (int rep = 0; rep < IRBPP_REPS(10); ++rep) total = IRBPP_HERE contour_list<IPT>(L, rows, clist, base, ntasks, nsub, sub, cwords);
@@ -1774,11 +1767,7 @@ __device__ inline void split_handover(const Params& P, const State& S, const Lds
                 if (total > 0) {
                     for (int k = 0; k < NXCD && at < 0; ++k) {
                         seg = (xcd + k) & (NXCD - 1);
-#ifndef IRBPP_AB_LATE_RESERVE
-                        const int got = (k == 0 && nsub == 1) ? early : atomicAdd(ka->S.w_total + seg * XCD_STRIDE, total);
-#else
                         const int got = atomicAdd(ka->S.w_total + seg * XCD_STRIDE, total);
-#endif
                         if (got + total <= P.seg_cap) at = got;
                         else atomicSub(ka->S.w_total + seg * XCD_STRIDE, total);
                     }
@@ -2217,13 +2206,13 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
         // their records: one allocation in this XCD's list (L2-local atomic, like the candidate lists)
         const int round_cap = P.round_cap;
         const int xcd = (int)(__builtin_amdgcn_s_getreg((31 << 11) | 20) & (NXCD - 1));
-        int at = 0, at_lane0 = 0;
-        if (n_rounds > 0 && lane == 0) at_lane0 = atomicAdd(S.w_nround + xcd * XCD_STRIDE, n_rounds);
-#ifdef IRBPP_AB_LATE_RESERVE
-        at = __builtin_amdgcn_readfirstlane(at_lane0);
-#endif
-        bool inline_dp = false;                                       // list full: approximate here (never changes results)
-        uint8_t* rec0 = nullptr;
+        int at = 0;
+        if (n_rounds > 0) {
+            if (lane == 0) at = atomicAdd(S.w_nround + xcd * XCD_STRIDE, n_rounds);
+            at = __builtin_amdgcn_readfirstlane(at);
+        }
+        const bool inline_dp = at + n_rounds > round_cap;             // list full: approximate here (never changes results)
+        uint8_t* const rec0 = S.w_round + ((size_t)xcd * round_cap + at) * ROUND_BYTES;
         int left = my_n, n_dp = 0;
         for (int cls = 0; cls < 2; ++cls)
         for (;;) {
@@ -2261,15 +2250,6 @@ __device__ __forceinline__ void trace_body(const Params& P, const State& S, long
                 if (!live[u]) { nn[u] = 1; sbq[u] = 0; jj[u] = 0; }
                 pv[u] = live[u] ? (int)pts[u][jj[u] < LCAP ? jj[u] : LCAP] : 0;
                 if (spilled && live[u] && jj[u] >= LCAP) pv[u] = (int)wave_spill[on * TRACE_SPILL + jj[u] - LCAP];
-            }
-            if (n_dp == 0) {
-                // (the answer of the allocation is looked at HERE, after the first round's gathers: the atomic's round trip to
-                // L2 runs beside them instead of in front of them -- every trace wave has it on its critical path)
-#ifndef IRBPP_AB_LATE_RESERVE
-                at = __builtin_amdgcn_readfirstlane(at_lane0);
-#endif
-                inline_dp = at + n_rounds > round_cap;
-                rec0 = S.w_round + ((size_t)xcd * round_cap + at) * ROUND_BYTES;
             }
             if (inline_dp) {
                 approx_convex_segmented<PP>(lane, live, pv, jj, nn, sbq, pts, prk, dps, dpscratch, S.w_vmask);
