@@ -13,15 +13,15 @@ from irbpp_amd.vec_env import GpuVecEnv
 from oracle.c_oracle import COracleVecEnv
 
 for spec in sys.argv[1:]:
-    wl, n, groups, steps = spec.split(":")
-    n, groups, steps = int(n), int(groups), int(steps)
+    wl, n, groups, steps, tuning = (spec.split(":") + ["0"])[:5]        # (optional fifth field: irbpp_config::tuning of the HIP side)
+    n, groups, steps, tuning = int(n), int(groups), int(steps), int(tuning)
     shapes, seqs, kw = make_workload(wl)
     k = int(kw.get("bufferSize", 1))
     seqs = seqs[:2000]
     # (the C-oracle environments of one COracleVecEnv share ONE copy of the tables and trajectories since round 6 -- session 39 of
     # round 5 took 4096 private copies of the 64 x 64 data set's 54 MB, and with them the box -- and step on host threads;
     # tests/test_gpu_large_forms.py runs this comparison as -m gpu tests)
-    genv = GpuVecEnv(shapes, seqs, n, device="cuda:0", num_groups=groups, **kw)
+    genv = GpuVecEnv(shapes, seqs, n, device="cuda:0", num_groups=groups, **(dict(kw, tuning=tuning) if tuning else kw))
     genv.candidates_on_device = True
     cenv = COracleVecEnv(n, shapes, seqs, threads=min(16, os.cpu_count() or 1), **kw)
     t0 = time.time()
