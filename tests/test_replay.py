@@ -288,3 +288,30 @@ def test_fused_sampling_kernel_draws_valid_stratified_positions(capacity, n_step
     lo = torch.arange(B, device="cuda:0")[None, :] * seg
     start = torch.gather(before, 1, data_idx)
     assert bool((start <= lo + seg + 1e-3).all()) and bool((start + prob >= lo - 1e-3).all())
+
+
+@pytest.mark.gpu
+def test_append_kernel_serves_capacities_beyond_the_sum_tree_kernels():
+    """A ring of more than 8192 transitions per env takes the sum-tree calls off the HIP kernels (their LDS row; warned once) --
+    irbpp_replay_append walks the leaf's ancestors in global memory and still serves: every tensor equal to the torch formulation,
+    through a wrap of the ring (capacity not a power of two)."""
+    import warnings
+    rng = np.random.RandomState(11)
+    n_envs, obs_len, cap = 5, 7, 8200
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", RuntimeWarning)
+        hip = VectorReplayMemory(n_envs, cap, obs_len, device="cuda:0")
+    ref = VectorReplayMemory(n_envs, cap, obs_len, device="cuda:0", use_hip=False)
+    assert hip._lib is None and hip._append_hip and not ref._append_hip
+    for t in range(cap + 40):
+        state = torch.from_numpy(rng.uniform(0, 0.3, size=(n_envs, obs_len)).astype(np.float32)).cuda()
+        action = torch.from_numpy(rng.randint(0, 500, size=n_envs).astype(np.int32)).cuda()
+        reward = torch.from_numpy(rng.uniform(0, 1, size=n_envs)).cuda()                  # float64, as the environment hands out
+        terminal = torch.from_numpy((rng.rand(n_envs) < 0.1).astype(np.uint8)).cuda()
+        valid = None if t % 7 else torch.from_numpy(rng.rand(n_envs) < 0.6).cuda()
+        hip.append(state, action, reward, terminal, valid)
+        ref.append(state, action, reward, terminal, valid)
+        if t % 997 == 0 or t >= cap - 3:
+            for name in ("sum_tree", "max", "states", "actions", "rewards", "nonterminals", "timesteps", "index", "full", "t"):
+                assert torch.equal(getattr(hip, name), getattr(ref, name)), (name, t)
+    assert bool(ref.full.any())
