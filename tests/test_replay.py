@@ -303,15 +303,15 @@ def test_append_kernel_serves_capacities_beyond_the_sum_tree_kernels():
         hip = VectorReplayMemory(n_envs, cap, obs_len, device="cuda:0")
     ref = VectorReplayMemory(n_envs, cap, obs_len, device="cuda:0", use_hip=False)
     assert hip._lib is None and hip._append_hip and not ref._append_hip
-    for t in range(cap + 40):
+    for t in range(cap + 200):
         state = torch.from_numpy(rng.uniform(0, 0.3, size=(n_envs, obs_len)).astype(np.float32)).cuda()
         action = torch.from_numpy(rng.randint(0, 500, size=n_envs).astype(np.int32)).cuda()
         reward = torch.from_numpy(rng.uniform(0, 1, size=n_envs)).cuda()                  # float64, as the environment hands out
         terminal = torch.from_numpy((rng.rand(n_envs) < 0.1).astype(np.uint8)).cuda()
-        valid = None if t % 7 else torch.from_numpy(rng.rand(n_envs) < 0.6).cuda()
+        valid = None if t % 41 else torch.from_numpy(rng.rand(n_envs) < 0.6).cuda()
         hip.append(state, action, reward, terminal, valid)
         ref.append(state, action, reward, terminal, valid)
         if t % 997 == 0 or t >= cap - 3:
             for name in ("sum_tree", "max", "states", "actions", "rewards", "nonterminals", "timesteps", "index", "full", "t"):
                 assert torch.equal(getattr(hip, name), getattr(ref, name)), (name, t)
-    assert bool(ref.full.any())
+    assert bool(ref.full.all()) and int(ref.index.min()) > 0             # (every ring has wrapped)
